@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- Kalman steps/s of the MOIHGP hot path on MI355X (BASELINE.json metric).
+
+A "step" of this bench = ONE pass of the per-latent infinite-horizon Kalman recursion + NLL over one
+batch: L latents x T ticks of a pre-projected, HBM-resident, series-major stream (filtered means written,
+per-latent NLL accumulated) -- moihgp_filter_stream() of include/moihgp.h.  One "Kalman step" (the metric's
+unit) = one latent x one tick.  value = N * L * T / seconds_per_pass, whole job.
+
+Default workload (N=1): BASELINE.json's target configuration "M=4096 outputs, T=10000, Matern-5/2, fp32,
+1xMI355X" (configs[2] without its L-BFGS outer loop, which stays on the host).  N>1: every rank owns 4096
+latents of a 4096*N-output model (weak scaling, configs[3] at N=8); the only collective is the RCCL
+all-reduce of the scalar NLL.  Other configs: --config c2 | c3f64.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c2|c3f64] [--no-cpu]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+CONFIGS = {
+    # name: (L per GPU, T, dtype, kernel, description)
+    "c3": (4096, 10000, torch.float32, "Matern52ss", "C3-filter: M=L=4096/GPU, T=10000, Matern-5/2 (matern52ss.h, d=3), fp32, filter+NLL"),
+    "c3f64": (4096, 10000, torch.float64, "Matern52ss", "C3 shape in fp64: M=L=4096/GPU, T=10000, Matern-5/2 (d=3), fp64, filter+NLL"),
+    "c2": (256, 10000, torch.float64, "Matern52ss", "C2: M=L=256, T=10000, Matern-5/2 (d=3), fp64, fixed hyper-parameters, filter+NLL"),
+}
+HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_COPY_GBPS = 6290.0
+SEED = 20260101
+
+
+def synth_params(L, lo, rng):
+    # mag~U(0.5,2), l~U(0.5,2), noise~U(0.05,0.2); drawn for the GLOBAL latent index range
+    return np.column_stack([rng.uniform(0.5, 2, L), rng.uniform(0.5, 2, L), rng.uniform(0.05, 0.2, L)])
+
+
+def synth_stream(L, lo, T, dtype, device, seed):
+    """Ty[l][t] = sin(0.05 t (1 + l mod 7)) + 0.1 N(0,1), generated on the device."""
+    from multioutputihgp_amd.streams import alloc_stream
+    g = torch.Generator(device=device); g.manual_seed(seed)
+    Ty = alloc_stream(L, T, dtype, device)
+    Ty.zero_()
+    t = torch.arange(T, device=device, dtype=torch.float64)[None, :]
+    l = (torch.arange(L, device=device) + lo)[:, None]
+    clean = torch.sin(0.05 * t * (1 + l % 7).to(torch.float64))
+    Ty[:, :T] = (clean + 0.1 * torch.randn((L, T), generator=g, device=device, dtype=torch.float64)).to(dtype)
+    return Ty
+
+
+def cpu_baseline(prm, Ty_host, T, nll_gpu_sum, yhat_gpu_sub, sub):
+    """Time the CPU restatement (oracle/, kind 'port': the reference itself cannot be built here) on this
+    box's host cores, on the same workload; also returns the parity figures of the metric."""
+    from oracle import cref
+    native = True
+    try:
+        cref.build(native=True)
+    except Exception:
+        native = False
+    Lb = cref.lib(native)
+    cores = os.cpu_count() or 1
+    nthreads = min(cores, int(Lb.orc_max_threads()))
+    L = prm.shape[0]
+    igps = cref.ihgp_array("Matern52", 0.1, prm, native=native)
+    f32 = Ty_host.dtype == np.float32
+    # (ii) fair-optimised: fixed-size arrays, -O3 -march=native, OpenMP over latents on all cores
+    reps, t_best = 0, 1e30
+    t_end = time.perf_counter() + 8.0
+    while reps < 3 or (time.perf_counter() < t_end and reps < 50):
+        t0 = time.perf_counter()
+        r = cref.filter_stream(igps, Ty_host, x0=None, want_yhat=True, nthreads=nthreads, native=native)
+        t_best = min(t_best, time.perf_counter() - t0)
+        reps += 1
+    v_opt = L * T / t_best
+    # (i) reference-shaped: single thread, one call per (tick, latent), heap temporaries (fp64 like the reference)
+    import ctypes as C
+    Ls = min(L, 512)
+    Ty64 = np.ascontiguousarray(Ty_host[:Ls].astype(np.float64))
+    x = np.zeros((Ls, 3)); yh = np.zeros_like(Ty64)
+    dp = C.POINTER(C.c_double)
+    t0 = time.perf_counter()
+    Lb.orc_filter_stream_refshaped(igps, Ls, T, Ty64.ctypes.data_as(dp), Ty64.shape[1], 0, x.ctypes.data_as(dp), yh.ctypes.data_as(dp))
+    t_ref = time.perf_counter() - t0
+    v_ref = Ls * T / t_ref
+    # parity figures of the metric: fp64 oracle on identical inputs
+    o64 = cref.filter_stream(igps, np.ascontiguousarray(Ty_host.astype(np.float64)), nthreads=nthreads, native=native)
+    nll_rel = abs(nll_gpu_sum - o64["nll"]) / abs(o64["nll"])
+    mean_rel = float(np.max(np.abs(yhat_gpu_sub - o64["yhat"][sub])) / np.max(np.abs(o64["yhat"][sub])))
+    return dict(
+        value=v_opt, unit="Kalman steps/s", cores=nthreads, kind="port",
+        sample=f"full workload L={L} x T={T} ({'fp32' if f32 else 'fp64'}), best of {reps} passes, oracle/moihgp_oracle.c "
+               f"{'-O3 -march=native' if native else '-O2'} OpenMP over latents",
+        reference_shaped=dict(value=v_ref, cores=1, sample=f"L={Ls} x T={T} fp64, one call per (tick, latent), heap temporaries (BASELINE.md variant i)"),
+    ), nll_rel, mean_rel
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / parity leg")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    assert torch.cuda.is_available(), "bench.py needs a GPU; there is no CPU fallback"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from multioutputihgp_amd.sharded import allreduce_nll, shard_bounds
+    from multioutputihgp_amd.streams import LatentBank
+
+    Lg_per, T, dtype, kernel, desc = CONFIGS[args.config]
+    Lglobal = Lg_per * world
+    lo, hi = shard_bounds(Lglobal, world, rank)
+    L = hi - lo
+    prm_all = synth_params(Lglobal, 0, np.random.default_rng(SEED))
+    prm = prm_all[lo:hi]
+    bank = LatentBank(0.1, prm, kernel=kernel)
+    Ty = synth_stream(L, lo, T, dtype, device, SEED + 1 + rank)
+    yhat = torch.empty_like(Ty)
+    nll = torch.empty((L,), dtype=torch.float64, device=device)
+    x = torch.zeros((L, bank.d), dtype=dtype, device=device)
+
+    def one_pass():
+        x.zero_()
+        bank.filter(Ty, T=T, x=x, yhat=yhat, nll=nll)
+        return allreduce_nll(nll)              # the path's only exchange: 8 bytes, SUM
+
+    for _ in range(args.warmup):
+        total = one_pass()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        x.zero_()
+        ev[k][0].record()
+        bank.filter(Ty, T=T, x=x, yhat=yhat, nll=nll)
+        ev[k][1].record()
+        total = allreduce_nll(nll)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = tmax.item()
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))     # HIP events on the launch stream
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = Lglobal * T / (elapsed / args.steps)
+        es = 4 if dtype == torch.float32 else 8
+        alg_bytes = 2 * es * L * T                      # SURVEY 8d mode F: read Ty + write Tyhat = 2*s B per Kalman step
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(args.config, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Kalman steps/sec (M outputs x T ticks) + NLL rel-err vs CPU oracle",
+            "value": value, "unit": "Kalman steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if dtype == torch.float32 else "f64", "data": "synthetic",
+            "config": {"workload": desc, "latents_per_gpu": Lg_per, "latents_total": Lglobal, "ticks": T, "state_dim": bank.d,
+                       "layout": "series-major [L][ld], HBM-resident", "sharding": f"latents x{world}, NLL scalar all-reduce"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": traffic, "kernel": "filter_scan_kernel", "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes, "frac_of_measured_copy_peak": achieved / HBM_COPY_GBPS},
+            "nll_total": float(total.item()),
+        }
+        if world == 1 and not args.no_cpu:
+            sub = np.arange(0, L, max(1, L // 64))[:64]
+            cb, nll_rel, mean_rel = cpu_baseline(prm, Ty[:, :T].cpu().numpy(), T, float(total.item()), yhat[sub][:, :T].double().cpu().numpy(), sub)
+            out["cpu_baseline"] = cb
+            out["nll_rel_err"] = nll_rel
+            out["filtered_mean_rel_err"] = mean_rel
+            out["speedup_vs_cpu_all_cores"] = value / cb["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,161 @@
+/* moihgp.h -- C ABI of libmoihgp.so (MI355X / gfx950 HIP implementation).
+ *
+ * Part 1 is the drop-in boundary: the exact 28 symbols the reference exports from
+ * moihgp/src/wrapper.cpp and that moihgp/pywrapper.py binds through ctypes
+ * (pywrapper.py:28-94).  Signatures, buffer layouts and ownership are the reference's:
+ * every pointer is a caller-owned host buffer of C-contiguous doubles, valid for the
+ * duration of the call only.
+ *     x, xnew   [L][d]          (wrapper.cpp:63,84)
+ *     dx, dxnew [L][P][d]       (wrapper.cpp:69,90)
+ *     y, yhat   [M]
+ *     params, grad [M*L + L + 1 + L*P] = U row-major | S | sigma | (magnitude, lengthscale, noise) x L
+ *                               (moihgp.h:93, :431-457, :721-738)
+ * All arithmetic behind these symbols runs in HIP kernels on the current device; there is no
+ * CPU fallback.  If no usable GPU is present `*_new` returns NULL and moihgp_last_error()
+ * says why; any later HIP failure prints the error and aborts (the reference ABI has no
+ * status channel, wrapper.cpp:31-326).
+ *
+ * Part 2 is additive: batched entry points over whole time streams (the per-tick ABI costs one
+ * FFI crossing + several launches per tick and cannot amortise them), taking DEVICE pointers.
+ *
+ * Citations `file:line` are into the reference tree /root/reference/moihgp/.
+ */
+#ifndef MOIHGP_C_API_H_
+#define MOIHGP_C_API_H_
+
+#include <stddef.h>
+#include <stdbool.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ Part 1: reference ABI */
+/* Opaque handle; the reference returns `GP32*` / `GP52*` (src/wrapper.cpp:21-22).            */
+typedef struct moihgp_gp moihgp_gp;
+
+/* replaces src/wrapper.cpp:31-34  (MOIHGP ctor, include/moihgp/moihgp.h:81-136).  `threading`
+ * is accepted and ignored: it only selects the reference's per-call pthread fan-out
+ * (moihgp.h:184-214), which the GPU replaces. */
+moihgp_gp* gp32_new(double dt, size_t num_output, size_t num_latent, bool threading);
+/* replaces src/wrapper.cpp:37-40 (which runs the destructor but leaks the object; we free it) */
+void   gp32_del(moihgp_gp* gp);
+/* replaces src/wrapper.cpp:43-94   -> MOIHGP::step overload 1, moihgp.h:148-226 */
+void   gp32_step1(moihgp_gp* gp, double* x, double* y, double* dx, double* xnew, double* yhat, double* dxnew);
+/* replaces src/wrapper.cpp:97-145  -> MOIHGP::step overload 2, moihgp.h:229-301 */
+void   gp32_step2(moihgp_gp* gp, double* x, double* y, double* dx, double* xnew, double* dxnew);
+/* replaces src/wrapper.cpp:148-184 -> MOIHGP::step overload 3, moihgp.h:304-378 */
+void   gp32_step3(moihgp_gp* gp, double* x, double* y, double* xnew, double* yhat);
+/* replaces src/wrapper.cpp:187-220 -> MOIHGP::step overload 4, moihgp.h:381-428 */
+void   gp32_step4(moihgp_gp* gp, double* x, double* xnew, double* yhat);
+/* replaces src/wrapper.cpp:223-228 -> MOIHGP::update, moihgp.h:431-457 (+ IHGP::update, ihgp.h:117-201) */
+void   gp32_update(moihgp_gp* gp, double* params);
+/* replaces src/wrapper.cpp:231-268 -> MOIHGP::negLogLikelihood(x,y,dx,grad), moihgp.h:460-611 */
+double gp32_lik1(moihgp_gp* gp, double* x, double* y, double* dx, double* grad);
+/* replaces src/wrapper.cpp:271-296 -> MOIHGP::negLogLikelihood(x,y), moihgp.h:614-688 */
+double gp32_lik2(moihgp_gp* gp, double* x, double* y);
+/* replaces src/wrapper.cpp:299-307 -> MOIHGP::getParams, moihgp.h:721-738 */
+void   gp32_get_params(moihgp_gp* gp, double* params);
+/* replace src/wrapper.cpp:310-325 */
+size_t gp32_igp_dim(moihgp_gp* gp);
+size_t gp32_num_param(moihgp_gp* gp);
+size_t gp32_num_igp_param(moihgp_gp* gp);
+
+/* replaces src/wrapper.cpp:329-624.  NOTE: in the reference `GP52` is a typedef of the
+ * Matern-3/2 model (typo alias, wrapper.cpp:22), so gp52_* behave exactly like gp32_*.
+ * That behaviour is kept by default.  Set the environment variable MOIHGP_GP52_MATERN52=1
+ * (read at gp52_new) to get the real Matern-5/2 model of include/moihgp/matern52ss.h, or
+ * use moihgp_new(MOIHGP_MATERN52, ...). */
+moihgp_gp* gp52_new(double dt, size_t num_output, size_t num_latent, bool threading);
+void   gp52_del(moihgp_gp* gp);
+void   gp52_step1(moihgp_gp* gp, double* x, double* y, double* dx, double* xnew, double* yhat, double* dxnew);
+void   gp52_step2(moihgp_gp* gp, double* x, double* y, double* dx, double* xnew, double* dxnew);
+void   gp52_step3(moihgp_gp* gp, double* x, double* y, double* xnew, double* yhat);
+void   gp52_step4(moihgp_gp* gp, double* x, double* xnew, double* yhat);
+void   gp52_update(moihgp_gp* gp, double* params);
+double gp52_lik1(moihgp_gp* gp, double* x, double* y, double* dx, double* grad);
+double gp52_lik2(moihgp_gp* gp, double* x, double* y);
+void   gp52_get_params(moihgp_gp* gp, double* params);
+size_t gp52_igp_dim(moihgp_gp* gp);
+size_t gp52_num_param(moihgp_gp* gp);
+size_t gp52_num_igp_param(moihgp_gp* gp);
+
+/* ------------------------------------------------------------------ Part 2: additive ABI */
+enum { MOIHGP_MATERN32 = 0, MOIHGP_MATERN52 = 1 };
+enum { MOIHGP_F64 = 0, MOIHGP_F32 = 1 };
+
+/* Thread-local message of the last failure ("" if none). */
+const char* moihgp_last_error(void);
+/* Number of usable HIP devices (0 if none / runtime missing). */
+int         moihgp_device_count(void);
+/* Library/ABI version: major*10000 + minor*100 + patch. */
+int         moihgp_version(void);
+
+/* Same object as gp32_new/gp52_new with an explicit kernel (the StateSpace template argument of
+ * moihgp::MOIHGP<SS>, include/moihgp/moihgp.h:76).  Returns NULL on failure. */
+moihgp_gp*  moihgp_new(int kernel, double dt, size_t num_output, size_t num_latent);
+void        moihgp_del(moihgp_gp* gp);
+size_t      moihgp_num_output(moihgp_gp* gp);
+size_t      moihgp_num_latent(moihgp_gp* gp);
+
+/* Deterministic counterpart of the ctor's random U (moihgp.h:103-125 uses std::random_device):
+ * reseeds and redraws U = polar(I + N(0,1e-3)) from a fixed 64-bit seed. */
+void        moihgp_reseed_U(moihgp_gp* gp, unsigned long long seed);
+
+/* Latent-sharded construction: the object owns latents [l0, l0+nl) only and takes only
+ * their (magnitude, lengthscale, noise) triples; no mixing matrix.  Used by one rank per GPU.
+ * params_LP is a HOST array [nl][3]. */
+moihgp_gp*  moihgp_new_latents(int kernel, double dt, size_t num_latent_local, const double* params_LP);
+/* Re-run IHGP::update (ihgp.h:117-201) for every owned latent from HOST params [nl][3]. */
+int         moihgp_update_latents(moihgp_gp* gp, const double* params_LP);
+
+/* Copy the stationary matrices of latent l (ihgp.h:243-254) to HOST buffers (any may be NULL):
+ * A[d*d] K[d] S[1] HA[d] AKHA[d*d] dA[P*d*d] dS[P] dK[P*d] dAKHA[P*d*d] HdA[P*d], row-major;
+ * iters[1+P] = DARE iteration count followed by the P DLyap counts (utils/dare.h returns are ignored
+ * by the reference; exposed here for diagnosis). */
+int         moihgp_get_latent(moihgp_gp* gp, size_t l, double* A, double* K, double* S, double* HA, double* AKHA,
+                              double* dA, double* dS, double* dK, double* dAKHA, double* HdA, int* iters);
+
+/* ---- batched recursion over pre-projected streams (DEVICE pointers) -------------------------
+ * The stream is SERIES-MAJOR: Ty[l*ld + t], l < L (latents owned by gp), t < T, element type per
+ * `dtype`.  Requirements: base pointers 16-byte aligned; ld*sizeof(elem) a multiple of 16 and
+ * ld >= T rounded up to a multiple of 16/sizeof(elem).
+ *
+ * For every latent, sequentially in t (order of moihgp_online.h:61-70 / moihgp_regression.h:45-49):
+ *     v = y_t - HA x            (pre-step state; ihgp.h:206)
+ *     nll += 1/2 (v^2/S + log S)                       (ihgp.h:207)
+ *     x <- AKHA x + K y_t ;  yhat_t = x[0]             (ihgp.h:90-91)
+ * A NaN y_t takes the missing-data branch x <- A x (ihgp.h:83-87) and contributes no NLL term.
+ *
+ *   x        [L][d]  in: state before tick 0; out: state after tick T-1   (dtype)
+ *   yhat     [L][ld] or NULL                                              (dtype)
+ *   nll      [L] doubles or NULL: per-latent sum of ihgp.h:207 terms (always fp64)
+ *   stream   hipStream_t (NULL = default stream).  The call is asynchronous.
+ * Returns 0 on success, nonzero on invalid arguments (see moihgp_last_error()).            */
+int moihgp_filter_stream(moihgp_gp* gp, int dtype, const void* Ty, size_t T, size_t ld,
+                         void* x, void* yhat, double* nll, void* stream);
+
+/* As above plus the hyper-parameter sensitivities (ihgp.h:54) and the per-latent NLL gradient
+ * (ihgp.h:216-220), summed over ticks:
+ *   dx   [L][P][d] in/out (dtype);  grad [L][P] doubles out. */
+int moihgp_grad_stream(moihgp_gp* gp, int dtype, const void* Ty, size_t T, size_t ld,
+                       void* x, void* dx, void* yhat, double* nll, double* grad, void* stream);
+
+/* ---- OILMM projection over whole streams (DEVICE pointers) ----------------------------------
+ * Y is TICK-MAJOR [T][M] (a stream of observation vectors, as the reference's callers hold it,
+ * example.py:40-42); the projected stream comes out series-major [L][ld] ready for the recursion:
+ *     Ty[l][t] = S_l^-1/2 * sum_m U[m][l] Y[t][m]                 (moihgp.h:181)
+ * and back:  Yhat[t][m] = sum_l U[m][l] S_l^1/2 Tyhat[l][t]       (moihgp.h:222-225)
+ * Rows with NaNs are NOT handled here (they need the least-squares projection, moihgp.h:167-178):
+ * moihgp_project_stream returns the number of ticks containing NaN in *n_nan_ticks (host int,
+ * may be NULL; forces a sync) and leaves NaN in Ty for those ticks. */
+int moihgp_project_stream(moihgp_gp* gp, int dtype, const void* Y, size_t T, void* Ty, size_t ld, void* stream);
+int moihgp_unproject_stream(moihgp_gp* gp, int dtype, const void* Tyhat, size_t T, size_t ld, void* Yhat, void* stream);
+
+/* Stream synchronisation helper for callers without a HIP runtime binding. */
+int moihgp_stream_sync(void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOIHGP_C_API_H_ */

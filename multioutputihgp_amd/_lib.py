@@ -1,0 +1,97 @@
+"""ctypes loader for lib/libmoihgp.so (the C ABI declared in include/moihgp.h)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+c_double_p = C.POINTER(C.c_double)
+
+# every symbol include/moihgp.h declares
+REFERENCE_SYMBOLS = [
+    f"{pfx}_{name}"
+    for pfx in ("gp32", "gp52")
+    for name in ("new", "del", "step1", "step2", "step3", "step4", "update", "lik1", "lik2",
+                 "get_params", "igp_dim", "num_param", "num_igp_param")
+]
+ADDITIVE_SYMBOLS = [
+    "moihgp_last_error", "moihgp_device_count", "moihgp_version", "moihgp_new", "moihgp_del",
+    "moihgp_num_output", "moihgp_num_latent", "moihgp_reseed_U", "moihgp_new_latents",
+    "moihgp_update_latents", "moihgp_get_latent", "moihgp_filter_stream", "moihgp_grad_stream",
+    "moihgp_project_stream", "moihgp_unproject_stream", "moihgp_stream_sync",
+]
+
+
+class MoihgpError(RuntimeError):
+    pass
+
+
+def library_path() -> str:
+    # same relative location the reference loads from (pywrapper.py:22)
+    return os.path.join(_HERE, "lib", "libmoihgp.so")
+
+
+def load_library():
+    """Load libmoihgp.so and declare prototypes.  Raises if the HIP library is missing:
+    the product has no other implementation to fall back to."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    # torch bundles its own libamdhip64 (same SONAME).  Importing it first makes the dynamic loader
+    # resolve our NEEDED libamdhip64.so.7 to that already-loaded copy, so tensors, streams and our
+    # kernels share ONE HIP runtime.  Without torch the system ROCm runtime is used.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    if not os.path.exists(path):
+        raise MoihgpError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C multioutputihgp_amd/csrc` (needs hipcc); there is no CPU fallback")
+    lib = C.CDLL(path)
+    for pfx in ("gp32", "gp52"):
+        f = getattr(lib, f"{pfx}_new"); f.restype = C.c_void_p; f.argtypes = [C.c_double, C.c_size_t, C.c_size_t, C.c_bool]
+        f = getattr(lib, f"{pfx}_del"); f.restype = None; f.argtypes = [C.c_void_p]
+        for name, n in (("step1", 6), ("step2", 5), ("step3", 4), ("step4", 3), ("update", 1), ("get_params", 1)):
+            f = getattr(lib, f"{pfx}_{name}"); f.restype = None; f.argtypes = [C.c_void_p] + [c_double_p] * n
+        f = getattr(lib, f"{pfx}_lik1"); f.restype = C.c_double; f.argtypes = [C.c_void_p] + [c_double_p] * 4
+        f = getattr(lib, f"{pfx}_lik2"); f.restype = C.c_double; f.argtypes = [C.c_void_p] + [c_double_p] * 2
+        for name in ("igp_dim", "num_param", "num_igp_param"):
+            f = getattr(lib, f"{pfx}_{name}"); f.restype = C.c_size_t; f.argtypes = [C.c_void_p]
+    lib.moihgp_last_error.restype = C.c_char_p
+    lib.moihgp_device_count.restype = C.c_int
+    lib.moihgp_version.restype = C.c_int
+    lib.moihgp_new.restype = C.c_void_p
+    lib.moihgp_new.argtypes = [C.c_int, C.c_double, C.c_size_t, C.c_size_t]
+    lib.moihgp_del.restype = None
+    lib.moihgp_del.argtypes = [C.c_void_p]
+    lib.moihgp_num_output.restype = C.c_size_t; lib.moihgp_num_output.argtypes = [C.c_void_p]
+    lib.moihgp_num_latent.restype = C.c_size_t; lib.moihgp_num_latent.argtypes = [C.c_void_p]
+    lib.moihgp_reseed_U.restype = None; lib.moihgp_reseed_U.argtypes = [C.c_void_p, C.c_ulonglong]
+    lib.moihgp_new_latents.restype = C.c_void_p
+    lib.moihgp_new_latents.argtypes = [C.c_int, C.c_double, C.c_size_t, c_double_p]
+    lib.moihgp_update_latents.restype = C.c_int
+    lib.moihgp_update_latents.argtypes = [C.c_void_p, c_double_p]
+    lib.moihgp_get_latent.restype = C.c_int
+    lib.moihgp_get_latent.argtypes = [C.c_void_p, C.c_size_t] + [c_double_p] * 10 + [C.POINTER(C.c_int)]
+    lib.moihgp_filter_stream.restype = C.c_int
+    lib.moihgp_filter_stream.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.moihgp_grad_stream.restype = C.c_int
+    lib.moihgp_grad_stream.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.moihgp_project_stream.restype = C.c_int
+    lib.moihgp_project_stream.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.moihgp_unproject_stream.restype = C.c_int
+    lib.moihgp_unproject_stream.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
+    lib.moihgp_stream_sync.restype = C.c_int
+    lib.moihgp_stream_sync.argtypes = [C.c_void_p]
+    _LIB = lib
+    return lib
+
+
+def last_error(lib=None) -> str:
+    lib = lib or load_library()
+    msg = lib.moihgp_last_error()
+    return msg.decode() if msg else ""

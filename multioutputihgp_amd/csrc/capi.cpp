@@ -1,0 +1,420 @@
+// capi.cpp -- the C ABI of libmoihgp.so: the reference's 28 gp32_*/gp52_* symbols
+// (reference moihgp/src/wrapper.cpp:31-624) plus the additive batched entries of include/moihgp.h.
+//
+// Host side = parameter bookkeeping + kernel orchestration only.  Every arithmetic step of the
+// reference path runs in a HIP kernel (stationary.hip, tick.hip, recursion.hip, oilmm.hip); the one
+// exception this round is the polar factor of the mixing matrix in update() (moihgp.h:433-447), a
+// once-per-update O(M L^2) host routine (SURVEY 8f N4 schedules its device form).
+#include "../../include/moihgp.h"
+#include "common.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+
+namespace moihgp {
+
+static thread_local char g_last_error[512] = "";
+
+void set_last_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
+    va_end(ap);
+}
+
+[[noreturn]] void fatal_hip(hipError_t e, const char* what, const char* file, int line) {
+    // The reference ABI has no status channel (all void / value returns, wrapper.cpp:31-326), so a
+    // device failure cannot be reported to the caller: say what happened and stop.
+    std::fprintf(stderr, "libmoihgp: HIP error %d (%s) at %s:%d: %s\n", (int)e, hipGetErrorString(e), file, line, what);
+    std::abort();
+}
+
+// ---- polar factor  svdU * svdV^T  (moihgp.h:438-446) by one-sided Jacobi rotations ---------------
+// Columns of W = Uparam are rotated pairwise until mutually orthogonal (W = Uparam * V); then
+// polar = W * diag(1/|w_j|) * V^T.  Unique for full column rank, so any convergent SVD gives the
+// same matrix as Eigen's BDCSVD/JacobiSVD up to rounding.
+static bool polar_factor(size_t M, size_t L, const double* Ain, double* out) {
+    if (M < L || L == 0) return false;
+    std::vector<double> W(Ain, Ain + M * L), V(L * L, 0.0);
+    for (size_t i = 0; i < L; i++) V[i * L + i] = 1.0;
+    const double eps = 2.220446049250313e-16;
+    for (int sweep = 0; sweep < 80; sweep++) {
+        bool rotated = false;
+        for (size_t p = 0; p + 1 < L; p++) {
+            for (size_t q = p + 1; q < L; q++) {
+                double a = 0, b = 0, c = 0;
+                for (size_t i = 0; i < M; i++) {
+                    const double wp = W[i * L + p], wq = W[i * L + q];
+                    a += wp * wp; b += wq * wq; c += wp * wq;
+                }
+                if (c == 0.0 || std::fabs(c) <= eps * std::sqrt(a * b)) continue;
+                rotated = true;
+                const double zeta = (b - a) / (2.0 * c);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+                const double cs = 1.0 / std::sqrt(1.0 + t * t), sn = cs * t;
+                for (size_t i = 0; i < M; i++) {
+                    const double wp = W[i * L + p], wq = W[i * L + q];
+                    W[i * L + p] = cs * wp - sn * wq;
+                    W[i * L + q] = sn * wp + cs * wq;
+                }
+                for (size_t i = 0; i < L; i++) {
+                    const double vp = V[i * L + p], vq = V[i * L + q];
+                    V[i * L + p] = cs * vp - sn * vq;
+                    V[i * L + q] = sn * vp + cs * vq;
+                }
+            }
+        }
+        if (!rotated) break;
+    }
+    for (size_t j = 0; j < L; j++) {
+        double s = 0;
+        for (size_t i = 0; i < M; i++) s += W[i * L + j] * W[i * L + j];
+        s = std::sqrt(s);
+        if (!(s > 0.0)) return false;
+        for (size_t i = 0; i < M; i++) W[i * L + j] /= s;
+    }
+    for (size_t i = 0; i < M; i++)
+        for (size_t j = 0; j < L; j++) {
+            double s = 0;
+            for (size_t k = 0; k < L; k++) s += W[i * L + k] * V[j * L + k];
+            out[i * L + j] = s;
+        }
+    return true;
+}
+
+template <typename T>
+static T* dev_alloc(size_t n) {
+    void* p = nullptr;
+    MOIHGP_HIP_FATAL(hipMalloc(&p, (n ? n : 1) * sizeof(T)));
+    return static_cast<T*>(p);
+}
+
+}  // namespace moihgp
+
+using namespace moihgp;
+
+struct moihgp_gp {
+    int kernel = 0;
+    double dt = 0;
+    size_t M = 0, L = 0;
+    int d = 2, P = kNumIgpParam;
+    size_t num_param = 0;
+    bool latents_only = false;
+    // host mirrors of the parameters (moihgp.h:741-744 + per-latent matern*ss.h:_params)
+    std::vector<double> U, S, igp;
+    double sigma = 1e-2;
+    // device state
+    hipStream_t stream = nullptr;
+    double *dU = nullptr, *dS = nullptr, *dsigma = nullptr, *dparams = nullptr, *cb64 = nullptr;
+    float* cb32 = nullptr;
+    // per-tick staging
+    double *dx = nullptr, *dy = nullptr, *ddx = nullptr, *dxnew = nullptr, *dyhat = nullptr, *ddxnew = nullptr;
+    double *dTy = nullptr, *dUty = nullptr, *dTyhat = nullptr, *dloss = nullptr, *dgrad = nullptr, *dscratch = nullptr;
+    double* dwork = nullptr;   // L*L + L, lazily (missing-output projection)
+
+    TickArgs tick() const { return TickArgs{d, M, L, cb64, dU, dS, dsigma}; }
+};
+
+static void gp_free(moihgp_gp* g) {
+    if (!g) return;
+    void* ptrs[] = {g->dU, g->dS, g->dsigma, g->dparams, g->cb64, g->cb32, g->dx, g->dy, g->ddx, g->dxnew, g->dyhat,
+                    g->ddxnew, g->dTy, g->dUty, g->dTyhat, g->dloss, g->dgrad, g->dscratch, g->dwork};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (g->stream) (void)hipStreamDestroy(g->stream);
+    delete g;
+}
+
+static void upload_mixing(moihgp_gp* g) {
+    if (g->latents_only) return;
+    MOIHGP_HIP_FATAL(hipMemcpyAsync(g->dU, g->U.data(), sizeof(double) * g->M * g->L, hipMemcpyHostToDevice, g->stream));
+    MOIHGP_HIP_FATAL(hipMemcpyAsync(g->dS, g->S.data(), sizeof(double) * g->L, hipMemcpyHostToDevice, g->stream));
+    MOIHGP_HIP_FATAL(hipMemcpyAsync(g->dsigma, &g->sigma, sizeof(double), hipMemcpyHostToDevice, g->stream));
+}
+
+static void run_ihgp_update(moihgp_gp* g) {
+    MOIHGP_HIP_FATAL(hipMemcpyAsync(g->dparams, g->igp.data(), sizeof(double) * g->L * g->P, hipMemcpyHostToDevice, g->stream));
+    launch_ihgp_update(g->kernel, g->d, g->dt, g->dparams, g->L, g->cb64, g->cb32, g->stream);
+    MOIHGP_HIP_FATAL(hipStreamSynchronize(g->stream));
+}
+
+static void draw_U(moihgp_gp* g, unsigned long long seed, bool use_seed) {
+    // moihgp.h:103-125: U = polar(I + N(0, 1e-3))
+    std::mt19937 gen;
+    if (use_seed) gen.seed((unsigned)(seed ^ (seed >> 32)));
+    else { std::random_device rd; gen.seed(rd()); }
+    std::normal_distribution<> distr(0.0, 1e-3);
+    std::vector<double> I(g->M * g->L, 0.0);
+    for (size_t r = 0; r < g->M; r++)
+        for (size_t c = 0; c < g->L; c++) I[r * g->L + c] = (r == c ? 1.0 : 0.0) + distr(gen);
+    polar_factor(g->M, g->L, I.data(), g->U.data());
+}
+
+static moihgp_gp* gp_create(int kernel, double dt, size_t M, size_t L, bool latents_only, const double* params_LP) {
+    g_last_error[0] = 0;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        set_last_error("libmoihgp: no usable HIP device (%s); this library has no CPU fallback",
+                       e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+        std::fprintf(stderr, "%s\n", g_last_error);
+        return nullptr;
+    }
+    if (kernel != MOIHGP_MATERN32 && kernel != MOIHGP_MATERN52) { set_last_error("unknown kernel id %d", kernel); return nullptr; }
+    if (L == 0) { set_last_error("num_latent must be >= 1"); return nullptr; }
+    if (!latents_only && M < L) {
+        // moihgp.h:510 indexes y(idx) for idx < num_latent and the thin SVD needs full column rank
+        set_last_error("num_output (%zu) must be >= num_latent (%zu)", M, L);
+        return nullptr;
+    }
+    moihgp_gp* g = new moihgp_gp();
+    g->kernel = kernel; g->dt = dt; g->M = M; g->L = L; g->latents_only = latents_only;
+    g->d = (kernel == MOIHGP_MATERN32) ? 2 : 3;                          // matern32ss.h:95, matern52ss.h:106
+    g->num_param = M * L + L + 1 + L * g->P;                             // moihgp.h:93
+    MOIHGP_HIP_FATAL(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+    const size_t cbs = (size_t)cb_size(g->d);
+    g->dparams = dev_alloc<double>(L * g->P);
+    g->cb64 = dev_alloc<double>(L * cbs);
+    g->cb32 = dev_alloc<float>(L * cbs);
+    g->igp.resize(L * g->P);
+    for (size_t l = 0; l < L; l++) {
+        if (params_LP) for (int p = 0; p < g->P; p++) g->igp[l * g->P + p] = params_LP[l * g->P + p];
+        else { g->igp[l * g->P + 0] = 1.0; g->igp[l * g->P + 1] = 1.0; g->igp[l * g->P + 2] = 0.1; }   // matern32ss.h:34-36
+    }
+    if (!latents_only) {
+        g->U.assign(M * L, 0.0);
+        g->S.assign(L, 1.0);                                             // moihgp.h:126
+        g->sigma = 1e-2;                                                 // moihgp.h:127
+        draw_U(g, 0, false);
+        g->dU = dev_alloc<double>(M * L);
+        g->dS = dev_alloc<double>(L);
+        g->dsigma = dev_alloc<double>(1);
+        g->dx = dev_alloc<double>(L * g->d);
+        g->dxnew = dev_alloc<double>(L * g->d);
+        g->ddx = dev_alloc<double>(L * g->P * g->d);
+        g->ddxnew = dev_alloc<double>(L * g->P * g->d);
+        g->dy = dev_alloc<double>(M);
+        g->dyhat = dev_alloc<double>(M);
+        g->dTy = dev_alloc<double>(L);
+        g->dUty = dev_alloc<double>(L);
+        g->dTyhat = dev_alloc<double>(L);
+        g->dloss = dev_alloc<double>(1);
+        g->dgrad = dev_alloc<double>(g->num_param);
+        g->dscratch = dev_alloc<double>(2 * L + L * g->P + M + 8);
+        upload_mixing(g);
+    }
+    run_ihgp_update(g);                                                  // moihgp.h:86-90 -> ihgp.h:33
+    return g;
+}
+
+// ---- per-tick paths (moihgp.h:148-428) ----------------------------------------------------------
+static bool has_nan(const double* y, size_t n) {                       // moihgp.h:150-158
+    for (size_t i = 0; i < n; i++)
+        if (y[i] != y[i]) return true;
+    return false;
+}
+
+static void do_project(moihgp_gp* g, const double* y_host) {
+    MOIHGP_HIP_FATAL(hipMemcpyAsync(g->dy, y_host, sizeof(double) * g->M, hipMemcpyHostToDevice, g->stream));
+    TickArgs a = g->tick();
+    launch_project_tick(a, g->dy, g->dTy, g->dUty, nullptr, g->stream);   // moihgp.h:181
+    if (has_nan(y_host, g->M)) {                                         // moihgp.h:167-178
+        if (!g->dwork) g->dwork = dev_alloc<double>(g->L * g->L + g->L);
+        launch_project_tick_missing(a, g->dy, g->dTy, g->dwork, g->stream);
+    }
+}
+
+static void do_step(moihgp_gp* g, const double* x, const double* y, const double* dx, double* xnew, double* yhat, double* dxnew) {
+    if (g->latents_only) { set_last_error("per-tick ABI needs a full MOIHGP object"); std::fprintf(stderr, "%s\n", g_last_error); std::abort(); }
+    const size_t L = g->L, d = g->d, P = g->P;
+    MOIHGP_HIP_FATAL(hipMemcpyAsync(g->dx, x, sizeof(double) * L * d, hipMemcpyHostToDevice, g->stream));
+    if (dx) MOIHGP_HIP_FATAL(hipMemcpyAsync(g->ddx, dx, sizeof(double) * L * P * d, hipMemcpyHostToDevice, g->stream));
+    if (y) do_project(g, y);
+    TickArgs a = g->tick();
+    launch_step_tick(a, g->dx, y ? g->dTy : nullptr, dx ? g->ddx : nullptr, g->dxnew, g->dTyhat, dx ? g->ddxnew : nullptr, g->stream);
+    if (yhat) {
+        launch_unproject_tick(a, g->dTyhat, g->dyhat, g->stream);
+        MOIHGP_HIP_FATAL(hipMemcpyAsync(yhat, g->dyhat, sizeof(double) * g->M, hipMemcpyDeviceToHost, g->stream));
+    }
+    MOIHGP_HIP_FATAL(hipMemcpyAsync(xnew, g->dxnew, sizeof(double) * L * d, hipMemcpyDeviceToHost, g->stream));
+    if (dx && dxnew) MOIHGP_HIP_FATAL(hipMemcpyAsync(dxnew, g->ddxnew, sizeof(double) * L * P * d, hipMemcpyDeviceToHost, g->stream));
+    MOIHGP_HIP_FATAL(hipStreamSynchronize(g->stream));
+}
+
+static double do_lik(moihgp_gp* g, const double* x, const double* y, const double* dx, double* grad) {
+    if (g->latents_only) { set_last_error("per-tick ABI needs a full MOIHGP object"); std::fprintf(stderr, "%s\n", g_last_error); std::abort(); }
+    const size_t L = g->L, d = g->d, P = g->P;
+    MOIHGP_HIP_FATAL(hipMemcpyAsync(g->dx, x, sizeof(double) * L * d, hipMemcpyHostToDevice, g->stream));
+    if (dx) MOIHGP_HIP_FATAL(hipMemcpyAsync(g->ddx, dx, sizeof(double) * L * P * d, hipMemcpyHostToDevice, g->stream));
+    do_project(g, y);
+    TickArgs a = g->tick();
+    launch_nll_tick(a, g->dx, g->dy, g->dTy, g->dUty, dx ? g->ddx : nullptr, g->dloss, g->dgrad, g->dscratch, g->stream);
+    double loss = 0.0;
+    MOIHGP_HIP_FATAL(hipMemcpyAsync(&loss, g->dloss, sizeof(double), hipMemcpyDeviceToHost, g->stream));
+    if (dx && grad) MOIHGP_HIP_FATAL(hipMemcpyAsync(grad, g->dgrad, sizeof(double) * g->num_param, hipMemcpyDeviceToHost, g->stream));
+    MOIHGP_HIP_FATAL(hipStreamSynchronize(g->stream));
+    return loss;
+}
+
+static void do_update(moihgp_gp* g, const double* params) {          // moihgp.h:431-457
+    const size_t M = g->M, L = g->L, sizeU = M * L;
+    if (!polar_factor(M, L, params, g->U.data())) {
+        set_last_error("update: mixing matrix is rank deficient");
+        std::fprintf(stderr, "libmoihgp: %s\n", g_last_error);
+        for (auto& u : g->U) u = std::nan("");
+    }
+    for (size_t l = 0; l < L; l++) g->S[l] = params[sizeU + l];          // moihgp.h:448
+    g->sigma = params[sizeU + L];                                        // moihgp.h:449
+    for (size_t i = 0; i < L * (size_t)g->P; i++) g->igp[i] = params[sizeU + L + 1 + i];   // moihgp.h:450-456
+    upload_mixing(g);
+    run_ihgp_update(g);
+}
+
+static void do_get_params(moihgp_gp* g, double* params) {            // moihgp.h:721-738
+    const size_t M = g->M, L = g->L, sizeU = M * L;
+    std::memcpy(params, g->U.data(), sizeof(double) * sizeU);
+    std::memcpy(params + sizeU, g->S.data(), sizeof(double) * L);
+    params[sizeU + L] = g->sigma;
+    std::memcpy(params + sizeU + L + 1, g->igp.data(), sizeof(double) * L * g->P);
+}
+
+static int gp52_kernel() {
+    // wrapper.cpp:22 typedefs GP52 to the Matern-3/2 model; keep that unless told otherwise.
+    const char* e = std::getenv("MOIHGP_GP52_MATERN52");
+    return (e && e[0] == '1') ? MOIHGP_MATERN52 : MOIHGP_MATERN32;
+}
+
+extern "C" {
+
+#define MOIHGP_DEFINE_REFERENCE_ABI(PFX, KERNEL_EXPR)                                                                   \
+    moihgp_gp* PFX##_new(double dt, size_t num_output, size_t num_latent, bool threading) {                             \
+        (void)threading;                                                                                                 \
+        return gp_create((KERNEL_EXPR), dt, num_output, num_latent, false, nullptr);                                     \
+    }                                                                                                                    \
+    void PFX##_del(moihgp_gp* gp) { gp_free(gp); }                                                                       \
+    void PFX##_step1(moihgp_gp* gp, double* x, double* y, double* dx, double* xnew, double* yhat, double* dxnew) {       \
+        do_step(gp, x, y, dx, xnew, yhat, dxnew);                                                                        \
+    }                                                                                                                    \
+    void PFX##_step2(moihgp_gp* gp, double* x, double* y, double* dx, double* xnew, double* dxnew) {                     \
+        do_step(gp, x, y, dx, xnew, nullptr, dxnew);                                                                     \
+    }                                                                                                                    \
+    void PFX##_step3(moihgp_gp* gp, double* x, double* y, double* xnew, double* yhat) {                                  \
+        do_step(gp, x, y, nullptr, xnew, yhat, nullptr);                                                                 \
+    }                                                                                                                    \
+    void PFX##_step4(moihgp_gp* gp, double* x, double* xnew, double* yhat) {                                             \
+        do_step(gp, x, nullptr, nullptr, xnew, yhat, nullptr);                                                           \
+    }                                                                                                                    \
+    void PFX##_update(moihgp_gp* gp, double* params) { do_update(gp, params); }                                          \
+    double PFX##_lik1(moihgp_gp* gp, double* x, double* y, double* dx, double* grad) { return do_lik(gp, x, y, dx, grad); } \
+    double PFX##_lik2(moihgp_gp* gp, double* x, double* y) { return do_lik(gp, x, y, nullptr, nullptr); }                \
+    void PFX##_get_params(moihgp_gp* gp, double* params) { do_get_params(gp, params); }                                  \
+    size_t PFX##_igp_dim(moihgp_gp* gp) { return (size_t)gp->d; }                                                        \
+    size_t PFX##_num_param(moihgp_gp* gp) { return gp->num_param; }                                                      \
+    size_t PFX##_num_igp_param(moihgp_gp* gp) { return (size_t)gp->P; }
+
+MOIHGP_DEFINE_REFERENCE_ABI(gp32, MOIHGP_MATERN32)
+MOIHGP_DEFINE_REFERENCE_ABI(gp52, gp52_kernel())
+
+const char* moihgp_last_error(void) { return g_last_error; }
+
+int moihgp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int moihgp_version(void) { return 100; }
+
+moihgp_gp* moihgp_new(int kernel, double dt, size_t num_output, size_t num_latent) {
+    return gp_create(kernel, dt, num_output, num_latent, false, nullptr);
+}
+void moihgp_del(moihgp_gp* gp) { gp_free(gp); }
+size_t moihgp_num_output(moihgp_gp* gp) { return gp->M; }
+size_t moihgp_num_latent(moihgp_gp* gp) { return gp->L; }
+
+void moihgp_reseed_U(moihgp_gp* gp, unsigned long long seed) {
+    if (gp->latents_only) return;
+    draw_U(gp, seed, true);
+    upload_mixing(gp);
+    MOIHGP_HIP_FATAL(hipStreamSynchronize(gp->stream));
+}
+
+moihgp_gp* moihgp_new_latents(int kernel, double dt, size_t nl, const double* params_LP) {
+    return gp_create(kernel, dt, 0, nl, true, params_LP);
+}
+
+int moihgp_update_latents(moihgp_gp* gp, const double* params_LP) {
+    if (!gp || !params_LP) { set_last_error("update_latents: null argument"); return 1; }
+    for (size_t i = 0; i < gp->L * (size_t)gp->P; i++) gp->igp[i] = params_LP[i];
+    run_ihgp_update(gp);
+    return 0;
+}
+
+int moihgp_get_latent(moihgp_gp* gp, size_t l, double* A, double* K, double* S, double* HA, double* AKHA, double* dA,
+                      double* dS, double* dK, double* dAKHA, double* HdA, int* iters) {
+    if (!gp || l >= gp->L) { set_last_error("get_latent: bad latent index"); return 1; }
+    const int d = gp->d, P = gp->P, cbs = cb_size(d);
+    std::vector<double> b(cbs);
+    MOIHGP_HIP_FATAL(hipMemcpy(b.data(), gp->cb64 + l * cbs, sizeof(double) * cbs, hipMemcpyDeviceToHost));
+    auto copy = [&](double* dst, int off, int n) { if (dst) std::memcpy(dst, b.data() + off, sizeof(double) * n); };
+    if (d == 2) {
+        using Ly = CB<2>;
+        copy(A, Ly::A, 4); copy(K, Ly::K, 2); copy(S, Ly::S, 1); copy(HA, Ly::HA, 2); copy(AKHA, Ly::AKHA, 4);
+        copy(dA, Ly::DA, P * 4); copy(dS, Ly::DS, P); copy(dK, Ly::DK, P * 2); copy(dAKHA, Ly::DAKHA, P * 4); copy(HdA, Ly::HDA, P * 2);
+        if (iters) for (int i = 0; i < 1 + P; i++) iters[i] = (int)b[Ly::ITERS + i];
+    } else {
+        using Ly = CB<3>;
+        copy(A, Ly::A, 9); copy(K, Ly::K, 3); copy(S, Ly::S, 1); copy(HA, Ly::HA, 3); copy(AKHA, Ly::AKHA, 9);
+        copy(dA, Ly::DA, P * 9); copy(dS, Ly::DS, P); copy(dK, Ly::DK, P * 3); copy(dAKHA, Ly::DAKHA, P * 9); copy(HdA, Ly::HDA, P * 3);
+        if (iters) for (int i = 0; i < 1 + P; i++) iters[i] = (int)b[Ly::ITERS + i];
+    }
+    return 0;
+}
+
+static int check_stream_args(moihgp_gp* gp, int dtype, const void* Ty, size_t T, size_t ld, const void* x) {
+    if (!gp) { set_last_error("null handle"); return 1; }
+    if (dtype != MOIHGP_F64 && dtype != MOIHGP_F32) { set_last_error("dtype must be MOIHGP_F64 or MOIHGP_F32"); return 1; }
+    const size_t es = dtype == MOIHGP_F64 ? 8 : 4, epv = 16 / es;
+    if (!x || (T > 0 && !Ty)) { set_last_error("null stream/state pointer"); return 1; }
+    if (((uintptr_t)Ty & 15) != 0) { set_last_error("stream base must be 16-byte aligned"); return 1; }
+    if (ld % epv != 0 || ld < (T + epv - 1) / epv * epv) { set_last_error("ld (%zu) must be a multiple of %zu and >= T rounded up to it", ld, epv); return 1; }
+    return 0;
+}
+
+int moihgp_filter_stream(moihgp_gp* gp, int dtype, const void* Ty, size_t T, size_t ld, void* x, void* yhat, double* nll, void* stream) {
+    if (int rc = check_stream_args(gp, dtype, Ty, T, ld, x)) return rc;
+    if (yhat && ((uintptr_t)yhat & 15) != 0) { set_last_error("yhat base must be 16-byte aligned"); return 1; }
+    return launch_filter_stream(gp->d, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cb32, x, yhat, nll, (hipStream_t)stream);
+}
+
+int moihgp_grad_stream(moihgp_gp* gp, int dtype, const void* Ty, size_t T, size_t ld, void* x, void* dx, void* yhat, double* nll,
+                       double* grad, void* stream) {
+    if (int rc = check_stream_args(gp, dtype, Ty, T, ld, x)) return rc;
+    if (!dx || !grad) { set_last_error("grad_stream: dx and grad are required"); return 1; }
+    return launch_grad_stream(gp->d, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cb32, x, dx, yhat, nll, grad, (hipStream_t)stream);
+}
+
+int moihgp_project_stream(moihgp_gp* gp, int dtype, const void* Y, size_t T, void* Ty, size_t ld, void* stream) {
+    if (!gp || gp->latents_only) { set_last_error("project_stream needs a full MOIHGP object"); return 1; }
+    if (ld < T) { set_last_error("ld < T"); return 1; }
+    return launch_project_stream(dtype, Y, T, gp->M, gp->L, gp->dU, gp->dS, Ty, ld, (hipStream_t)stream);
+}
+
+int moihgp_unproject_stream(moihgp_gp* gp, int dtype, const void* Tyhat, size_t T, size_t ld, void* Yhat, void* stream) {
+    if (!gp || gp->latents_only) { set_last_error("unproject_stream needs a full MOIHGP object"); return 1; }
+    if (ld < T) { set_last_error("ld < T"); return 1; }
+    return launch_unproject_stream(dtype, Tyhat, T, ld, gp->M, gp->L, gp->dU, gp->dS, Yhat, (hipStream_t)stream);
+}
+
+int moihgp_stream_sync(void* stream) {
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) { set_last_error("stream sync: %s", hipGetErrorString(e)); return 2; }
+    return 0;
+}
+
+}  // extern "C"

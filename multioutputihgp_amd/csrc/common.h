@@ -1,0 +1,86 @@
+// common.h -- shared definitions for libmoihgp.so (gfx950 HIP).
+//
+// Per-latent "constant block": the stationary matrices of one IHGP (reference
+// include/moihgp/ihgp.h:243-254), computed once per hyper-parameter update by
+// stationary.hip and read by every recursion kernel.  One block per latent, array-of-
+// structs, so that a wavefront that owns one latent fetches its block with scalar loads.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+
+namespace moihgp {
+
+constexpr int kNumIgpParam = 3;   // magnitude, lengthscale, noise (matern32ss.h:34-36)
+
+// Offsets (in scalars) inside a constant block for state dim D and P hyper-parameters.
+template <int D, int P = kNumIgpParam>
+struct CB {
+    static constexpr int AKHA  = 0;                 // [D*D]  A - K H A            ihgp.h:130
+    static constexpr int K     = AKHA + D * D;      // [D]    PP H^T / S           ihgp.h:127
+    static constexpr int A     = K + D;             // [D*D]  expm(dt F)           ihgp.h:120
+    static constexpr int HA    = A + D * D;         // [D]    H A                  ihgp.h:129
+    static constexpr int S     = HA + D;            // [1]    H PP H^T + R         ihgp.h:126
+    static constexpr int LOGS  = S + 1;             // [1]    log(S)
+    static constexpr int DAKHA = LOGS + 1;          // [P][D*D]                    ihgp.h:192,197
+    static constexpr int DK    = DAKHA + P * D * D; // [P][D]                      ihgp.h:189
+    static constexpr int DA    = DK + P * D;        // [P][D*D]                    ihgp.h:143,167
+    static constexpr int HDA   = DA + P * D * D;    // [P][D]   (H dA)^T           ihgp.h:193,198
+    static constexpr int DS    = HDA + P * D;       // [P]                         ihgp.h:188
+    static constexpr int PARAMS = DS + P;           // [P]    hyper-parameters of this latent
+    static constexpr int ITERS = PARAMS + P;        // [1+P]  DARE / DLyap iteration counts (as scalars)
+    static constexpr int RAW   = ITERS + 1 + P;
+    static constexpr int SIZE  = (RAW + 3) / 4 * 4; // padded to 16/32 bytes
+};
+
+constexpr int cb_size(int d) { return d == 2 ? CB<2>::SIZE : CB<3>::SIZE; }
+
+// ---- error handling -------------------------------------------------------------------------
+void set_last_error(const char* fmt, ...);
+[[noreturn]] void fatal_hip(hipError_t e, const char* what, const char* file, int line);
+
+#define MOIHGP_HIP_FATAL(expr)                                                      \
+    do {                                                                            \
+        hipError_t e__ = (expr);                                                    \
+        if (e__ != hipSuccess) ::moihgp::fatal_hip(e__, #expr, __FILE__, __LINE__); \
+    } while (0)
+
+// ---- kernel launchers (implemented in the .hip files) ---------------------------------------
+// stationary.hip: IHGP::update for n latents.  params_dev [n][3] fp64 (device).  Writes the fp64
+// constant blocks and their fp32 copies.
+void launch_ihgp_update(int kernel, int d, double dt, const double* params_dev, size_t n,
+                        double* cb64, float* cb32, hipStream_t stream);
+
+// recursion.hip: batched sweeps over series-major streams.
+int launch_filter_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, size_t L,
+                         const double* cb64, const float* cb32, void* x, void* yhat, double* nll,
+                         hipStream_t stream);
+int launch_grad_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, size_t L,
+                       const double* cb64, const float* cb32, void* x, void* dx, void* yhat,
+                       double* nll, double* grad, hipStream_t stream);
+
+// tick.hip: one-tick kernels behind the reference ABI (all fp64, device pointers).
+struct TickArgs {
+    int d; size_t M, L;
+    const double* cb64;      // [L] constant blocks
+    const double* U;         // [M][L]
+    const double* S;         // [L]
+    const double* sigma;     // [1]
+};
+void launch_project_tick(const TickArgs& a, const double* y, double* Ty, double* Uty, int* n_nan, hipStream_t s);
+void launch_project_tick_missing(const TickArgs& a, const double* y, double* Ty, double* work /*L*L+L*/, hipStream_t s);
+void launch_step_tick(const TickArgs& a, const double* x, const double* Ty /*NULL: predict only*/, const double* dx,
+                      double* xnew, double* Tyhat, double* dxnew, hipStream_t s);
+void launch_unproject_tick(const TickArgs& a, const double* Tyhat, double* yhat, hipStream_t s);
+// NLL of one tick: loss (device scalar) and, if grad != NULL, the full gradient vector
+// [M*L + L + 1 + L*P] (moihgp.h:460-611).  scratch: >= 4*L + 8 doubles.
+void launch_nll_tick(const TickArgs& a, const double* x, const double* y, const double* Ty, const double* Uty,
+                     const double* dx, double* loss, double* grad, double* scratch, hipStream_t s);
+
+// oilmm.hip: whole-stream projection GEMMs.
+int launch_project_stream(int dtype, const void* Y, size_t T, size_t M, size_t L, const double* U, const double* S,
+                          void* Ty, size_t ld, hipStream_t s);
+int launch_unproject_stream(int dtype, const void* Tyhat, size_t T, size_t ld, size_t M, size_t L, const double* U,
+                            const double* S, void* Yhat, hipStream_t s);
+
+}  // namespace moihgp

@@ -1,0 +1,400 @@
+// stationary.hip -- batched IHGP::update on the device: one lane per latent, fp64 always.
+//
+// Restates, for every latent independently, reference include/moihgp/ihgp.h:117-201:
+//   A = expm(dt F); Q = sym(Pinf - A Pinf A^T); PP = DARE(A, H^T, Q, R); S, K, HA, AKHA;
+//   per hyper-parameter p: dA[p] (2d x 2d block expm), dQ, QLyap (four cases on exact zeros),
+//   dPP = DLyap(A - A K H, QLyap), dS, dK, dAKHA, HdA.
+// with the state-space models of matern32ss.h:40-64 / matern52ss.h:38-75 and the fixed-point
+// solvers of include/utils/dare.h:10-58 (tolerance 1e-8, at most 100 iterations, literal forms).
+// The matrix exponential follows the published algorithm behind Eigen's MatrixBase::exp()
+// (Higham 2005: Pade [3/3]..[13/13] chosen on the 1-norm, scaling and squaring).
+//
+// This kernel is launch-latency sized work (n latents x ~3e4 fp64 flops); it is written for
+// fidelity to the reference's operation order, not for speed: FP contraction is off so that the
+// iteration counts of DARE/DLyap agree with a plain-C evaluation.
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace moihgp {
+namespace {
+
+template <int N>
+__device__ inline void mm(const double* A, const double* B, double* C) {
+    double T[N * N];
+    for (int i = 0; i < N; i++)
+        for (int j = 0; j < N; j++) {
+            double s = 0.0;
+            for (int k = 0; k < N; k++) s += A[i * N + k] * B[k * N + j];
+            T[i * N + j] = s;
+        }
+    for (int i = 0; i < N * N; i++) C[i] = T[i];
+}
+template <int N>
+__device__ inline void mt(const double* A, double* At) {
+    double T[N * N];
+    for (int i = 0; i < N; i++)
+        for (int j = 0; j < N; j++) T[j * N + i] = A[i * N + j];
+    for (int i = 0; i < N * N; i++) At[i] = T[i];
+}
+template <int N>
+__device__ inline void mv(const double* A, const double* x, double* y) {
+    double T[N];
+    for (int i = 0; i < N; i++) {
+        double s = 0.0;
+        for (int k = 0; k < N; k++) s += A[i * N + k] * x[k];
+        T[i] = s;
+    }
+    for (int i = 0; i < N; i++) y[i] = T[i];
+}
+template <int N>
+__device__ inline bool all_zero(const double* A) {
+    for (int i = 0; i < N * N; i++)
+        if (A[i] != 0.0) return false;
+    return true;
+}
+
+// X = Den^-1 Num, partial pivoting (Eigen partialPivLu().solve)
+template <int N>
+__device__ void lu_solve(const double* Ain, const double* Bin, double* X) {
+    double A[N * N], B[N * N];
+    for (int i = 0; i < N * N; i++) { A[i] = Ain[i]; B[i] = Bin[i]; }
+    for (int k = 0; k < N; k++) {
+        int p = k;
+        double best = fabs(A[k * N + k]);
+        for (int i = k + 1; i < N; i++)
+            if (fabs(A[i * N + k]) > best) { best = fabs(A[i * N + k]); p = i; }
+        if (p != k)
+            for (int j = 0; j < N; j++) {
+                double t = A[k * N + j]; A[k * N + j] = A[p * N + j]; A[p * N + j] = t;
+                t = B[k * N + j]; B[k * N + j] = B[p * N + j]; B[p * N + j] = t;
+            }
+        for (int i = k + 1; i < N; i++) {
+            double f = A[i * N + k] / A[k * N + k];
+            for (int j = k; j < N; j++) A[i * N + j] -= f * A[k * N + j];
+            for (int j = 0; j < N; j++) B[i * N + j] -= f * B[k * N + j];
+        }
+    }
+    for (int j = 0; j < N; j++)
+        for (int i = N - 1; i >= 0; i--) {
+            double s = B[i * N + j];
+            for (int k = i + 1; k < N; k++) s -= A[i * N + k] * X[k * N + j];
+            X[i * N + j] = s / A[i * N + i];
+        }
+}
+
+// E = exp(Ain): Pade approximant of degree 3/5/7/9/13 by 1-norm, scaling & squaring for the last.
+template <int N>
+__device__ void expm(const double* Ain, double* E) {
+    constexpr int NN = N * N;
+    double A[NN], A2[NN], A4[NN], A6[NN], U[NN], V[NN], T[NN];
+    double l1 = 0.0;
+    for (int j = 0; j < N; j++) {
+        double s = 0.0;
+        for (int i = 0; i < N; i++) s += fabs(Ain[i * N + j]);
+        if (s > l1) l1 = s;
+    }
+    for (int i = 0; i < NN; i++) A[i] = Ain[i];
+    int squarings = 0;
+    if (l1 < 1.495585217958292e-002) {
+        const double b[] = {120., 60., 12., 1.};
+        mm<N>(A, A, A2);
+        for (int i = 0; i < NN; i++) T[i] = b[3] * A2[i];
+        for (int i = 0; i < N; i++) T[i * N + i] += b[1];
+        mm<N>(A, T, U);
+        for (int i = 0; i < NN; i++) V[i] = b[2] * A2[i];
+        for (int i = 0; i < N; i++) V[i * N + i] += b[0];
+    } else if (l1 < 2.539398330063230e-001) {
+        const double b[] = {30240., 15120., 3360., 420., 30., 1.};
+        mm<N>(A, A, A2); mm<N>(A2, A2, A4);
+        for (int i = 0; i < NN; i++) T[i] = b[5] * A4[i] + b[3] * A2[i];
+        for (int i = 0; i < N; i++) T[i * N + i] += b[1];
+        mm<N>(A, T, U);
+        for (int i = 0; i < NN; i++) V[i] = b[4] * A4[i] + b[2] * A2[i];
+        for (int i = 0; i < N; i++) V[i * N + i] += b[0];
+    } else if (l1 < 9.504178996162932e-001) {
+        const double b[] = {17297280., 8648640., 1995840., 277200., 25200., 1512., 56., 1.};
+        mm<N>(A, A, A2); mm<N>(A2, A2, A4); mm<N>(A4, A2, A6);
+        for (int i = 0; i < NN; i++) T[i] = b[7] * A6[i] + b[5] * A4[i] + b[3] * A2[i];
+        for (int i = 0; i < N; i++) T[i * N + i] += b[1];
+        mm<N>(A, T, U);
+        for (int i = 0; i < NN; i++) V[i] = b[6] * A6[i] + b[4] * A4[i] + b[2] * A2[i];
+        for (int i = 0; i < N; i++) V[i * N + i] += b[0];
+    } else if (l1 < 2.097847961257068e+000) {
+        const double b[] = {17643225600., 8821612800., 2075673600., 302702400., 30270240., 2162160., 110880., 3960., 90., 1.};
+        double A8[NN];
+        mm<N>(A, A, A2); mm<N>(A2, A2, A4); mm<N>(A4, A2, A6); mm<N>(A6, A2, A8);
+        for (int i = 0; i < NN; i++) T[i] = b[9] * A8[i] + b[7] * A6[i] + b[5] * A4[i] + b[3] * A2[i];
+        for (int i = 0; i < N; i++) T[i * N + i] += b[1];
+        mm<N>(A, T, U);
+        for (int i = 0; i < NN; i++) V[i] = b[8] * A8[i] + b[6] * A6[i] + b[4] * A4[i] + b[2] * A2[i];
+        for (int i = 0; i < N; i++) V[i * N + i] += b[0];
+    } else {
+        const double b[] = {64764752532480000., 32382376266240000., 7771770303897600., 1187353796428800.,
+                            129060195264000., 10559470521600., 670442572800., 33522128640., 1323241920.,
+                            40840800., 960960., 16380., 182., 1.};
+        const double maxnorm = 5.371920351148152;
+        frexp(l1 / maxnorm, &squarings);
+        if (squarings < 0) squarings = 0;
+        double sc = ldexp(1.0, -squarings);
+        for (int i = 0; i < NN; i++) A[i] *= sc;
+        mm<N>(A, A, A2); mm<N>(A2, A2, A4); mm<N>(A4, A2, A6);
+        for (int i = 0; i < NN; i++) V[i] = b[13] * A6[i] + b[11] * A4[i] + b[9] * A2[i];
+        mm<N>(A6, V, T);
+        for (int i = 0; i < NN; i++) T[i] += b[7] * A6[i] + b[5] * A4[i] + b[3] * A2[i];
+        for (int i = 0; i < N; i++) T[i * N + i] += b[1];
+        mm<N>(A, T, U);
+        for (int i = 0; i < NN; i++) T[i] = b[12] * A6[i] + b[10] * A4[i] + b[8] * A2[i];
+        mm<N>(A6, T, V);
+        for (int i = 0; i < NN; i++) V[i] += b[6] * A6[i] + b[4] * A4[i] + b[2] * A2[i];
+        for (int i = 0; i < N; i++) V[i * N + i] += b[0];
+    }
+    for (int i = 0; i < NN; i++) { double u = U[i], v = V[i]; A2[i] = u + v; A4[i] = -u + v; }
+    lu_solve<N>(A4, A2, E);
+    for (int s = 0; s < squarings; s++) mm<N>(E, E, E);
+}
+
+template <int D>
+struct SS {
+    double F[D * D], Pinf[D * D], H[D], R;
+    double dF[3][D * D], dPinf[3][D * D], dR[3];
+};
+
+// matern32ss.h:40-64 (D == 2) and matern52ss.h:38-75 (D == 3), including `lam = sqrt(3)/l` there.
+template <int D>
+__device__ void ss_build(int kernel, const double* params, SS<D>& s) {
+    for (int i = 0; i < D * D; i++) {
+        s.F[i] = 0.0; s.Pinf[i] = 0.0;
+        for (int p = 0; p < 3; p++) { s.dF[p][i] = 0.0; s.dPinf[p][i] = 0.0; }
+    }
+    for (int i = 0; i < D; i++) s.H[i] = 0.0;
+    s.H[0] = 1.0;
+    double magnitude = params[0], lengthscale = params[1];
+    s.R = params[2];
+    s.dR[0] = 0.0; s.dR[1] = 0.0; s.dR[2] = 1.0;
+    if constexpr (D == 2) {
+        double lam = sqrt(3.0) / lengthscale, lam2 = lam * lam;
+        double len3 = 6.0 / (lengthscale * lengthscale * lengthscale);
+        s.F[1] = 1.0;
+        s.F[2] = -lam2;
+        s.F[3] = -2.0 * lam;
+        s.Pinf[0] = magnitude;
+        s.Pinf[3] = magnitude * lam2;
+        s.dF[1][2] = len3;
+        s.dF[1][3] = 2.0 * lam / lengthscale;
+        s.dPinf[0][0] = 1.0;
+        s.dPinf[0][3] = lam2;
+        s.dPinf[1][3] = -magnitude * len3;
+    } else {
+        double lam = sqrt(3.0) / lengthscale;
+        double lam2 = lam * lam, len2 = lengthscale * lengthscale, len3 = len2 * lengthscale, len4 = len2 * len2;
+        double kappa = 5.0 / 3.0 * magnitude / len2, kappa2 = -2.0 * kappa / lengthscale, sq5 = sqrt(5.0);
+        s.F[1] = 1.0; s.F[5] = 1.0;
+        s.F[6] = -lam2 * lam; s.F[7] = -3.0 * lam2; s.F[8] = -3.0 * lam;
+        s.Pinf[0] = magnitude; s.Pinf[8] = 25.0 * magnitude / len4; s.Pinf[4] = kappa;
+        s.Pinf[6] = -kappa; s.Pinf[2] = -kappa;
+        s.dF[1][6] = 15.0 * sq5 / len4; s.dF[1][7] = 30.0 / len3; s.dF[1][8] = sq5 * lam2;
+        for (int i = 0; i < 9; i++) s.dPinf[0][i] = s.Pinf[i] / magnitude;
+        s.dPinf[1][4] = kappa2; s.dPinf[1][6] = -kappa2; s.dPinf[1][2] = -kappa2;
+        s.dPinf[1][8] = -100.0 * magnitude / len2 / len3;
+    }
+    (void)kernel;
+}
+
+constexpr double kDareTol = 1e-8;   // utils/dare.h:7
+constexpr int kDareMaxIter = 100;   // utils/dare.h:8
+
+// utils/dare.h:10-33, Bd = H^T
+template <int D>
+__device__ int dare(const double* Ad, const double* Bd, const double* Q, double R, double* P) {
+    double AdT[D * D], Pn[D * D], T1[D * D], PB[D], APB[D], BtP[D], BPA[D];
+    mt<D>(Ad, AdT);
+    for (int i = 0; i < D * D; i++) P[i] = Q[i];
+    for (int it = 0; it < kDareMaxIter; it++) {
+        mm<D>(AdT, P, T1); mm<D>(T1, Ad, Pn);
+        mv<D>(P, Bd, PB);
+        double g = R;
+        for (int i = 0; i < D; i++) g += Bd[i] * PB[i];
+        mv<D>(AdT, PB, APB);
+        for (int j = 0; j < D; j++) { double s = 0.0; for (int i = 0; i < D; i++) s += Bd[i] * P[i * D + j]; BtP[j] = s; }
+        for (int j = 0; j < D; j++) { double s = 0.0; for (int k = 0; k < D; k++) s += BtP[k] * Ad[k * D + j]; BPA[j] = s; }
+        double ginv = 1.0 / g;
+        double diff = -INFINITY;
+        for (int i = 0; i < D; i++)
+            for (int j = 0; j < D; j++) {
+                double v = Pn[i * D + j] - APB[i] * ginv * BPA[j] + Q[i * D + j];   // dare.h:23
+                Pn[i * D + j] = v;
+                double dlt = v - P[i * D + j];
+                if (dlt > diff) diff = dlt;                                       // maxCoeff, dare.h:25
+            }
+        diff = fabs(diff);
+        for (int i = 0; i < D; i++)
+            for (int j = 0; j < D; j++) P[i * D + j] = (Pn[i * D + j] + Pn[j * D + i]) / 2.0;   // dare.h:26
+        if (diff < kDareTol) return it + 1;
+    }
+    return kDareMaxIter;
+}
+
+// utils/dare.h:36-58 (literal `AdT P Ad - P + Q`)
+template <int D>
+__device__ int dlyap(const double* Ad, const double* Q, double* P) {
+    double AdT[D * D], Pn[D * D], T1[D * D];
+    mt<D>(Ad, AdT);
+    for (int i = 0; i < D * D; i++) P[i] = Q[i];
+    for (int it = 0; it < kDareMaxIter; it++) {
+        mm<D>(AdT, P, T1); mm<D>(T1, Ad, Pn);
+        double diff = -INFINITY;
+        for (int i = 0; i < D * D; i++) {
+            double v = Pn[i] - P[i] + Q[i];
+            Pn[i] = v;
+            double dlt = v - P[i];
+            if (dlt > diff) diff = dlt;
+        }
+        diff = fabs(diff);
+        for (int i = 0; i < D; i++)
+            for (int j = 0; j < D; j++) P[i * D + j] = (Pn[i * D + j] + Pn[j * D + i]) / 2.0;
+        if (diff < kDareTol) return it + 1;
+    }
+    return kDareMaxIter;
+}
+
+template <int D>
+__global__ void __launch_bounds__(64) ihgp_update_kernel(int kernel, double dt, const double* __restrict__ params,
+                                                         size_t n, double* __restrict__ cb64, float* __restrict__ cb32) {
+    using L = CB<D>;
+    constexpr int P = kNumIgpParam, NN = D * D;
+    size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= n) return;
+    double prm[3] = {params[l * 3 + 0], params[l * 3 + 1], params[l * 3 + 2]};
+    SS<D> s;
+    ss_build<D>(kernel, prm, s);
+    double out[L::SIZE];
+    for (int i = 0; i < L::SIZE; i++) out[i] = 0.0;
+
+    double A[NN], AT[NN], T1[NN], T2[NN], Q[NN], PP[NN];
+    for (int i = 0; i < NN; i++) T1[i] = dt * s.F[i];
+    expm<D>(T1, A);                                                    // ihgp.h:120
+    mt<D>(A, AT);
+    mm<D>(A, s.Pinf, T1); mm<D>(T1, AT, T2);
+    for (int i = 0; i < NN; i++) T1[i] = s.Pinf[i] - T2[i];             // ihgp.h:121
+    for (int i = 0; i < D; i++)
+        for (int j = 0; j < D; j++) Q[i * D + j] = (T1[i * D + j] + T1[j * D + i]) / 2.0;   // ihgp.h:122
+    int dare_iters = dare<D>(A, s.H, Q, s.R, PP);                       // ihgp.h:125
+    double PPHt[D], HPP[D], K[D], HA[D], AK[D], AAKH[NN];
+    mv<D>(PP, s.H, PPHt);
+    double S = s.R;
+    for (int i = 0; i < D; i++) S += s.H[i] * PPHt[i];                  // ihgp.h:126
+    for (int i = 0; i < D; i++) K[i] = PPHt[i] / S;                     // ihgp.h:127
+    for (int j = 0; j < D; j++) { double t = 0.0; for (int i = 0; i < D; i++) t += s.H[i] * PP[i * D + j]; HPP[j] = t; }
+    for (int j = 0; j < D; j++) { double t = 0.0; for (int i = 0; i < D; i++) t += s.H[i] * A[i * D + j]; HA[j] = t; }   // ihgp.h:129
+    for (int i = 0; i < D; i++)
+        for (int j = 0; j < D; j++) out[L::AKHA + i * D + j] = A[i * D + j] - K[i] * HA[j];   // ihgp.h:130
+    mv<D>(A, K, AK);                                                    // ihgp.h:132
+    for (int i = 0; i < D; i++)
+        for (int j = 0; j < D; j++) AAKH[i * D + j] = A[i * D + j] - AK[i] * s.H[j];   // ihgp.h:133
+    for (int i = 0; i < NN; i++) out[L::A + i] = A[i];
+    for (int i = 0; i < D; i++) { out[L::K + i] = K[i]; out[L::HA + i] = HA[i]; }
+    out[L::S] = S;
+    out[L::LOGS] = log(S);
+    out[L::ITERS] = (double)dare_iters;
+
+    for (int p = 0; p < P; p++) {                                       // ihgp.h:136
+        double dA[NN], dAT[NN], dQ[NN], QL[NN], dPP[NN];
+        bool dF_zero = all_zero<D>(s.dF[p]), dPinf_zero = all_zero<D>(s.dPinf[p]), dR_zero = (s.dR[p] == 0.0);
+        if (dF_zero) {                                                  // ihgp.h:141
+            for (int i = 0; i < NN; i++) dA[i] = 0.0;
+            if (dPinf_zero) {
+                for (int i = 0; i < NN; i++) dQ[i] = 0.0;
+            } else {
+                mm<D>(A, s.dPinf[p], T1); mm<D>(T1, AT, T2);
+                for (int i = 0; i < NN; i++) dQ[i] = s.dPinf[p][i] - T2[i];   // ihgp.h:150
+            }
+            if (dR_zero) {
+                for (int i = 0; i < NN; i++) QL[i] = dQ[i];             // ihgp.h:154
+            } else {
+                // ihgp.h:158 is `AK * AK^T * dR` ((d x d) * (1 x 1), an invalid Eigen product);
+                // evaluated with its evident meaning AK dR AK^T, as ihgp.h:183 writes it.
+                for (int i = 0; i < D; i++)
+                    for (int j = 0; j < D; j++) QL[i * D + j] = AK[i] * s.dR[p] * AK[j] + dQ[i * D + j];
+            }
+        } else {
+            constexpr int M2 = 2 * D;
+            double FF[M2 * M2], EF[M2 * M2];
+            for (int i = 0; i < M2 * M2; i++) FF[i] = 0.0;
+            for (int i = 0; i < D; i++)
+                for (int j = 0; j < D; j++) {                           // ihgp.h:163-166
+                    FF[i * M2 + j] = dt * s.F[i * D + j];
+                    FF[(D + i) * M2 + (D + j)] = dt * s.F[i * D + j];
+                    FF[(D + i) * M2 + j] = dt * s.dF[p][i * D + j];
+                }
+            expm<M2>(FF, EF);
+            for (int i = 0; i < D; i++)
+                for (int j = 0; j < D; j++) dA[i * D + j] = EF[(D + i) * M2 + j];   // ihgp.h:167
+            mt<D>(dA, dAT);
+            double dAPAt[NN], APdAt[NN];
+            mm<D>(dA, s.Pinf, T1); mm<D>(T1, AT, dAPAt);
+            mm<D>(A, s.Pinf, T1); mm<D>(T1, dAT, APdAt);
+            if (dPinf_zero) {
+                for (int i = 0; i < NN; i++) dQ[i] = -dAPAt[i] - APdAt[i];   // ihgp.h:171
+            } else {
+                mm<D>(A, s.dPinf[p], T1); mm<D>(T1, AT, T2);
+                for (int i = 0; i < NN; i++) dQ[i] = s.dPinf[p][i] - dAPAt[i] - T2[i] - APdAt[i];   // ihgp.h:175
+            }
+            double t1[NN], t2[NN], dAPPHt[D], HPPdAT[D];
+            mm<D>(dA, PP, T1); mm<D>(T1, AT, t1);
+            mm<D>(A, PP, T1); mm<D>(T1, dAT, t2);
+            mv<D>(dA, PPHt, dAPPHt);
+            for (int j = 0; j < D; j++) { double t = 0.0; for (int k = 0; k < D; k++) t += HPP[k] * dAT[k * D + j]; HPPdAT[j] = t; }
+            for (int i = 0; i < D; i++)
+                for (int j = 0; j < D; j++) {                           // ihgp.h:179 / :183
+                    double v = t1[i * D + j] + t2[i * D + j] - dAPPHt[i] * AK[j] - AK[i] * HPPdAT[j];
+                    if (!dR_zero) v += AK[i] * s.dR[p] * AK[j];
+                    QL[i * D + j] = v + dQ[i * D + j];
+                }
+        }
+        int its = dlyap<D>(AAKH, QL, dPP);                               // ihgp.h:187
+        double dS = s.dR[p];
+        for (int i = 0; i < D; i++)
+            for (int j = 0; j < D; j++) dS += s.H[i] * dPP[i * D + j] * s.H[j];   // ihgp.h:188
+        double dK[D];
+        for (int i = 0; i < D; i++) {                                    // ihgp.h:189
+            double t = 0.0;
+            for (int j = 0; j < D; j++) t += (dPP[i * D + j] - PP[i * D + j] * dS / S) * s.H[j];
+            dK[i] = t / S;
+        }
+        out[L::DS + p] = dS;
+        out[L::ITERS + 1 + p] = (double)its;
+        for (int i = 0; i < D; i++) out[L::DK + p * D + i] = dK[i];
+        for (int i = 0; i < NN; i++) out[L::DA + p * NN + i] = dA[i];
+        if (dF_zero) {                                                   // ihgp.h:192-193
+            for (int i = 0; i < D; i++)
+                for (int j = 0; j < D; j++) out[L::DAKHA + p * NN + i * D + j] = -dK[i] * HA[j];
+            for (int i = 0; i < D; i++) out[L::HDA + p * D + i] = 0.0;
+        } else {                                                         // ihgp.h:197-198
+            double HdA[D];
+            for (int j = 0; j < D; j++) { double t = 0.0; for (int i = 0; i < D; i++) t += s.H[i] * dA[i * D + j]; HdA[j] = t; }
+            for (int i = 0; i < D; i++)
+                for (int j = 0; j < D; j++) out[L::DAKHA + p * NN + i * D + j] = dA[i * D + j] - dK[i] * HA[j] - K[i] * HdA[j];
+            for (int i = 0; i < D; i++) out[L::HDA + p * D + i] = HdA[i];
+        }
+        out[L::PARAMS + p] = prm[p];
+    }
+    double* o64 = cb64 + l * L::SIZE;
+    float* o32 = cb32 + l * L::SIZE;
+    for (int i = 0; i < L::SIZE; i++) { o64[i] = out[i]; o32[i] = (float)out[i]; }
+}
+
+}  // namespace
+
+void launch_ihgp_update(int kernel, int d, double dt, const double* params_dev, size_t n, double* cb64, float* cb32,
+                        hipStream_t stream) {
+    if (n == 0) return;
+    dim3 block(64), grid((unsigned)((n + 63) / 64));
+    if (d == 2)
+        hipLaunchKernelGGL(ihgp_update_kernel<2>, grid, block, 0, stream, kernel, dt, params_dev, n, cb64, cb32);
+    else
+        hipLaunchKernelGGL(ihgp_update_kernel<3>, grid, block, 0, stream, kernel, dt, params_dev, n, cb64, cb32);
+    MOIHGP_HIP_FATAL(hipGetLastError());
+}
+
+}  // namespace moihgp

@@ -1,0 +1,271 @@
+// tick.hip -- single-tick kernels behind the reference's per-tick ABI (gp32_step1..4, gp32_lik1/2).
+// All fp64, device pointers.  These calls are launch-latency bound by construction (the reference
+// ABI hands over one observation vector per FFI crossing); the throughput path is recursion.hip.
+//
+// Reference: include/moihgp/moihgp.h:148-428 (step x4: project -> L x IHGP::step -> unproject),
+// :460-688 (negLogLikelihood x2), include/moihgp/ihgp.h:37-100, :204-222.
+#include "common.h"
+
+namespace moihgp {
+namespace {
+
+constexpr int P = kNumIgpParam;
+
+// Ty = S^-1/2 U^T y (moihgp.h:181); Uty = U^T y kept for the NLL terms.
+__global__ void project_tick_kernel(size_t M, size_t L, const double* __restrict__ U, const double* __restrict__ S,
+                                    const double* __restrict__ y, double* __restrict__ Ty, double* __restrict__ Uty) {
+    size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= L) return;
+    double s = 0.0;
+    for (size_t m = 0; m < M; m++) s += U[m * L + l] * y[m];
+    if (Uty) Uty[l] = s;
+    if (Ty) Ty[l] = (1.0 / sqrt(S[l])) * s;
+}
+
+// Normal equations over observed rows (moihgp.h:167-177): N = U0^T U0, r = U0^T y0.
+__global__ void normal_eq_kernel(size_t M, size_t L, const double* __restrict__ U, const double* __restrict__ y,
+                                 double* __restrict__ N, double* __restrict__ r) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= L * L) return;
+    size_t a = idx / L, b = idx % L;
+    double s = 0.0, rr = 0.0;
+    for (size_t m = 0; m < M; m++) {
+        double ym = y[m];
+        if (ym != ym) continue;
+        double ua = U[m * L + a];
+        s += ua * U[m * L + b];
+        if (b == 0) rr += ua * ym;
+    }
+    N[idx] = s;
+    if (b == 0) r[a] = rr;
+}
+
+// Solve N a = r for SPD N in place (stand-in for Eigen ldlt().solve, moihgp.h:177), one workgroup.
+// Then Ty = S^-1/2 a.  Edge path (only ticks with missing outputs); O(L^3) on one CU.
+__global__ void __launch_bounds__(256) spd_solve_kernel(size_t L, double* __restrict__ N, double* __restrict__ r,
+                                                        const double* __restrict__ S, double* __restrict__ Ty) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (size_t k = 0; k < L; k++) {
+        const double pivot = N[k * L + k];
+        for (size_t i = k + 1 + tid; i < L; i += nt) {
+            double f = N[i * L + k] / pivot;
+            for (size_t j = k; j < L; j++) N[i * L + j] -= f * N[k * L + j];
+            r[i] -= f * r[k];
+        }
+        __syncthreads();
+    }
+    __shared__ double red[256];
+    for (size_t ii = L; ii-- > 0;) {
+        double s = 0.0;
+        for (size_t k = ii + 1 + tid; k < L; k += nt) s += N[ii * L + k] * r[k];
+        red[tid] = s;
+        __syncthreads();
+        for (int o = nt / 2; o > 0; o >>= 1) {
+            if (tid < o) red[tid] += red[tid + o];
+            __syncthreads();
+        }
+        if (tid == 0) r[ii] = (r[ii] - red[0]) / N[ii * L + ii];
+        __syncthreads();
+    }
+    for (size_t l = tid; l < L; l += nt) Ty[l] = (1.0 / sqrt(S[l])) * r[l];
+}
+
+// L x IHGP::step (ihgp.h:37-100), one lane per latent.
+template <int D>
+__global__ void step_tick_kernel(size_t L, const double* __restrict__ cb, const double* __restrict__ x,
+                                 const double* __restrict__ Ty, const double* __restrict__ dx, double* __restrict__ xnew,
+                                 double* __restrict__ Tyhat, double* __restrict__ dxnew) {
+    using Lay = CB<D>;
+    size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= L) return;
+    const double* c = cb + l * Lay::SIZE;
+    double xs[D], xn[D];
+    for (int i = 0; i < D; i++) xs[i] = x[l * D + i];
+    const bool has_y = (Ty != nullptr);
+    const double y = has_y ? Ty[l] : 0.0;
+    const bool miss = !has_y || (y != y);                                // ihgp.h:39 / :96
+    const double* Mx = c + (miss ? Lay::A : Lay::AKHA);
+    for (int i = 0; i < D; i++) {
+        double s = 0.0;
+        for (int k = 0; k < D; k++) s += Mx[i * D + k] * xs[k];
+        xn[i] = miss ? s : s + c[Lay::K + i] * y;                        // ihgp.h:41 / :50
+    }
+    for (int i = 0; i < D; i++) xnew[l * D + i] = xn[i];
+    if (Tyhat) Tyhat[l] = xn[0];                                         // ihgp.h:42 / :51
+    if (dx && dxnew) {
+        for (int p = 0; p < P; p++) {
+            const double* dM = c + (miss ? Lay::DA : Lay::DAKHA) + p * D * D;
+            for (int i = 0; i < D; i++) {
+                double a = 0.0, b = 0.0;
+                for (int k = 0; k < D; k++) { a += dM[i * D + k] * xs[k]; b += Mx[i * D + k] * dx[(l * P + p) * D + k]; }
+                double v = a + b;
+                if (!miss) v += c[Lay::DK + p * D + i] * y;              // ihgp.h:45 / :54
+                dxnew[(l * P + p) * D + i] = v;
+            }
+        }
+    }
+}
+
+// yhat = U S^1/2 Tyhat (moihgp.h:222-225): one wave per output row.
+__global__ void __launch_bounds__(256) unproject_tick_kernel(size_t M, size_t L, const double* __restrict__ U,
+                                                             const double* __restrict__ S, const double* __restrict__ Tyhat,
+                                                             double* __restrict__ yhat) {
+    const int lane = threadIdx.x & 63;
+    size_t m = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (m >= M) return;
+    double s = 0.0;
+    for (size_t l = lane; l < L; l += 64) s += U[m * L + l] * (sqrt(S[l]) * Tyhat[l]);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) yhat[m] = s;
+}
+
+// Per-latent NLL terms: loss_l (ihgp.h:204-209), grad_l (ihgp.h:212-222), pv_l (moihgp.h:505-512).
+template <int D>
+__global__ void igp_nll_kernel(size_t L, const double* __restrict__ cb, const double* __restrict__ x,
+                               const double* __restrict__ yraw, const double* __restrict__ Ty, const double* __restrict__ dx,
+                               double* __restrict__ lossv, double* __restrict__ pv, double* __restrict__ igrad) {
+    using Lay = CB<D>;
+    size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= L) return;
+    const double* c = cb + l * Lay::SIZE;
+    const double S = c[Lay::S];
+    double hx = 0.0, hak = 0.0;
+    for (int i = 0; i < D; i++) { hx += c[Lay::HA + i] * x[l * D + i]; hak += c[Lay::HA + i] * c[Lay::K + i]; }
+    const double y = Ty[l];
+    const double v = y - hx;
+    lossv[l] = 0.5 * (v * v / S + log(S));                               // ihgp.h:207
+    if (dx) {
+        pv[l] = (yraw[l] - hx) * (1 - hak) / S;                          // moihgp.h:510-511 (raw y(idx), sic)
+        for (int p = 0; p < P; p++) {
+            double a = 0.0, b = 0.0;
+            for (int i = 0; i < D; i++) { a += c[Lay::HDA + p * D + i] * x[l * D + i]; b += c[Lay::HA + i] * dx[(l * P + p) * D + i]; }
+            double dv = -a - b;                                          // ihgp.h:218
+            igrad[l * P + p] = (v * dv - 0.5 * (v * v / S - 1) * c[Lay::DS + p]) / S;   // ihgp.h:219
+        }
+    }
+}
+
+// resid2[m] = (y - U U^T y)_m^2  (moihgp.h:501 / :651): one wave per output row.
+__global__ void __launch_bounds__(256) resid_kernel(size_t M, size_t L, const double* __restrict__ U,
+                                                    const double* __restrict__ y, const double* __restrict__ Uty,
+                                                    double* __restrict__ resid2) {
+    const int lane = threadIdx.x & 63;
+    size_t m = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (m >= M) return;
+    double s = 0.0;
+    for (size_t l = lane; l < L; l += 64) s += U[m * L + l] * Uty[l];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) { double r = y[m] - s; resid2[m] = r * r; }
+}
+
+__device__ double block_sum(double v, double* red) {
+    const int tid = threadIdx.x;
+    red[tid] = v;
+    __syncthreads();
+    for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    double r = red[0];
+    __syncthreads();
+    return r;
+}
+
+// loss and the S / sigma / per-latent gradient entries (moihgp.h:503, :553-563, :598-609): one workgroup.
+__global__ void __launch_bounds__(256) nll_finalize_kernel(size_t M, size_t L, const double* __restrict__ S,
+                                                           const double* __restrict__ sigma_p, const double* __restrict__ Uty,
+                                                           const double* __restrict__ lossv, const double* __restrict__ pv,
+                                                           const double* __restrict__ igrad, const double* __restrict__ resid2,
+                                                           double* __restrict__ loss, double* __restrict__ grad) {
+    __shared__ double red[256];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const double sigma = *sigma_p;
+    double a = 0.0, b = 0.0, c = 0.0;
+    for (size_t l = tid; l < L; l += nt) { a += S[l]; c += lossv[l]; }
+    for (size_t m = tid; m < M; m += nt) b += resid2[m];
+    const double Ssum = block_sum(a, red);
+    const double nrm = sqrt(block_sum(b, red));
+    const double lsum = block_sum(c, red);
+    double m_n = (double)M - (double)L;
+    if (m_n < 0.0) m_n = 0.0;                                            // moihgp.h:502
+    if (tid == 0) *loss = 0.5 * log(Ssum) + 0.5 * m_n * log(sigma) + 0.5 * nrm / sigma + lsum;   // moihgp.h:503 (sic)
+    if (!grad) return;
+    const size_t sizeU = M * L;
+    double gs = 0.0;
+    for (size_t l = tid; l < L; l += nt) {
+        const double Sl = S[l], sq = sqrt(Sl);
+        const double dn = igrad[l * P + (P - 1)];
+        double g = 0.5 / Sl + pv[l] * (-0.5 * (1.0 / sq / sq / sq) * Uty[l]);   // moihgp.h:555-561
+        g -= dn * sigma / Sl / Sl;                                       // moihgp.h:604
+        grad[sizeU + l] = g;
+        gs += dn / Sl;                                                   // moihgp.h:605
+        for (int p = 0; p < P; p++) grad[sizeU + L + 1 + l * P + p] = igrad[l * P + p];   // moihgp.h:608-609
+    }
+    const double gsum = block_sum(gs, red);
+    if (tid == 0) grad[sizeU + L] = 0.5 * (m_n - nrm / sigma) / sigma + gsum;   // moihgp.h:563
+}
+
+// U-gradient (moihgp.h:538-552).  U is a polar factor (moihgp.h:438-446) so its singular values are
+// 1 and `dU` (moihgp.h:545) reduces to the one-hot basis matrix dA[idx1]; the M*L-iteration loop of
+// dense products then collapses to  grad_U[r][c] = y_r (pv_c / sqrt(S_c) - (U^T y)_c / sigma).
+__global__ void ugrad_kernel(size_t M, size_t L, const double* __restrict__ S, const double* __restrict__ sigma_p,
+                             const double* __restrict__ y, const double* __restrict__ Uty, const double* __restrict__ pv,
+                             double* __restrict__ grad) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * L) return;
+    size_t r = idx / L, c = idx % L;
+    grad[idx] = y[r] * (pv[c] * (1.0 / sqrt(S[c])) - Uty[c] / *sigma_p);
+}
+
+}  // namespace
+
+static inline unsigned nblk(size_t n, unsigned b) { return (unsigned)((n + b - 1) / b); }
+
+void launch_project_tick(const TickArgs& a, const double* y, double* Ty, double* Uty, int* /*n_nan*/, hipStream_t s) {
+    hipLaunchKernelGGL(project_tick_kernel, dim3(nblk(a.L, 128)), dim3(128), 0, s, a.M, a.L, a.U, a.S, y, Ty, Uty);
+    MOIHGP_HIP_FATAL(hipGetLastError());
+}
+
+void launch_project_tick_missing(const TickArgs& a, const double* y, double* Ty, double* work, hipStream_t s) {
+    double* N = work;
+    double* r = work + a.L * a.L;
+    hipLaunchKernelGGL(normal_eq_kernel, dim3(nblk(a.L * a.L, 128)), dim3(128), 0, s, a.M, a.L, a.U, y, N, r);
+    hipLaunchKernelGGL(spd_solve_kernel, dim3(1), dim3(256), 0, s, a.L, N, r, a.S, Ty);
+    MOIHGP_HIP_FATAL(hipGetLastError());
+}
+
+void launch_step_tick(const TickArgs& a, const double* x, const double* Ty, const double* dx, double* xnew,
+                      double* Tyhat, double* dxnew, hipStream_t s) {
+    dim3 grid(nblk(a.L, 64)), block(64);
+    if (a.d == 2)
+        hipLaunchKernelGGL(step_tick_kernel<2>, grid, block, 0, s, a.L, a.cb64, x, Ty, dx, xnew, Tyhat, dxnew);
+    else
+        hipLaunchKernelGGL(step_tick_kernel<3>, grid, block, 0, s, a.L, a.cb64, x, Ty, dx, xnew, Tyhat, dxnew);
+    MOIHGP_HIP_FATAL(hipGetLastError());
+}
+
+void launch_unproject_tick(const TickArgs& a, const double* Tyhat, double* yhat, hipStream_t s) {
+    hipLaunchKernelGGL(unproject_tick_kernel, dim3(nblk(a.M, 4)), dim3(256), 0, s, a.M, a.L, a.U, a.S, Tyhat, yhat);
+    MOIHGP_HIP_FATAL(hipGetLastError());
+}
+
+void launch_nll_tick(const TickArgs& a, const double* x, const double* y, const double* Ty, const double* Uty,
+                     const double* dx, double* loss, double* grad, double* scratch, hipStream_t s) {
+    double* lossv = scratch;                 // [L]
+    double* pv = lossv + a.L;                // [L]
+    double* igrad = pv + a.L;                // [L][P]
+    double* resid2 = igrad + a.L * P;        // [M]
+    dim3 grid(nblk(a.L, 64)), block(64);
+    if (a.d == 2)
+        hipLaunchKernelGGL(igp_nll_kernel<2>, grid, block, 0, s, a.L, a.cb64, x, y, Ty, dx, lossv, pv, igrad);
+    else
+        hipLaunchKernelGGL(igp_nll_kernel<3>, grid, block, 0, s, a.L, a.cb64, x, y, Ty, dx, lossv, pv, igrad);
+    hipLaunchKernelGGL(resid_kernel, dim3(nblk(a.M, 4)), dim3(256), 0, s, a.M, a.L, a.U, y, Uty, resid2);
+    hipLaunchKernelGGL(nll_finalize_kernel, dim3(1), dim3(256), 0, s, a.M, a.L, a.S, a.sigma, Uty, lossv, pv, igrad,
+                       resid2, loss, dx ? grad : nullptr);
+    if (dx && grad)
+        hipLaunchKernelGGL(ugrad_kernel, dim3(nblk(a.M * a.L, 256)), dim3(256), 0, s, a.M, a.L, a.S, a.sigma, y, Uty, pv, grad);
+    MOIHGP_HIP_FATAL(hipGetLastError());
+}
+
+}  // namespace moihgp

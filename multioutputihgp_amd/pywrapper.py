@@ -1,0 +1,159 @@
+"""`MOIHGP`: host-side mirror of the reference ctypes class (reference moihgp/pywrapper.py:10-270).
+
+Same constructor, methods, properties, argument meaning and return shapes, so code written against
+the reference class runs unchanged; behind it every call goes through the C ABI of
+`lib/libmoihgp.so` (include/moihgp.h part 1) into HIP kernels.
+
+Differences, all documented in INTEGRATION.md:
+  * `kernel="Matern52"` works (the reference raises AttributeError, pywrapper.py:59 `self.lib`);
+    it reaches `gp52_*`, which like the reference aliases the Matern-3/2 model unless
+    MOIHGP_GP52_MATERN52=1.  `kernel="Matern52ss"` selects the real matern52ss.h model explicitly.
+  * construction raises `MoihgpError` when no GPU / library is available (the reference would
+    fail inside `cdll.LoadLibrary`).
+"""
+from __future__ import annotations
+
+from ctypes import c_bool, c_double, c_size_t
+
+import numpy as np
+
+from ._lib import MoihgpError, c_double_p, last_error, load_library
+
+
+class MOIHGP(object):
+
+    def __init__(self, dt, num_output, num_latent, kernel="Matern32", threading=False):
+        self.dt = dt
+        self.__num_output = num_output
+        self.__num_latent = num_latent
+        lib = load_library()
+        self.__lib = lib
+        if kernel == "Matern32":
+            pfx = "gp32"
+            self.__obj = lib.gp32_new(c_double(dt), c_size_t(num_output), c_size_t(num_latent), c_bool(threading))
+        elif kernel == "Matern52":
+            pfx = "gp52"
+            self.__obj = lib.gp52_new(c_double(dt), c_size_t(num_output), c_size_t(num_latent), c_bool(threading))
+        elif kernel == "Matern52ss":
+            pfx = "gp52"     # same entry points; object built with the true Matern-5/2 state space
+            self.__obj = lib.moihgp_new(1, c_double(dt), c_size_t(num_output), c_size_t(num_latent))
+        else:
+            raise NotImplementedError("Unsupported kernel type.")
+        if not self.__obj:
+            raise MoihgpError(last_error(lib) or "libmoihgp: object construction failed")
+        self.__del = getattr(lib, pfx + "_del")
+        self.__step1 = getattr(lib, pfx + "_step1")
+        self.__step2 = getattr(lib, pfx + "_step2")
+        self.__step3 = getattr(lib, pfx + "_step3")
+        self.__step4 = getattr(lib, pfx + "_step4")
+        self.__update = getattr(lib, pfx + "_update")
+        self.__lik1 = getattr(lib, pfx + "_lik1")
+        self.__lik2 = getattr(lib, pfx + "_lik2")
+        self.__get_params = getattr(lib, pfx + "_get_params")
+        self.__num_param = int(getattr(lib, pfx + "_num_param")(self.__obj))
+        self.__num_igp_param = int(getattr(lib, pfx + "_num_igp_param")(self.__obj))
+        self.__igp_dim = int(getattr(lib, pfx + "_igp_dim")(self.__obj))
+        # persistent staging buffers, as pywrapper.py:146-167
+        self.__params = np.zeros((self.num_param,), dtype=np.float64)
+        self.__params_p = self.__params.ctypes.data_as(c_double_p)
+        self.__grad = np.zeros((self.num_param,), dtype=np.float64)
+        self.__grad_p = self.__grad.ctypes.data_as(c_double_p)
+        self.__x = np.zeros((self.num_latent, self.igp_dim), dtype=np.float64)
+        self.__x_p = self.__x.ctypes.data_as(c_double_p)
+        self.__y = np.zeros((self.num_output,), dtype=np.float64)
+        self.__y_p = self.__y.ctypes.data_as(c_double_p)
+        self.__dx = np.zeros((self.num_latent, self.num_igp_param, self.igp_dim), dtype=np.float64)
+        self.__dx_p = self.__dx.ctypes.data_as(c_double_p)
+        self.__xnew = np.zeros((self.num_latent, self.igp_dim), dtype=np.float64)
+        self.__xnew_p = self.__xnew.ctypes.data_as(c_double_p)
+        self.__yhat = np.zeros((self.num_output,), dtype=np.float64)
+        self.__yhat_p = self.__yhat.ctypes.data_as(c_double_p)
+        self.__dxnew = np.zeros((self.num_latent, self.num_igp_param, self.igp_dim), dtype=np.float64)
+        self.__dxnew_p = self.__dxnew.ctypes.data_as(c_double_p)
+
+    def __del__(self):
+        try:
+            if self.__obj:
+                self.__del(self.__obj)
+                self.__obj = None
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        """Opaque `moihgp_gp*` for the additive batched entry points (streams.py)."""
+        return self.__obj
+
+    def step(self, x, y=None, dx=None):
+        """pywrapper.py:175-196.  Returns (xnew, yhat) or (xnew, yhat, dxnew)."""
+        self.__x[...] = np.asarray(x, dtype=np.float64).reshape(self.__x.shape)
+        if y is None:
+            self.__step4(self.__obj, self.__x_p, self.__xnew_p, self.__yhat_p)
+            return self.__xnew.astype(np.float64), self.__yhat.astype(np.float64)
+        self.__y[...] = np.asarray(y, dtype=np.float64).reshape(self.__y.shape)
+        if dx is None:
+            self.__step3(self.__obj, self.__x_p, self.__y_p, self.__xnew_p, self.__yhat_p)
+            return self.__xnew.astype(np.float64), self.__yhat.astype(np.float64)
+        self.__dx[...] = np.asarray(dx, dtype=np.float64).reshape(self.__dx.shape)
+        self.__step1(self.__obj, self.__x_p, self.__y_p, self.__dx_p, self.__xnew_p, self.__yhat_p, self.__dxnew_p)
+        return self.__xnew.astype(np.float64), self.__yhat.astype(np.float64), self.__dxnew.astype(np.float64)
+
+    def step_no_yhat(self, x, y, dx):
+        """C++ overload 2 (moihgp.h:229-301, `gp32_step2`), which the reference Python class never binds
+        to a method although it loads the symbol (pywrapper.py:49)."""
+        self.__x[...] = np.asarray(x, dtype=np.float64).reshape(self.__x.shape)
+        self.__y[...] = np.asarray(y, dtype=np.float64).reshape(self.__y.shape)
+        self.__dx[...] = np.asarray(dx, dtype=np.float64).reshape(self.__dx.shape)
+        self.__step2(self.__obj, self.__x_p, self.__y_p, self.__dx_p, self.__xnew_p, self.__dxnew_p)
+        return self.__xnew.astype(np.float64), self.__dxnew.astype(np.float64)
+
+    def update(self, params):
+        """pywrapper.py:199-201."""
+        self.__params[...] = np.asarray(params, dtype=np.float64).reshape(self.__params.shape)
+        self.__update(self.__obj, self.__params_p)
+
+    def negLogLikelihood(self, x, y, dx=None):
+        """pywrapper.py:204-222.  Returns loss or (loss, grad)."""
+        self.__x[...] = np.asarray(x, dtype=np.float64).reshape(self.__x.shape)
+        self.__y[...] = np.asarray(y, dtype=np.float64).reshape(self.__y.shape)
+        if dx is None:
+            return np.float64(self.__lik2(self.__obj, self.__x_p, self.__y_p))
+        self.__dx[...] = np.asarray(dx, dtype=np.float64).reshape(self.__dx.shape)
+        res = self.__lik1(self.__obj, self.__x_p, self.__y_p, self.__dx_p, self.__grad_p)
+        return np.float64(res), self.__grad.astype(np.float64)
+
+    @property
+    def num_output(self):
+        return self.__num_output
+
+    @property
+    def num_latent(self):
+        return self.__num_latent
+
+    @property
+    def igp_dim(self):
+        return self.__igp_dim
+
+    @property
+    def num_param(self):
+        return self.__num_param
+
+    @property
+    def num_igp_param(self):
+        return self.__num_igp_param
+
+    @property
+    def params(self):
+        self.__get_params(self.__obj, self.__params_p)
+        return self.__params
+
+    @property
+    def covariance(self):
+        """pywrapper.py:256-270."""
+        params = self.params.copy()
+        M, L = self.num_output, self.num_latent
+        U = np.reshape(params[:M * L], (M, L))
+        sqrtS = np.diag(np.sqrt(params[M * L:(M + 1) * L]))
+        igp_params = np.reshape(params[-L * 3:], (L, 3))
+        B = np.diag([magnitude ** 0.5 * (3 ** 0.5 / lengthscale ** 0.5) ** 1.5 for magnitude, lengthscale, _ in igp_params])
+        return U @ sqrtS @ B @ sqrtS @ U.T

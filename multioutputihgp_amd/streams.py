@@ -1,0 +1,168 @@
+"""Batched, device-resident entry points (include/moihgp.h part 2) over torch tensors.
+
+torch is plumbing here: it owns device memory and streams; all arithmetic is in libmoihgp.so.
+
+Stream layout: SERIES-MAJOR `[L, ld]` (one contiguous row per latent), fp32 or fp64.  The per-tick loop of
+the reference callers (`for y in data: gp.step(x, y)`, example.py:40-42; moihgp_online.h:61-70;
+moihgp_regression.h:42-50) becomes ONE call over T ticks.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from ._lib import MoihgpError, c_double_p, last_error, load_library
+
+KERNEL_ID = {"Matern32": 0, "Matern52": 1, "Matern52ss": 1}
+_DT = {torch.float64: 0, torch.float32: 1}
+
+
+def _check(rc, lib):
+    if rc != 0:
+        raise MoihgpError(last_error(lib) or f"libmoihgp call failed (rc={rc})")
+
+
+def _stream_ptr(stream=None):
+    s = torch.cuda.current_stream() if stream is None else stream
+    return C.c_void_p(s.cuda_stream)
+
+
+def padded_len(T: int, dtype) -> int:
+    """Row length that satisfies the alignment contract of moihgp_filter_stream (16-byte vectors)."""
+    epv = 2 if dtype == torch.float64 else 4
+    return (T + epv - 1) // epv * epv
+
+
+def alloc_stream(L: int, T: int, dtype=torch.float32, device="cuda") -> torch.Tensor:
+    """[L, ld] tensor with ld = T rounded up; use `[:, :T]` for the payload."""
+    return torch.empty((L, padded_len(T, dtype)), dtype=dtype, device=device)
+
+
+class LatentBank:
+    """A shard of independent latent IHGPs (reference include/moihgp/ihgp.h `IHGP<SS>` x L) on one GPU.
+
+    Holds the stationary matrices of `L` latents (computed on device by `IHGP::update`, ihgp.h:117-201)
+    and runs the per-latent recursion + NLL over whole streams.
+    """
+
+    def __init__(self, dt: float, params_LP, kernel: str = "Matern52ss"):
+        self._lib = load_library()
+        p = np.ascontiguousarray(np.asarray(params_LP, dtype=np.float64).reshape(-1, 3))
+        self.L = p.shape[0]
+        self.kernel = kernel
+        self.d = 2 if KERNEL_ID[kernel] == 0 else 3
+        self.P = 3
+        self._h = self._lib.moihgp_new_latents(KERNEL_ID[kernel], float(dt), self.L, p.ctypes.data_as(c_double_p))
+        if not self._h:
+            raise MoihgpError(last_error(self._lib) or "moihgp_new_latents failed")
+        self.device = torch.device("cuda", torch.cuda.current_device())
+
+    @classmethod
+    def from_handle(cls, gp):
+        """View the latents of a full `MOIHGP` object (pywrapper.MOIHGP) without copying."""
+        self = cls.__new__(cls)
+        self._lib = load_library()
+        self._h = gp.handle
+        self._owner = gp
+        self.L = gp.num_latent
+        self.d = gp.igp_dim
+        self.P = gp.num_igp_param
+        self.kernel = None
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        return self
+
+    def __del__(self):
+        try:
+            if getattr(self, "_owner", None) is None and self._h:
+                self._lib.moihgp_del(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def update(self, params_LP):
+        p = np.ascontiguousarray(np.asarray(params_LP, dtype=np.float64).reshape(self.L, 3))
+        _check(self._lib.moihgp_update_latents(self._h, p.ctypes.data_as(c_double_p)), self._lib)
+
+    def latent(self, l: int) -> dict:
+        d, P = self.d, self.P
+        out = dict(A=np.zeros((d, d)), K=np.zeros(d), S=np.zeros(1), HA=np.zeros(d), AKHA=np.zeros((d, d)),
+                   dA=np.zeros((P, d, d)), dS=np.zeros(P), dK=np.zeros((P, d)), dAKHA=np.zeros((P, d, d)), HdA=np.zeros((P, d)))
+        iters = (C.c_int * (1 + P))()
+        ptrs = [out[k].ctypes.data_as(c_double_p) for k in ("A", "K", "S", "HA", "AKHA", "dA", "dS", "dK", "dAKHA", "HdA")]
+        _check(self._lib.moihgp_get_latent(self._h, l, *ptrs, iters), self._lib)
+        out["S"] = float(out["S"][0])
+        out["iters"] = list(iters)
+        return out
+
+    # ---------------------------------------------------------------------------------------
+    def _check_stream(self, Ty: torch.Tensor, T: Optional[int]):
+        if not Ty.is_cuda or Ty.dtype not in _DT or Ty.dim() != 2 or Ty.shape[0] != self.L or Ty.stride(1) != 1:
+            raise ValueError("Ty must be a CUDA tensor [L, ld] (float32/float64) with unit stride along time")
+        T = Ty.shape[1] if T is None else int(T)
+        return T, Ty.stride(0)
+
+    def filter(self, Ty: torch.Tensor, T: Optional[int] = None, x: Optional[torch.Tensor] = None,
+               want_yhat: bool = True, want_nll: bool = True, yhat: Optional[torch.Tensor] = None,
+               nll: Optional[torch.Tensor] = None, stream=None):
+        """One sweep of ihgp.h:81-93 (+ :204-209 on the pre-step state) over T ticks for every latent.
+
+        Returns (yhat [L, ld] or None, x [L, d] final state, nll [L] float64 or None).  Asynchronous on
+        the current torch stream.  `x` (initial state) is updated IN PLACE if given."""
+        T, ld = self._check_stream(Ty, T)
+        if x is None:
+            x = torch.zeros((self.L, self.d), dtype=Ty.dtype, device=Ty.device)
+        if want_yhat and yhat is None:
+            yhat = torch.empty_like(Ty)
+        if want_nll and nll is None:
+            nll = torch.empty((self.L,), dtype=torch.float64, device=Ty.device)
+        rc = self._lib.moihgp_filter_stream(
+            self._h, _DT[Ty.dtype], C.c_void_p(Ty.data_ptr()), T, ld, C.c_void_p(x.data_ptr()),
+            C.c_void_p(yhat.data_ptr()) if want_yhat else None,
+            C.c_void_p(nll.data_ptr()) if want_nll else None, _stream_ptr(stream))
+        _check(rc, self._lib)
+        return (yhat if want_yhat else None), x, (nll if want_nll else None)
+
+    def grad(self, Ty: torch.Tensor, T: Optional[int] = None, x: Optional[torch.Tensor] = None,
+             dx: Optional[torch.Tensor] = None, want_yhat: bool = False, stream=None):
+        """Sweep with sensitivities (ihgp.h:37-57) and the per-latent NLL gradient (ihgp.h:212-222).
+
+        Returns dict(yhat, x, dx, nll [L], grad [L, P])."""
+        T, ld = self._check_stream(Ty, T)
+        if x is None:
+            x = torch.zeros((self.L, self.d), dtype=Ty.dtype, device=Ty.device)
+        if dx is None:
+            dx = torch.zeros((self.L, self.P, self.d), dtype=Ty.dtype, device=Ty.device)
+        yhat = torch.empty_like(Ty) if want_yhat else None
+        nll = torch.empty((self.L,), dtype=torch.float64, device=Ty.device)
+        grad = torch.empty((self.L, self.P), dtype=torch.float64, device=Ty.device)
+        rc = self._lib.moihgp_grad_stream(
+            self._h, _DT[Ty.dtype], C.c_void_p(Ty.data_ptr()), T, ld, C.c_void_p(x.data_ptr()), C.c_void_p(dx.data_ptr()),
+            C.c_void_p(yhat.data_ptr()) if want_yhat else None, C.c_void_p(nll.data_ptr()), C.c_void_p(grad.data_ptr()),
+            _stream_ptr(stream))
+        _check(rc, self._lib)
+        return dict(yhat=yhat, x=x, dx=dx, nll=nll, grad=grad)
+
+
+def project_stream(gp, Y: torch.Tensor, stream=None) -> torch.Tensor:
+    """OILMM projection of a tick-major observation stream Y [T, M] with the mixing of `gp`
+    (a pywrapper.MOIHGP): returns the series-major projected stream [L, ld] (moihgp.h:181 per tick)."""
+    lib = load_library()
+    if not Y.is_cuda or Y.dtype not in _DT or Y.dim() != 2 or not Y.is_contiguous() or Y.shape[1] != gp.num_output:
+        raise ValueError("Y must be a contiguous CUDA tensor [T, M]")
+    T = Y.shape[0]
+    Ty = alloc_stream(gp.num_latent, T, Y.dtype, Y.device)
+    _check(lib.moihgp_project_stream(gp.handle, _DT[Y.dtype], C.c_void_p(Y.data_ptr()), T, C.c_void_p(Ty.data_ptr()),
+                                     Ty.stride(0), _stream_ptr(stream)), lib)
+    return Ty
+
+
+def unproject_stream(gp, Tyhat: torch.Tensor, T: int, stream=None) -> torch.Tensor:
+    """Yhat [T, M] = U S^1/2 Tyhat (moihgp.h:222-225 per tick) from a series-major stream [L, ld]."""
+    lib = load_library()
+    Yhat = torch.empty((T, gp.num_output), dtype=Tyhat.dtype, device=Tyhat.device)
+    _check(lib.moihgp_unproject_stream(gp.handle, _DT[Tyhat.dtype], C.c_void_p(Tyhat.data_ptr()), T, Tyhat.stride(0),
+                                       C.c_void_p(Yhat.data_ptr()), _stream_ptr(stream)), lib)
+    return Yhat

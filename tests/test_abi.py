@@ -1,0 +1,61 @@
+"""CPU suite: the C-ABI library builds for gfx950, loads, exports every symbol include/moihgp.h declares,
+and fails loudly (no fallback) without a GPU.  No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "moihgp.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b((?:gp32|gp52|moihgp)_[a-zA-Z0-9_]+)\s*\(", src)
+    return sorted(set(names))
+
+
+def test_header_declares_reference_abi():
+    names = _declared_symbols()
+    for pfx in ("gp32", "gp52"):          # reference src/wrapper.cpp:31-326, :329-624: 13 symbols per prefix
+        for n in ("new", "del", "step1", "step2", "step3", "step4", "update", "lik1", "lik2", "get_params",
+                  "igp_dim", "num_param", "num_igp_param"):
+            assert f"{pfx}_{n}" in names
+    assert len([n for n in names if n.startswith(("gp32_", "gp52_"))]) == 26
+
+
+def test_library_exports_every_declared_symbol(hip_built):
+    lib = C.CDLL(hip_built)
+    missing = [n for n in _declared_symbols() if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_python_loader_lists_match_header(hip_built):
+    from multioutputihgp_amd import _lib
+    assert sorted(_lib.REFERENCE_SYMBOLS + _lib.ADDITIVE_SYMBOLS) == _declared_symbols()
+    _lib.load_library()
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "multioutputihgp_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.replace("oracle/README.md", ""), f"{f} references the oracle"
+
+
+def test_fails_loudly_without_gpu(hip_built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from multioutputihgp_amd import MOIHGP, MoihgpError, load_library
+    lib = load_library()
+    assert lib.moihgp_device_count() == 0
+    with pytest.raises(MoihgpError) as ei:
+        MOIHGP(0.1, 4, 2)
+    assert "no usable HIP device" in str(ei.value) and "no CPU fallback" in str(ei.value)
+    from multioutputihgp_amd.streams import LatentBank
+    with pytest.raises(MoihgpError):
+        LatentBank(0.1, [[1.0, 1.0, 0.1]])

@@ -1,0 +1,316 @@
+"""GPU suite (-m gpu): the HIP path, called through the C ABI (ctypes -> libmoihgp.so), against the CPU
+oracle on the same seeded inputs, the committed golden vectors, and size-independent properties at
+BASELINE.json's full sizes.
+
+Tolerances (BASELINE.json north_star): 1e-6 relative for fp64, 1e-3 for fp32 on filtered means and NLL.
+The asserts below use tighter bars where the arithmetic allows, and say so."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+FP64_TOL = 1e-6      # the bar
+FP64_TIGHT = 1e-9    # what we actually expect from fp64 (rounding-order differences only)
+FP32_TOL = 1e-3
+KMAP = {"Matern32": "Matern32", "Matern52": "Matern52ss"}   # oracle kernel -> product kernel name
+
+
+@pytest.fixture(scope="module")
+def env(hip_built):
+    assert torch.cuda.is_available(), "GPU suite needs a GPU"
+    torch.cuda.set_device(0)
+    from multioutputihgp_amd import MOIHGP, load_library
+    from multioutputihgp_amd import streams
+    from oracle import cref
+    lib = load_library()
+    assert lib.moihgp_device_count() >= 1
+    return dict(MOIHGP=MOIHGP, streams=streams, cref=cref, lib=lib)
+
+
+def synth(L, T, rng, nan_frac=0.0):
+    t = np.arange(T)[None, :]; l = np.arange(L)[:, None]
+    Ty = np.sin(0.05 * t * (1 + l % 7)) + 0.1 * rng.standard_normal((L, T))
+    if nan_frac:
+        Ty[rng.random((L, T)) < nan_frac] = np.nan
+    return Ty
+
+
+def synth_params(L, rng):
+    return np.column_stack([rng.uniform(0.5, 2, L), rng.uniform(0.5, 2, L), rng.uniform(0.05, 0.2, L)])
+
+
+def to_dev(a, dtype):
+    """numpy [L, T] -> cuda [L, ld] padded per the alignment contract."""
+    from multioutputihgp_amd.streams import alloc_stream
+    L, T = a.shape
+    t = alloc_stream(L, T, dtype)
+    t.zero_()
+    t[:, :T] = torch.from_numpy(a).to(dtype)
+    return t
+
+
+# ------------------------------------------------------------------------------------------ A7
+@pytest.mark.parametrize("kern", ["Matern32", "Matern52"])
+def test_stationary_matrices_vs_golden(env, kern):
+    g = load_golden(f"stationary_{kern}.npz")
+    same_dt = np.isclose(g["dt"], 0.1)
+    bank = env["streams"].LatentBank(0.1, g["params"][same_dt], kernel=KMAP[kern])
+    worst = 0.0
+    for j, i in enumerate(np.nonzero(same_dt)[0]):
+        lat = bank.latent(j)
+        for k in ("A", "K", "HA", "AKHA", "dA", "dS", "dK", "dAKHA", "HdA"):
+            ref = g[k][i]
+            if np.max(np.abs(ref)) == 0:
+                assert np.max(np.abs(lat[k])) == 0
+            else:
+                e = rel_err(lat[k], ref); worst = max(worst, e)
+                assert e < FP64_TIGHT, (k, i, e)
+        assert abs(lat["S"] - g["S"][i]) / g["S"][i] < FP64_TIGHT
+        assert lat["iters"] == list(g["iters"][i])     # DARE / DLyap iteration counts (utils/dare.h)
+    print(f"stationary {kern}: worst rel err {worst:.2e}")
+
+
+# ------------------------------------------------------------------------------------------ A1-A6, A8 per-tick ABI
+@pytest.mark.parametrize("kern", ["Matern32", "Matern52"])
+@pytest.mark.parametrize("ML", [(2, 1), (4, 2), (6, 6), (8, 4)])
+def test_reference_abi_vs_golden(env, kern, ML):
+    M, L = ML
+    g = load_golden(f"moihgp_{kern}_M{M}_L{L}.npz")
+    gp = env["MOIHGP"](0.1, M, L, kernel=KMAP[kern])
+    assert gp.num_param == M * L + L + 1 + 3 * L and gp.num_igp_param == 3 and gp.igp_dim == (2 if kern == "Matern32" else 3)
+    gp.update(g["params_in"])
+    assert rel_err(gp.params, g["params_out"]) < FP64_TIGHT
+    a = gp.step(g["x"], g["y"], g["dx"])
+    assert rel_err(a[0], g["s1_xnew"]) < FP64_TIGHT and rel_err(a[1], g["s1_yhat"]) < FP64_TIGHT and rel_err(a[2], g["s1_dxnew"]) < FP64_TIGHT
+    b = gp.step_no_yhat(g["x"], g["y"], g["dx"])
+    assert rel_err(b[0], g["s1_xnew"]) < FP64_TIGHT and rel_err(b[1], g["s1_dxnew"]) < FP64_TIGHT
+    a = gp.step(g["x"], g["y"])
+    assert rel_err(a[0], g["s3_xnew"]) < FP64_TIGHT and rel_err(a[1], g["s3_yhat"]) < FP64_TIGHT
+    a = gp.step(g["x"])
+    assert rel_err(a[0], g["s4_xnew"]) < FP64_TIGHT and rel_err(a[1], g["s4_yhat"]) < FP64_TIGHT
+    assert abs(gp.negLogLikelihood(g["x"], g["y"]) - g["lik2"]) < FP64_TIGHT * abs(g["lik2"])
+    l1, g1 = gp.negLogLikelihood(g["x"], g["y"], g["dx"])
+    assert abs(l1 - g["lik1"]) < FP64_TIGHT * abs(g["lik1"])
+    assert rel_err(g1, g["grad"]) < 1e-8     # closed-form U-gradient vs the literal SVD loop of the golden
+    if "y_missing" in g:                      # least-squares projection over observed rows, moihgp.h:167-178
+        a = gp.step(g["x"], g["y_missing"])
+        assert rel_err(a[0], g["m3_xnew"]) < FP64_TIGHT and rel_err(a[1], g["m3_yhat"]) < FP64_TIGHT
+        assert np.isnan(gp.negLogLikelihood(g["x"], g["y_missing"]))   # moihgp.h:651 does not guard NaN
+
+
+@pytest.mark.parametrize("kern,M,L", [("Matern32", 64, 32), ("Matern52", 96, 96), ("Matern52", 300, 40)])
+def test_reference_abi_vs_oracle_larger(env, kern, M, L):
+    rng = np.random.default_rng(M * 1000 + L)
+    gp = env["MOIHGP"](0.1, M, L, kernel=KMAP[kern])
+    ref = env["cref"].GP(0.1, M, L, kern)
+    ref.set_literal_ugrad(0)
+    d, P = gp.igp_dim, 3
+    params = np.concatenate([(np.eye(M, L) + 0.2 * rng.standard_normal((M, L))).ravel(), rng.uniform(0.5, 2, L), [0.03], synth_params(L, rng).ravel()])
+    gp.update(params); ref.update(params)
+    assert rel_err(gp.params, ref.params) < FP64_TIGHT
+    x, dx = rng.standard_normal((L, d)), rng.standard_normal((L, P, d))
+    for _ in range(3):                        # a short closed loop: feed states forward like the callers do
+        y = rng.standard_normal(M)
+        l1, g1 = gp.negLogLikelihood(x, y, dx); l2, g2 = ref.negLogLikelihood(x, y, dx)
+        assert abs(l1 - l2) < FP64_TIGHT * abs(l2) and rel_err(g1, g2) < FP64_TIGHT
+        a = gp.step(x, y, dx); b = ref.step(x, y, dx)
+        for u, v in zip(a, b):
+            assert rel_err(u, v) < FP64_TIGHT
+        x, dx = a[0], a[2]
+    ym = y.copy(); ym[rng.choice(M, size=max(1, (M - L) // 2), replace=False)] = np.nan
+    if M > L:
+        a = gp.step(x, ym); b = ref.step(x, ym)
+        assert rel_err(a[0], b[0]) < 1e-8 and rel_err(a[1], b[1]) < 1e-8
+
+
+def test_gp52_alias_and_ctor_state(env):
+    # wrapper.cpp:22: GP52 is a typedef of the Matern-3/2 model; kept by default
+    gp = env["MOIHGP"](0.1, 5, 2, kernel="Matern52")
+    assert gp.igp_dim == 2
+    p = gp.params
+    M, L = 5, 2
+    U = p[:M * L].reshape(M, L)
+    assert np.max(np.abs(U.T @ U - np.eye(L))) < 1e-13 and np.max(np.abs(U - np.eye(M, L))) < 0.02   # moihgp.h:103-125
+    assert np.all(p[M * L:M * L + L] == 1.0) and p[M * L + L] == 1e-2                                  # moihgp.h:126-127
+    assert np.allclose(p[M * L + L + 1:].reshape(L, 3), [1.0, 1.0, 0.1])                               # matern32ss.h:34-36
+    gp.update(p)
+    assert rel_err(gp.params, p) < 1e-13       # get_params / update round trip (checkpoint = params)
+
+
+# ------------------------------------------------------------------------------------------ A1/A4 streams
+@pytest.mark.parametrize("kern", ["Matern32", "Matern52"])
+@pytest.mark.parametrize("tag", ["dense", "nan5"])
+def test_stream_vs_golden_fp64(env, kern, tag):
+    g = load_golden(f"stream_{kern}_{tag}.npz")
+    bank = env["streams"].LatentBank(float(g["dt"]), g["params"], kernel=KMAP[kern])
+    T = g["Ty"].shape[1]
+    Ty = to_dev(g["Ty"], torch.float64)
+    x = torch.from_numpy(g["x0"]).cuda()
+    yhat, xT, nll = bank.filter(Ty, T=T, x=x)
+    torch.cuda.synchronize()
+    e = (rel_err(yhat[:, :T].cpu().numpy(), g["yhat"]), rel_err(xT.cpu().numpy(), g["xT"]), rel_err(nll.cpu().numpy(), g["nll"]))
+    print(f"stream fp64 {kern} {tag}: yhat {e[0]:.2e} x {e[1]:.2e} nll {e[2]:.2e}")
+    assert max(e) < FP64_TIGHT and max(e) < FP64_TOL
+
+
+@pytest.mark.parametrize("kern", ["Matern32", "Matern52"])
+@pytest.mark.parametrize("tag", ["dense", "nan5"])
+def test_stream_vs_golden_fp32(env, kern, tag):
+    g = load_golden(f"stream_{kern}_{tag}.npz")
+    bank = env["streams"].LatentBank(float(g["dt"]), g["params"], kernel=KMAP[kern])
+    T = g["Ty"].shape[1]
+    Ty = to_dev(g["Ty"], torch.float32)
+    x = torch.from_numpy(g["x0"]).float().cuda()
+    yhat, xT, nll = bank.filter(Ty, T=T, x=x)
+    torch.cuda.synchronize()
+    e = (rel_err(yhat[:, :T].cpu().numpy(), g["yhat"]), rel_err(xT.cpu().numpy(), g["xT"]), rel_err(nll.cpu().numpy(), g["nll"]))
+    print(f"stream fp32 {kern} {tag}: yhat {e[0]:.2e} x {e[1]:.2e} nll {e[2]:.2e}")
+    assert max(e) < FP32_TOL
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("L,T", [(1, 1), (3, 3), (4, 511), (5, 512), (67, 513), (2, 1023), (9, 1024), (6, 1025), (130, 2600), (3, 0)])
+def test_stream_ragged_shapes_vs_oracle(env, dtype, L, T):
+    rng = np.random.default_rng(1000 * L + T)
+    prm = synth_params(L, rng)
+    bank = env["streams"].LatentBank(0.1, prm, kernel="Matern52ss")
+    igps = env["cref"].ihgp_array("Matern52", 0.1, prm)
+    Ty = synth(L, T, rng)
+    x0 = 0.2 * rng.standard_normal((L, 3))
+    if T == 0:
+        Tyd = torch.zeros((L, 4), dtype=dtype, device="cuda")
+        yhat, xT, nll = bank.filter(Tyd, T=0, x=torch.from_numpy(x0).to(dtype).cuda())
+        torch.cuda.synchronize()
+        assert rel_err(xT.cpu().numpy(), x0) < 1e-6 and float(nll.abs().sum()) == 0.0
+        return
+    o = env["cref"].filter_stream(igps, Ty, x0=x0)
+    Tyd = to_dev(Ty, dtype)
+    sentinel = 12345.0
+    yh = torch.full_like(Tyd, sentinel)
+    yhat, xT, nll = bank.filter(Tyd, T=T, x=torch.from_numpy(x0).to(dtype).cuda(), yhat=yh)
+    torch.cuda.synchronize()
+    tol = FP64_TIGHT if dtype == torch.float64 else FP32_TOL
+    assert rel_err(yhat[:, :T].cpu().numpy(), o["yhat"]) < tol
+    assert rel_err(xT.cpu().numpy(), o["x"]) < tol
+    assert rel_err(nll.cpu().numpy(), o["nll_per_latent"]) < tol
+    # nll-only and yhat-only variants agree with the fused one
+    _, x2, nll2 = bank.filter(Tyd, T=T, x=torch.from_numpy(x0).to(dtype).cuda(), want_yhat=False)
+    yh3, x3, _ = bank.filter(Tyd, T=T, x=torch.from_numpy(x0).to(dtype).cuda(), want_nll=False)
+    torch.cuda.synchronize()
+    assert torch.equal(nll2, nll) and torch.equal(x2, xT) and torch.equal(x3, xT) and torch.equal(yh3[:, :T], yhat[:, :T])
+
+
+def test_stream_all_missing_and_inf(env):
+    rng = np.random.default_rng(4)
+    L, T = 4, 1500
+    prm = synth_params(L, rng)
+    bank = env["streams"].LatentBank(0.1, prm, kernel="Matern32")
+    igps = env["cref"].ihgp_array("Matern32", 0.1, prm)
+    Ty = synth(L, T, rng)
+    Ty[0, :] = np.nan                 # a fully missing series: pure prediction x <- A x, NLL 0
+    Ty[1, 100:1400] = np.nan          # a long gap spanning whole segments
+    Ty[2, ::2] = np.nan               # every other tick missing
+    x0 = rng.standard_normal((L, 2))
+    o = env["cref"].filter_stream(igps, Ty, x0=x0)
+    yhat, xT, nll = bank.filter(to_dev(Ty, torch.float64), T=T, x=torch.from_numpy(x0).cuda())
+    torch.cuda.synchronize()
+    assert rel_err(yhat[:, :T].cpu().numpy(), o["yhat"]) < FP64_TIGHT
+    assert rel_err(nll.cpu().numpy(), o["nll_per_latent"]) < FP64_TIGHT and nll[0].item() == 0.0
+
+
+def test_stream_argument_errors(env):
+    bank = env["streams"].LatentBank(0.1, [[1, 1, 0.1]] * 4, kernel="Matern32")
+    from multioutputihgp_amd import MoihgpError
+    bad = torch.zeros((4, 10), dtype=torch.float32, device="cuda")      # ld = 10 is not a multiple of 4
+    with pytest.raises(MoihgpError):
+        bank.filter(bad, T=10)
+    with pytest.raises(ValueError):
+        bank.filter(torch.zeros((3, 12), dtype=torch.float32, device="cuda"))   # wrong L
+
+
+# ------------------------------------------------------------------------------------------ full-size properties
+@pytest.mark.parametrize("dtype,L,T", [(torch.float32, 4096, 10000), (torch.float64, 256, 10000), (torch.float64, 4096, 10000)])
+def test_full_size_properties(env, dtype, L, T):
+    """BASELINE configs C2/C3 shapes: checks that do not need a full-size oracle run --
+    (1) a 64-latent subset against the oracle, (2) linearity of the filter, (3) slab consistency
+    (one sweep == two sweeps carrying the state), (4) NLL additivity over slabs."""
+    rng = np.random.default_rng(7)
+    prm = synth_params(L, rng)
+    bank = env["streams"].LatentBank(0.1, prm, kernel="Matern52ss")
+    Ty = synth(L, T, rng)
+    tol = 1e-8 if dtype == torch.float64 else FP32_TOL
+    Tyd = to_dev(Ty, dtype)
+    yhat, xT, nll = bank.filter(Tyd, T=T)
+    torch.cuda.synchronize()
+    sub = np.sort(rng.choice(L, size=64, replace=False))
+    o = env["cref"].filter_stream(env["cref"].ihgp_array("Matern52", 0.1, prm[sub]), np.ascontiguousarray(Ty[sub]), nthreads=4)
+    e = (rel_err(yhat[sub][:, :T].cpu().numpy(), o["yhat"]), rel_err(xT[sub].cpu().numpy(), o["x"]), rel_err(nll[sub].cpu().numpy(), o["nll_per_latent"]))
+    print(f"full-size {dtype} L={L}: subset vs oracle yhat {e[0]:.2e} x {e[1]:.2e} nll {e[2]:.2e}")
+    assert max(e) < (FP64_TOL if dtype == torch.float64 else FP32_TOL)
+    # linearity (zero initial state): f(a y1 + b y2) = a f(y1) + b f(y2)
+    Y2 = to_dev(synth(L, T, rng), dtype)
+    f1 = yhat
+    f2, _, _ = bank.filter(Y2, T=T, want_nll=False)
+    f12, _, _ = bank.filter(2.0 * Tyd - 0.5 * Y2, T=T, want_nll=False)
+    torch.cuda.synchronize()
+    lin = (f12 - (2.0 * f1 - 0.5 * f2))[:, :T].abs().max().item() / f12[:, :T].abs().max().item()
+    assert lin < (1e-11 if dtype == torch.float64 else 2e-5), lin
+    # slab consistency + NLL additivity
+    cut = 4096 + 4 * 37
+    ya, xa, na = bank.filter(Tyd[:, :cut], T=cut)
+    yb, xb, nb = bank.filter(Tyd[:, cut:], T=T - cut, x=xa.clone())
+    torch.cuda.synchronize()
+    d1 = (torch.cat([ya[:, :cut], yb[:, :T - cut]], 1) - yhat[:, :T]).abs().max().item() / yhat[:, :T].abs().max().item()
+    d2 = ((na + nb) - nll).abs().max().item() / nll.abs().max().item()
+    d3 = (xb - xT).abs().max().item() / xT.abs().max().item()
+    assert max(d1, d2, d3) < tol, (d1, d2, d3)
+
+
+# ------------------------------------------------------------------------------------------ A2/A5 gradient sweep
+@pytest.mark.parametrize("kern", ["Matern32", "Matern52"])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_gradstream_vs_golden(env, kern, dtype):
+    g = load_golden(f"gradstream_{kern}.npz")
+    bank = env["streams"].LatentBank(float(g["dt"]), g["params"], kernel=KMAP[kern])
+    T = g["Ty"].shape[1]
+    r = bank.grad(to_dev(g["Ty"], dtype), T=T, x=torch.from_numpy(g["x0"]).to(dtype).cuda(),
+                  dx=torch.from_numpy(g["dx0"]).to(dtype).cuda(), want_yhat=True)
+    torch.cuda.synchronize()
+    tol = FP64_TIGHT if dtype == torch.float64 else FP32_TOL
+    assert rel_err(r["yhat"][:, :T].cpu().numpy(), g["yhat"]) < tol
+    assert rel_err(r["x"].cpu().numpy(), g["xT"]) < tol and rel_err(r["dx"].cpu().numpy(), g["dxT"]) < tol * 10
+    assert rel_err(r["nll"].cpu().numpy(), g["nll"]) < tol and rel_err(r["grad"].cpu().numpy(), g["grad"]) < tol * 10
+
+
+# ------------------------------------------------------------------------------------------ A3 projection over streams
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("M,L,T", [(8, 4, 50), (100, 70, 333), (256, 256, 1000)])
+def test_project_unproject_stream(env, dtype, M, L, T):
+    rng = np.random.default_rng(M + L + T)
+    gp = env["MOIHGP"](0.1, M, L, kernel="Matern32")
+    params = np.concatenate([(np.eye(M, L) + 0.2 * rng.standard_normal((M, L))).ravel(), rng.uniform(0.5, 2, L), [0.03], synth_params(L, rng).ravel()])
+    gp.update(params)
+    p = gp.params
+    U = p[:M * L].reshape(M, L); S = p[M * L:M * L + L]
+    Y = rng.standard_normal((T, M))
+    Ty = env["streams"].project_stream(gp, torch.from_numpy(Y).to(dtype).cuda())
+    ref = (Y @ U / np.sqrt(S)).T
+    tol = 1e-12 if dtype == torch.float64 else 1e-5
+    assert rel_err(Ty[:, :T].cpu().numpy(), ref) < tol
+    Yh = env["streams"].unproject_stream(gp, Ty, T)
+    ref2 = (ref.T * np.sqrt(S)) @ U.T
+    assert rel_err(Yh.cpu().numpy(), ref2) < tol * 10
+    # per-tick ABI and stream path agree: project -> filter -> unproject over the stream equals
+    # calling gp.step(x, y_t) tick by tick (the reference's caller loop, example.py:40-42)
+    bank = env["streams"].LatentBank.from_handle(gp)
+    yhat, xT, nll = bank.filter(Ty, T=T)
+    Yhat_f = env["streams"].unproject_stream(gp, yhat, T)
+    torch.cuda.synchronize()
+    x = np.zeros((L, gp.igp_dim))
+    nt = min(T, 20)
+    for t in range(nt):
+        x, yh = gp.step(x, Y[t])
+        assert rel_err(yh, Yhat_f[t].cpu().numpy()) < (1e-10 if dtype == torch.float64 else 1e-4)

@@ -1,0 +1,172 @@
+"""CPU suite: the oracle against itself (C vs NumPy), the committed golden vectors and analytic anchors.
+Parity with the reference itself is UNPINNED (no reference tests/fixtures; reference unbuildable here)."""
+import numpy as np
+import pytest
+from conftest import load_golden, rel_err
+
+from oracle import cref, moihgp_numpy as onp
+
+KERNELS = ("Matern32", "Matern52")
+
+
+def test_matern32_expm_closed_form():
+    # analytic anchor: expm(dt F) = e^{-lam dt} [[1 + lam dt, dt], [-lam^2 dt, 1 - lam dt]]
+    for ell, dt in [(1.0, 0.1), (0.37, 0.05), (2.5, 1.0)]:
+        lam = np.sqrt(3.0) / ell
+        F = np.array([[0.0, 1.0], [-lam * lam, -2 * lam]])
+        ref = np.exp(-lam * dt) * np.array([[1 + lam * dt, dt], [-lam * lam * dt, 1 - lam * dt]])
+        assert rel_err(cref.expm(dt * F), ref) < 1e-14
+        g = cref.ihgp_update("Matern32", dt, np.array([1.3, ell, 0.1]))
+        assert rel_err(g.mat("A"), ref) < 1e-14
+
+
+def test_expm_all_pade_branches_vs_scipy():
+    from scipy.linalg import expm
+    rng = np.random.default_rng(0)
+    for n in (2, 3, 4, 6):
+        for scale in (1e-3, 0.05, 0.5, 1.5, 4.0, 30.0):
+            A = rng.standard_normal((n, n))
+            A *= scale / np.abs(A).sum(axis=0).max()
+            assert rel_err(cref.expm(A), expm(A)) < 5e-13
+
+
+def test_survey_known_answers():
+    # SURVEY.md 8c provisional KATs (Matern-3/2, dt=0.1, params (1,1,0.1))
+    g = cref.ihgp_update("Matern32", 0.1, np.array([1.0, 1.0, 0.1]))
+    assert g.dare_iters == 13
+    assert abs(g.S - 0.36252384873095067) < 1e-14
+    np.testing.assert_allclose(g.mat("K"), [0.724156078696451, -1.003988227664166], rtol=1e-13)
+    np.testing.assert_allclose(g.mat("AKHA"), [[0.272154388833584, 0.023197511952301], [0.738269908855631, 0.779737607075854]], rtol=1e-12)
+    arr = cref.ihgp_array("Matern32", 0.1, np.array([[1.0, 1.0, 0.1]]))
+    r = cref.filter_stream(arr, np.array([[1.0, 0.5, -0.25, 0.75]]))
+    assert abs(r["nll"] - 0.954978477988885) < 1e-13
+    np.testing.assert_allclose(r["x"][0], [0.530230876912133, -0.743763121942643], rtol=1e-13)
+    g5 = cref.ihgp_update("Matern52", 0.1, np.array([1.0, 1.0, 0.1]))
+    assert g5.dare_iters == 100          # literal: truncated DARE (matern52ss.h:42 lam quirk)
+    assert abs(g5.S - 2.6888023285229594) < 1e-12
+
+
+def test_dare_residual_when_converged():
+    # the literal fixed-point equation of utils/dare.h:23 holds at the returned P when it converged
+    g = onp.IHGP(0.1, "Matern32")
+    assert g.dare_converged
+    A, HT, Q, R, P = g.A, g.ss.H.T, g.Q, g.ss.R, g.PP
+    G = R + HT.T @ P @ HT
+    Pn = A.T @ P @ A - A.T @ P @ HT @ np.linalg.inv(G) @ HT.T @ P @ A + Q
+    assert np.max(np.abs(Pn - P)) < 1e-7
+
+
+@pytest.mark.parametrize("kern", KERNELS)
+def test_stationary_golden(kern):
+    gld = load_golden(f"stationary_{kern}.npz")
+    for i, (p, dt) in enumerate(zip(gld["params"], gld["dt"])):
+        c = cref.ihgp_update(kern, float(dt), p)
+        n = onp.IHGP(float(dt), kern); n.update(p)
+        for k in ("A", "K", "HA", "AKHA", "dA", "dS", "dK", "dAKHA", "HdA"):
+            ref = gld[k][i]
+            if np.max(np.abs(ref)) == 0:
+                assert np.max(np.abs(c.mat(k))) == 0
+            else:
+                assert rel_err(c.mat(k), ref) < 1e-11, (k, i)
+        assert abs(c.S - gld["S"][i]) / gld["S"][i] < 1e-12
+        assert abs(n.S[0, 0] - gld["S"][i]) / gld["S"][i] < 1e-13
+        assert [c.dare_iters] + list(c.dlyap_iters)[:3] == list(gld["iters"][i])
+
+
+@pytest.mark.parametrize("kern", KERNELS)
+@pytest.mark.parametrize("ML", [(2, 1), (4, 2), (6, 6), (8, 4)])
+def test_moihgp_golden(kern, ML):
+    M, L = ML
+    g = load_golden(f"moihgp_{kern}_M{M}_L{L}.npz")
+    for impl in ("c", "numpy"):
+        if impl == "c":
+            gp = cref.GP(0.1, M, L, kern); gp.update(g["params_in"]); params = gp.params
+            step, nll = gp.step, gp.negLogLikelihood
+        else:
+            gp = onp.MOIHGP(0.1, M, L, kern); gp.update(g["params_in"]); params = gp.get_params()
+            step, nll = gp.step, gp.nll
+        assert rel_err(params, g["params_out"]) < 1e-12
+        U = params[:M * L].reshape(M, L)
+        assert np.max(np.abs(U.T @ U - np.eye(L))) < 1e-13          # polar factor is orthonormal
+        a = step(g["x"], g["y"], g["dx"])
+        assert rel_err(a[0], g["s1_xnew"]) < 1e-12 and rel_err(a[1], g["s1_yhat"]) < 1e-12 and rel_err(a[2], g["s1_dxnew"]) < 1e-12
+        a = step(g["x"], g["y"])
+        assert rel_err(a[0], g["s3_xnew"]) < 1e-12 and rel_err(a[1], g["s3_yhat"]) < 1e-12
+        a = step(g["x"])
+        assert rel_err(a[0], g["s4_xnew"]) < 1e-12 and rel_err(a[1], g["s4_yhat"]) < 1e-12
+        assert abs(nll(g["x"], g["y"]) - g["lik2"]) < 1e-11 * abs(g["lik2"])
+        l1, g1 = nll(g["x"], g["y"], g["dx"])
+        assert abs(l1 - g["lik1"]) < 1e-11 * abs(g["lik1"]) and rel_err(g1, g["grad"]) < 1e-11
+        if "y_missing" in g:
+            a = step(g["x"], g["y_missing"])
+            assert rel_err(a[0], g["m3_xnew"]) < 1e-11 and rel_err(a[1], g["m3_yhat"]) < 1e-11
+
+
+def test_ugrad_closed_form_equals_literal_loop():
+    # moihgp.h:538-552 collapses to a rank-1 form because U is a polar factor (singular values 1)
+    rng = np.random.default_rng(5)
+    M, L = 7, 3
+    gp = cref.GP(0.1, M, L, "Matern32")
+    params = np.concatenate([rng.standard_normal(M * L), rng.uniform(0.5, 2, L), [0.05], np.tile([1.2, 0.8, 0.1], L)])
+    gp.update(params)
+    x, dx, y = rng.standard_normal((L, 2)), rng.standard_normal((L, 3, 2)), rng.standard_normal(M)
+    _, g_lit = gp.negLogLikelihood(x, y, dx)
+    gp.set_literal_ugrad(0)
+    _, g_cf = gp.negLogLikelihood(x, y, dx)
+    assert rel_err(g_cf, g_lit) < 1e-12
+
+
+@pytest.mark.parametrize("kern", KERNELS)
+@pytest.mark.parametrize("tag", ["dense", "nan5"])
+def test_stream_golden(kern, tag):
+    g = load_golden(f"stream_{kern}_{tag}.npz")
+    igps = cref.ihgp_array(kern, float(g["dt"]), g["params"])
+    for layout in (0, 1):
+        Ty = g["Ty"] if layout == 0 else np.ascontiguousarray(g["Ty"].T)
+        r = cref.filter_stream(igps, Ty, layout=layout, x0=g["x0"], nthreads=2)
+        yh = r["yhat"] if layout == 0 else r["yhat"].T
+        assert rel_err(yh, g["yhat"]) < 1e-12 and rel_err(r["x"], g["xT"]) < 1e-12
+        assert rel_err(r["nll_per_latent"], g["nll"]) < 1e-12
+    # fp32 variant stays within the fp32 bar of the fp64 golden
+    r32 = cref.filter_stream(igps, g["Ty"].astype(np.float32), x0=g["x0"].astype(np.float32))
+    assert rel_err(r32["yhat"], g["yhat"]) < 1e-4 and rel_err(r32["nll_per_latent"], g["nll"]) < 1e-4
+
+
+@pytest.mark.parametrize("kern", KERNELS)
+def test_gradstream_golden(kern):
+    g = load_golden(f"gradstream_{kern}.npz")
+    igps = cref.ihgp_array(kern, float(g["dt"]), g["params"])
+    r = cref.grad_stream(igps, g["Ty"], x0=g["x0"], dx0=g["dx0"])
+    assert rel_err(r["yhat"], g["yhat"]) < 1e-12 and rel_err(r["x"], g["xT"]) < 1e-12
+    assert rel_err(r["dx"], g["dxT"]) < 1e-10 and rel_err(r["grad"], g["grad"]) < 1e-10
+    assert rel_err(r["nll_per_latent"], g["nll"]) < 1e-12
+
+
+def test_refshaped_loop_matches():
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    L, T = 5, 200
+    params = np.column_stack([rng.uniform(0.5, 2, L), rng.uniform(0.5, 2, L), rng.uniform(0.05, 0.2, L)])
+    igps = cref.ihgp_array("Matern52", 0.1, params)
+    Ty = rng.standard_normal((L, T))
+    a = cref.filter_stream(igps, Ty)
+    x = np.zeros((L, 3)); yh = np.zeros((L, T))
+    dp = C.POINTER(C.c_double)
+    cref.lib().orc_filter_stream_refshaped(igps, L, T, Ty.ctypes.data_as(dp), T, 0, x.ctypes.data_as(dp), yh.ctypes.data_as(dp))
+    assert rel_err(yh, a["yhat"]) < 1e-15 and rel_err(x, a["x"]) < 1e-15
+
+
+def test_filter_is_linear_and_slab_consistent():
+    # domain properties the GPU tests rely on at full size
+    rng = np.random.default_rng(11)
+    L, T = 4, 500
+    params = np.column_stack([rng.uniform(0.5, 2, L), rng.uniform(0.5, 2, L), rng.uniform(0.05, 0.2, L)])
+    igps = cref.ihgp_array("Matern52", 0.1, params)
+    y1, y2 = rng.standard_normal((L, T)), rng.standard_normal((L, T))
+    f = lambda y: cref.filter_stream(igps, y)["yhat"]
+    assert rel_err(f(2.0 * y1 - 3.0 * y2), 2.0 * f(y1) - 3.0 * f(y2)) < 1e-12
+    whole = cref.filter_stream(igps, y1)
+    a = cref.filter_stream(igps, np.ascontiguousarray(y1[:, :123]))
+    b = cref.filter_stream(igps, np.ascontiguousarray(y1[:, 123:]), x0=a["x"])
+    assert rel_err(np.hstack([a["yhat"], b["yhat"]]), whole["yhat"]) < 1e-15
+    assert abs(a["nll"] + b["nll"] - whole["nll"]) < 1e-12 * abs(whole["nll"])
