@@ -102,7 +102,15 @@ class LatentBank:
         if not Ty.is_cuda or Ty.dtype not in _DT or Ty.dim() != 2 or Ty.shape[0] != self.L or Ty.stride(1) != 1:
             raise ValueError("Ty must be a CUDA tensor [L, ld] (float32/float64) with unit stride along time")
         T = Ty.shape[1] if T is None else int(T)
+        if T < 0 or T > Ty.shape[1]:
+            raise ValueError("T exceeds the stream tensor")
         return T, Ty.stride(0)
+
+    @staticmethod
+    def _like_stream(Ty: torch.Tensor) -> torch.Tensor:
+        """Output stream with the SAME row stride as Ty (Ty may be a column slice of a wider slab)."""
+        buf = torch.empty((Ty.shape[0], Ty.stride(0)), dtype=Ty.dtype, device=Ty.device)
+        return buf[:, :Ty.shape[1]]
 
     def filter(self, Ty: torch.Tensor, T: Optional[int] = None, x: Optional[torch.Tensor] = None,
                want_yhat: bool = True, want_nll: bool = True, yhat: Optional[torch.Tensor] = None,
@@ -114,8 +122,14 @@ class LatentBank:
         T, ld = self._check_stream(Ty, T)
         if x is None:
             x = torch.zeros((self.L, self.d), dtype=Ty.dtype, device=Ty.device)
-        if want_yhat and yhat is None:
-            yhat = torch.empty_like(Ty)
+        if want_yhat:
+            if yhat is None:
+                yhat = self._like_stream(Ty)
+            elif (not yhat.is_cuda or yhat.dtype != Ty.dtype or yhat.dim() != 2 or yhat.stride(1) != 1
+                  or yhat.stride(0) != ld or yhat.shape[0] != self.L or yhat.shape[1] < T):
+                raise ValueError("yhat must match Ty: same dtype, [L, >=T], same row stride (the C ABI has one ld)")
+        if x.dtype != Ty.dtype or not x.is_contiguous() or tuple(x.shape) != (self.L, self.d):
+            raise ValueError("x must be a contiguous [L, d] tensor of the stream dtype")
         if want_nll and nll is None:
             nll = torch.empty((self.L,), dtype=torch.float64, device=Ty.device)
         rc = self._lib.moihgp_filter_stream(
@@ -135,7 +149,9 @@ class LatentBank:
             x = torch.zeros((self.L, self.d), dtype=Ty.dtype, device=Ty.device)
         if dx is None:
             dx = torch.zeros((self.L, self.P, self.d), dtype=Ty.dtype, device=Ty.device)
-        yhat = torch.empty_like(Ty) if want_yhat else None
+        if x.dtype != Ty.dtype or dx.dtype != Ty.dtype or not x.is_contiguous() or not dx.is_contiguous():
+            raise ValueError("x / dx must be contiguous tensors of the stream dtype")
+        yhat = self._like_stream(Ty) if want_yhat else None
         nll = torch.empty((self.L,), dtype=torch.float64, device=Ty.device)
         grad = torch.empty((self.L, self.P), dtype=torch.float64, device=Ty.device)
         rc = self._lib.moihgp_grad_stream(
