@@ -146,11 +146,20 @@ int moihgp_grad_stream(moihgp_gp* gp, int dtype, const void* Ty, size_t T, size_
  * example.py:40-42); the projected stream comes out series-major [L][ld] ready for the recursion:
  *     Ty[l][t] = S_l^-1/2 * sum_m U[m][l] Y[t][m]                 (moihgp.h:181)
  * and back:  Yhat[t][m] = sum_l U[m][l] S_l^1/2 Tyhat[l][t]       (moihgp.h:222-225)
- * Rows with NaNs are NOT handled here (they need the least-squares projection, moihgp.h:167-178):
- * moihgp_project_stream returns the number of ticks containing NaN in *n_nan_ticks (host int,
- * may be NULL; forces a sync) and leaves NaN in Ty for those ticks. */
+ * Ticks whose observation vector contains NaN are NOT re-projected here (the reference switches those
+ * ticks to a least-squares projection over the observed rows, moihgp.h:167-178): the NaN propagates
+ * into Ty[:, t], i.e. the whole tick is treated as missing by the recursion.  Use the per-tick ABI
+ * (gp32_step*) for partially observed ticks. */
 int moihgp_project_stream(moihgp_gp* gp, int dtype, const void* Y, size_t T, void* Ty, size_t ld, void* stream);
 int moihgp_unproject_stream(moihgp_gp* gp, int dtype, const void* Tyhat, size_t T, size_t ld, void* Yhat, void* stream);
+
+/* Kernel-exact timing of moihgp_filter_stream launches (bench / diagnosis).  After
+ * moihgp_profile_enable(gp, n) the next n launches on this handle are bracketed by a HIP event pair
+ * attached to the dispatch itself (hipExtLaunchKernel), not to the stream.  moihgp_profile_read waits
+ * for them, writes the per-launch durations in milliseconds, rearms the slots and returns the count.
+ * moihgp_profile_enable(gp, 0) turns it off. */
+int moihgp_profile_enable(moihgp_gp* gp, int max_launches);
+int moihgp_profile_read(moihgp_gp* gp, float* ms, int n);
 
 /* Stream synchronisation helper for callers without a HIP runtime binding. */
 int moihgp_stream_sync(void* stream);

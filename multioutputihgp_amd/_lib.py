@@ -21,6 +21,7 @@ ADDITIVE_SYMBOLS = [
     "moihgp_num_output", "moihgp_num_latent", "moihgp_reseed_U", "moihgp_new_latents",
     "moihgp_update_latents", "moihgp_get_latent", "moihgp_filter_stream", "moihgp_grad_stream",
     "moihgp_project_stream", "moihgp_unproject_stream", "moihgp_stream_sync",
+    "moihgp_profile_enable", "moihgp_profile_read",
 ]
 
 
@@ -85,6 +86,10 @@ def load_library():
     lib.moihgp_project_stream.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.moihgp_unproject_stream.restype = C.c_int
     lib.moihgp_unproject_stream.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
+    lib.moihgp_profile_enable.restype = C.c_int
+    lib.moihgp_profile_enable.argtypes = [C.c_void_p, C.c_int]
+    lib.moihgp_profile_read.restype = C.c_int
+    lib.moihgp_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
     lib.moihgp_stream_sync.restype = C.c_int
     lib.moihgp_stream_sync.argtypes = [C.c_void_p]
     _LIB = lib

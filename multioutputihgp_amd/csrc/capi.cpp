@@ -116,6 +116,9 @@ struct moihgp_gp {
     double *dx = nullptr, *dy = nullptr, *ddx = nullptr, *dxnew = nullptr, *dyhat = nullptr, *ddxnew = nullptr;
     double *dTy = nullptr, *dUty = nullptr, *dTyhat = nullptr, *dloss = nullptr, *dgrad = nullptr, *dscratch = nullptr;
     double* dwork = nullptr;   // L*L + L, lazily (missing-output projection)
+    // optional kernel-exact timing of filter launches (moihgp_profile_enable)
+    std::vector<hipEvent_t> prof_ev;
+    int prof_n = 0;
 
     TickArgs tick() const { return TickArgs{d, M, L, cb64, dU, dS, dsigma}; }
 };
@@ -126,6 +129,7 @@ static void gp_free(moihgp_gp* g) {
                     g->ddxnew, g->dTy, g->dUty, g->dTyhat, g->dloss, g->dgrad, g->dscratch, g->dwork};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    for (hipEvent_t e : g->prof_ev) (void)hipEventDestroy(e);
     if (g->stream) (void)hipStreamDestroy(g->stream);
     delete g;
 }
@@ -389,7 +393,39 @@ static int check_stream_args(moihgp_gp* gp, int dtype, const void* Ty, size_t T,
 int moihgp_filter_stream(moihgp_gp* gp, int dtype, const void* Ty, size_t T, size_t ld, void* x, void* yhat, double* nll, void* stream) {
     if (int rc = check_stream_args(gp, dtype, Ty, T, ld, x)) return rc;
     if (yhat && ((uintptr_t)yhat & 15) != 0) { set_last_error("yhat base must be 16-byte aligned"); return 1; }
-    return launch_filter_stream(gp->d, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cb32, x, yhat, nll, (hipStream_t)stream);
+    const char* ve = std::getenv("MOIHGP_FILTER_VARIANT");   // tuning hook: kernel tiling variant
+    const int variant = ve ? std::atoi(ve) : 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (!gp->prof_ev.empty() && 2 * (size_t)(gp->prof_n + 1) <= gp->prof_ev.size()) {
+        e0 = gp->prof_ev[2 * gp->prof_n];
+        e1 = gp->prof_ev[2 * gp->prof_n + 1];
+        gp->prof_n++;
+    }
+    return launch_filter_stream(gp->d, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cb32, x, yhat, nll, (hipStream_t)stream, variant, e0, e1);
+}
+
+int moihgp_profile_enable(moihgp_gp* gp, int max_launches) {
+    if (!gp) { set_last_error("null handle"); return 1; }
+    for (hipEvent_t e : gp->prof_ev) (void)hipEventDestroy(e);
+    gp->prof_ev.clear();
+    gp->prof_n = 0;
+    for (int i = 0; i < 2 * max_launches; i++) {
+        hipEvent_t e;
+        MOIHGP_HIP_FATAL(hipEventCreate(&e));
+        gp->prof_ev.push_back(e);
+    }
+    return 0;
+}
+
+int moihgp_profile_read(moihgp_gp* gp, float* ms, int n) {
+    if (!gp) { set_last_error("null handle"); return -1; }
+    int cnt = gp->prof_n < n ? gp->prof_n : n;
+    for (int i = 0; i < cnt; i++) {
+        MOIHGP_HIP_FATAL(hipEventSynchronize(gp->prof_ev[2 * i + 1]));
+        MOIHGP_HIP_FATAL(hipEventElapsedTime(&ms[i], gp->prof_ev[2 * i], gp->prof_ev[2 * i + 1]));
+    }
+    gp->prof_n = 0;
+    return cnt;
 }
 
 int moihgp_grad_stream(moihgp_gp* gp, int dtype, const void* Ty, size_t T, size_t ld, void* x, void* dx, void* yhat, double* nll,

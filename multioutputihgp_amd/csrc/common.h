@@ -29,9 +29,17 @@ struct CB {
     static constexpr int DS    = HDA + P * D;       // [P]                         ihgp.h:188
     static constexpr int PARAMS = DS + P;           // [P]    hyper-parameters of this latent
     static constexpr int ITERS = PARAMS + P;        // [1+P]  DARE / DLyap iteration counts (as scalars)
-    static constexpr int RAW   = ITERS + 1 + P;
+    // ---- tables for the time-parallel segment solve of recursion.hip (derived from AKHA, K) ----
+    // CK = ticks per lane per segment: kChunk32 in the fp32 copy of the block, kChunk64 in the fp64 one.
+    static constexpr int G     = ITERS + 1 + P;     // [16][D]   g_k = AKHA^(CK-1-k) K, chunk response z = sum_k g_k y_k
+    static constexpr int SP    = G + 16 * D;        // [4][D*D]  M^(1,2,4,8), M = AKHA^CK (in-row scan levels)
+    static constexpr int PJ    = SP + 4 * D * D;    // [16][D*D] M^(r+1), r = lane % 16 (cross-row fix-up)
+    static constexpr int RAW   = PJ + 16 * D * D;
     static constexpr int SIZE  = (RAW + 3) / 4 * 4; // padded to 16/32 bytes
 };
+
+constexpr int kChunk32 = 16;   // fp32: 16 ticks = 64 B per lane per segment (1024-tick segments)
+constexpr int kChunk64 = 8;    // fp64:  8 ticks = 64 B per lane per segment (512-tick segments)
 
 constexpr int cb_size(int d) { return d == 2 ? CB<2>::SIZE : CB<3>::SIZE; }
 
@@ -54,7 +62,7 @@ void launch_ihgp_update(int kernel, int d, double dt, const double* params_dev, 
 // recursion.hip: batched sweeps over series-major streams.
 int launch_filter_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, size_t L,
                          const double* cb64, const float* cb32, void* x, void* yhat, double* nll,
-                         hipStream_t stream);
+                         hipStream_t stream, int variant = 0, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 int launch_grad_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, size_t L,
                        const double* cb64, const float* cb32, void* x, void* dx, void* yhat,
                        double* nll, double* grad, hipStream_t stream);

@@ -19,6 +19,7 @@
 // Missing data (NaN y, ihgp.h:83-87: x <- A x) and the ragged tail segment make chunk maps
 // lane-dependent; those segments take the generic path that scans (M_j, z_j) pairs.
 #include "common.h"
+#include <hip/hip_ext.h>
 
 namespace moihgp {
 namespace {
@@ -70,9 +71,233 @@ __device__ inline void matmul(const T* a, const T* b, T* c) {
 
 constexpr int kWavesPerBlock = 4;
 
+// ---- DPP lane movement (no LDS, no ds_bpermute) --------------------------------------------------
+// v_mov_b32_dpp with `old` = 0: lanes that the control leaves without a source (or that row_mask
+// excludes) read 0, which is exactly the "no contribution" value of the scan below.
+template <int CTRL, int ROW_MASK>
+__device__ inline float dpp0(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ inline double dpp0(double v) {
+    unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, ROW_MASK, 0xF, false);
+    unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, ROW_MASK, 0xF, false);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+// wave_shr:1 with lane 0 keeping `first`
+__device__ inline float wave_shr1(float v, float first) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, first), __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, false));
+}
+__device__ inline double wave_shr1(double v, double first) {
+    unsigned long long u = __builtin_bit_cast(unsigned long long, v), f = __builtin_bit_cast(unsigned long long, first);
+    unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)f, (int)(unsigned)u, 0x138, 0xF, 0xF, false);
+    unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(f >> 32), (int)(unsigned)(u >> 32), 0x138, 0xF, 0xF, false);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ inline float read_lane(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+__device__ inline double read_lane(double v, int l) {
+    unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), l);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+constexpr int DPP_ROW_SHR = 0x110, DPP_ROW_BCAST15 = 0x142;
+
+// Per-latent constants of the fast path.  sp / g / a / k are wave-uniform; pj is per lane.
+template <typename T, int D, int CK>
+struct FastConst {
+    T a[D * D];        // A = expm(dt F): x <- A x + K v is the innovation form of ihgp.h:90 (v = y - HA x)
+    T k[D];            // K
+    T g[CK * D];       // g_k = AKHA^(CK-1-k) K
+    T sp[4 * D * D];   // M^(1,2,4,8), M = AKHA^CK
+    T pj[D * D];       // M^(lane%16 + 1)
+};
+
+// Fast path for one segment (64 lanes x CK ticks) of one latent without missing ticks.  y[] holds the
+// lane's chunk on entry and the filtered means on exit.  xin (wave-uniform) is the state before the
+// segment's first tick and is replaced by the state after its last valid tick.
+//   1. chunk response from a zero state as a CK-tap dot product  z_j = sum_k g_k y_k  (no serial chain);
+//      lane 0 adds M xin
+//   2. inclusive scan s_j = M s_{j-1} + z_j over the 64 lanes, all in DPP: four in-row Kogge-Stone
+//      levels (row_shr 1,2,4,8 with the uniform M^(1,2,4,8)), then three row_bcast:15 rounds that hand
+//      the finished prefix of row r-1 to row r through the per-lane power M^(lane%16+1)
+//   3. replay of the chunk from its true start state in innovation form (H = e0^T, so HA is row 0 of A):
+//      hx = A0.x ; v = y - hx ; yhat = hx + K0 v ; x_i <- A_i.x + K_i v
+//   TAIL = true: ragged last segment (zero padded): lanes past the end never feed a valid lane; the
+//   replay is masked per tick.
+// Returns false (wave-uniform) without touching xin / acc when a NaN was met: the caller then runs
+// generic_segment() on the chunk still parked in LDS.
+template <typename T, int D, int CK, bool NLL, bool TAIL>
+__device__ inline bool fast_segment(T* y, T* xin, const FastConst<T, D, CK>& c, int lane, size_t t0, size_t Tlen,
+                                    double& acc, unsigned& nobs) {
+    // ---- 1. chunk response ----------------------------------------------------------------------
+    T z[D];
+#pragma unroll
+    for (int i = 0; i < D; i++) z[i] = T(0);
+#pragma unroll
+    for (int k = 0; k < CK; k++)
+#pragma unroll
+        for (int i = 0; i < D; i++) z[i] = fma(c.g[k * D + i], y[k], z[i]);
+    bool bad = false;                       // a NaN y poisons z: one vote per segment detects missing data
+#pragma unroll
+    for (int i = 0; i < D; i++) bad |= (z[i] != z[i]);
+    if (__any(bad)) return false;
+    {
+        T x0[D];
+#pragma unroll
+        for (int i = 0; i < D; i++) x0[i] = (lane == 0) ? xin[i] : T(0);
+        matvec_acc<T, D>(c.sp, x0, z);      // lane 0: + M xin
+    }
+    // ---- 2. scan --------------------------------------------------------------------------------
+    {
+        T t[D];
+#pragma unroll
+        for (int i = 0; i < D; i++) t[i] = dpp0<DPP_ROW_SHR + 1, 0xF>(z[i]);
+        matvec_acc<T, D>(c.sp + 0 * D * D, t, z);
+#pragma unroll
+        for (int i = 0; i < D; i++) t[i] = dpp0<DPP_ROW_SHR + 2, 0xF>(z[i]);
+        matvec_acc<T, D>(c.sp + 1 * D * D, t, z);
+#pragma unroll
+        for (int i = 0; i < D; i++) t[i] = dpp0<DPP_ROW_SHR + 4, 0xF>(z[i]);
+        matvec_acc<T, D>(c.sp + 2 * D * D, t, z);
+#pragma unroll
+        for (int i = 0; i < D; i++) t[i] = dpp0<DPP_ROW_SHR + 8, 0xF>(z[i]);
+        matvec_acc<T, D>(c.sp + 3 * D * D, t, z);
+#pragma unroll
+        for (int i = 0; i < D; i++) t[i] = dpp0<DPP_ROW_BCAST15, 0x2>(z[i]);
+        matvec_acc<T, D>(c.pj, t, z);
+#pragma unroll
+        for (int i = 0; i < D; i++) t[i] = dpp0<DPP_ROW_BCAST15, 0x4>(z[i]);
+        matvec_acc<T, D>(c.pj, t, z);
+#pragma unroll
+        for (int i = 0; i < D; i++) t[i] = dpp0<DPP_ROW_BCAST15, 0x8>(z[i]);
+        matvec_acc<T, D>(c.pj, t, z);
+    }
+    // exclusive state: lane j starts from the inclusive result of lane j-1, lane 0 from xin
+    T xs[D];
+#pragma unroll
+    for (int i = 0; i < D; i++) xs[i] = wave_shr1(z[i], xin[i]);
+    // ---- 3. replay ------------------------------------------------------------------------------
+    T part = 0;                              // sum of v^2 over this chunk (<= 16 terms) in stream precision
+#pragma unroll
+    for (int k = 0; k < CK; k++) {
+        const bool valid = !TAIL || (t0 + k) < Tlen;
+        T hx = 0;
+#pragma unroll
+        for (int j = 0; j < D; j++) hx = fma(c.a[j], xs[j], hx);
+        T v = y[k] - hx;
+        if (TAIL) v = valid ? v : T(0);
+        if (NLL) {
+            part = fma(v, v, part);
+            if (TAIL) nobs += valid ? 1u : 0u;
+        }
+        T xn[D];
+        xn[0] = fma(c.k[0], v, hx);
+#pragma unroll
+        for (int i = 1; i < D; i++) {
+            T s = c.k[i] * v;
+#pragma unroll
+            for (int j = 0; j < D; j++) s = fma(c.a[i * D + j], xs[j], s);
+            xn[i] = s;
+        }
+#pragma unroll
+        for (int i = 0; i < D; i++) xs[i] = (TAIL && !valid) ? xs[i] : xn[i];
+        y[k] = xs[0];
+    }
+    if (NLL) acc += (double)part;
+    // state after the last valid tick = final replay state of the lane that owns it
+    int jl = 63;
+    if (TAIL) {
+        size_t last = Tlen - 1 - (t0 - (size_t)lane * CK);
+        jl = (int)(last / CK);
+    }
+#pragma unroll
+    for (int i = 0; i < D; i++) xin[i] = read_lane(xs[i], jl);
+    return true;
+}
+
+// Missing-data path (ihgp.h:83-87: a NaN observation advances x <- A x): chunk maps become
+// lane-dependent, so (M_j, z_j) pairs are scanned (Kogge-Stone over 64 lanes with shuffles).  Works on the
+// chunk parked in LDS (ch = this lane's CK elements) and leaves the filtered means there; rolled loops
+// and its own constant loads keep it out of the register budget of the fast path.
+template <typename T, int D, int CK, bool NLL>
+__device__ inline void generic_segment(T* ch, T* xin, const T* cb /* this latent's constant block */,
+                                       int lane, size_t t0, size_t Tlen, double& acc, unsigned& nobs) {
+    using Lay = CB<D>;
+    T aa[D * D], akha[D * D], kk[D], ha[D], mj[D * D], z[D];
+#pragma unroll
+    for (int i = 0; i < D * D; i++) { aa[i] = cb[Lay::A + i]; akha[i] = cb[Lay::AKHA + i]; mj[i] = (i % (D + 1) == 0) ? T(1) : T(0); }
+#pragma unroll
+    for (int i = 0; i < D; i++) { kk[i] = cb[Lay::K + i]; ha[i] = cb[Lay::HA + i]; z[i] = (lane == 0) ? xin[i] : T(0); }
+#pragma unroll 1
+    for (int k = 0; k < CK; k++) {
+        const T yk = ch[k];
+        const bool miss = (yk != yk);
+        if ((t0 + k) < Tlen) {
+            T b[D * D], zn[D];
+#pragma unroll
+            for (int i = 0; i < D * D; i++) b[i] = miss ? aa[i] : akha[i];
+#pragma unroll
+            for (int i = 0; i < D; i++) zn[i] = miss ? T(0) : kk[i] * yk;
+            matvec_acc<T, D>(b, z, zn);
+#pragma unroll
+            for (int i = 0; i < D; i++) z[i] = zn[i];
+            matmul<T, D>(b, mj, mj);
+        }
+    }
+#pragma unroll 1
+    for (int s = 0; s < 6; s++) {
+        const int o = 1 << s;
+        T zp[D], mq[D * D];
+#pragma unroll
+        for (int i = 0; i < D; i++) zp[i] = __shfl_up(z[i], o);
+#pragma unroll
+        for (int i = 0; i < D * D; i++) mq[i] = __shfl_up(mj[i], o);
+        if (lane >= o) {
+            matvec_acc<T, D>(mj, zp, z);
+            matmul<T, D>(mj, mq, mj);
+        }
+    }
+    T xs[D];
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+        T up = __shfl_up(z[i], 1);
+        xs[i] = (lane == 0) ? xin[i] : up;
+    }
+#pragma unroll 1
+    for (int k = 0; k < CK; k++) {
+        const T yk = ch[k];
+        const bool miss = (yk != yk);
+        if ((t0 + k) < Tlen) {
+            if (NLL && !miss) {
+                T hx = 0;
+#pragma unroll
+                for (int i = 0; i < D; i++) hx = fma(ha[i], xs[i], hx);
+                double v = (double)(yk - hx);
+                acc = fma(v, v, acc);
+                nobs++;
+            }
+            T b[D * D], xn[D];
+#pragma unroll
+            for (int i = 0; i < D * D; i++) b[i] = miss ? aa[i] : akha[i];
+#pragma unroll
+            for (int i = 0; i < D; i++) xn[i] = miss ? T(0) : kk[i] * yk;
+            matvec_acc<T, D>(b, xs, xn);
+#pragma unroll
+            for (int i = 0; i < D; i++) xs[i] = xn[i];
+        }
+        ch[k] = xs[0];
+    }
+    size_t tb = t0 - (size_t)lane * CK;               // wave-uniform segment base
+    size_t last = Tlen - 1 - tb;
+    int jl = (last / CK) > 63 ? 63 : (int)(last / CK);
+#pragma unroll
+    for (int i = 0; i < D; i++) xin[i] = __shfl(xs[i], jl);
+}
+
 // ---------------------------------------------------------------------------------------------
-template <typename T, int D, int CK, bool WRITE, bool NLL>
-__global__ void __launch_bounds__(64 * kWavesPerBlock)
+template <typename T, int D, int CK, bool WRITE, bool NLL, int MINW, int DBG = 0>
+__global__ void __launch_bounds__(64 * kWavesPerBlock, MINW)
 filter_scan_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, const T* __restrict__ cbT,
                    const double* __restrict__ cb64, T* __restrict__ x, T* __restrict__ yhat, double* __restrict__ nll) {
     using V = typename VecOf<T>::type;
@@ -81,7 +306,7 @@ filter_scan_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, c
     constexpr int VPL = CK / EPV;              // vectors per lane per segment
     constexpr int SEG = 64 * CK;               // ticks per segment
     constexpr int NVP = 64 * (VPL + 1);        // padded vectors per wave tile (one pad vector per lane row)
-    static_assert(CK % EPV == 0 && (CK & (CK - 1)) == 0, "CK must be a power of two multiple of 16 bytes");
+    static_assert(CK % EPV == 0 && CK <= 16, "CK must be a multiple of 16 bytes and fit the G table");
     __shared__ V lds_all[kWavesPerBlock][NVP];
 
     const int lane = threadIdx.x & 63;
@@ -89,30 +314,21 @@ filter_scan_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, c
     const size_t l = (size_t)blockIdx.x * kWavesPerBlock + wave;
     if (l >= L) return;
     V* lds = lds_all[wave];
+    T* chunk = reinterpret_cast<T*>(&lds[lane * (VPL + 1)]);   // this lane's CK elements inside the tile
 
-    // ---- wave-uniform per-latent constants -------------------------------------------------
-    const T* c = cbT + l * Lay::SIZE;
-    T akha[D * D], kk[D], aa[D * D], ha[D];
+    // ---- per-latent constants: wave-uniform scalar loads, plus this lane's cross-row power ----------
+    const T* cb = cbT + l * Lay::SIZE;
+    FastConst<T, D, CK> c;
 #pragma unroll
-    for (int i = 0; i < D * D; i++) { akha[i] = c[Lay::AKHA + i]; aa[i] = c[Lay::A + i]; }
+    for (int i = 0; i < D * D; i++) c.a[i] = cb[Lay::A + i];
 #pragma unroll
-    for (int i = 0; i < D; i++) { kk[i] = c[Lay::K + i]; ha[i] = c[Lay::HA + i]; }
-    // scan powers M^(2^s), M = AKHA^CK, from the fp64 master copy
-    T mp[6][D * D];
-    {
-        const double* c64 = cb64 + l * Lay::SIZE;
-        double m[D * D];
+    for (int i = 0; i < D; i++) c.k[i] = cb[Lay::K + i];
 #pragma unroll
-        for (int i = 0; i < D * D; i++) m[i] = c64[Lay::AKHA + i];
+    for (int i = 0; i < CK * D; i++) c.g[i] = cb[Lay::G + i];
 #pragma unroll
-        for (int s = 1; s < CK; s <<= 1) matmul<double, D>(m, m, m);
+    for (int i = 0; i < 4 * D * D; i++) c.sp[i] = cb[Lay::SP + i];
 #pragma unroll
-        for (int s = 0; s < 6; s++) {
-#pragma unroll
-            for (int i = 0; i < D * D; i++) mp[s][i] = (T)m[i];
-            if (s < 5) matmul<double, D>(m, m, m);
-        }
-    }
+    for (int i = 0; i < D * D; i++) c.pj[i] = cb[Lay::PJ + (lane & 15) * D * D + i];
 
     const T* row = Ty + l * ld;
     T* orow = WRITE ? yhat + l * ld : nullptr;
@@ -121,31 +337,37 @@ filter_scan_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, c
     for (int i = 0; i < D; i++) xin[i] = x[l * D + i];
 
     double acc = 0.0;          // per-lane sum of v^2 over observed ticks
-    unsigned nobs = 0;         // per-lane count of observed ticks handled by the generic path
-    size_t nobs_uniform = 0;   // observed ticks handled by the fast path (same for all lanes: count per wave)
+    unsigned nobs = 0;         // per-lane count of observed ticks (tail / generic segments)
+    size_t nobs_uniform = 0;   // observed ticks of full fast-path segments (every lane contributes CK)
 
     const size_t nfull = Tlen / SEG;
     const size_t nseg = (Tlen + SEG - 1) / SEG;
 
     V r[VPL];
-    auto load_seg = [&](size_t seg) {
+    auto load_full = [&](size_t seg) {
+        const T* p = row + seg * SEG + (size_t)lane * EPV;
+#pragma unroll
+        for (int i = 0; i < VPL; i++) r[i] = *reinterpret_cast<const V*>(p + (size_t)i * 64 * EPV);
+    };
+    auto load_tail = [&](size_t seg) {
         const size_t base = seg * SEG;
-        if (seg < nfull) {
 #pragma unroll
-            for (int i = 0; i < VPL; i++) r[i] = *reinterpret_cast<const V*>(row + base + (size_t)(i * 64 + lane) * EPV);
-        } else {
+        for (int i = 0; i < VPL; i++) {
+            size_t tq = base + (size_t)(i * 64 + lane) * EPV;
+            T e[EPV] = {};
+            if (tq < Tlen) {                                        // ld >= roundup(T, EPV): the vector is in bounds
+                unpack<T>(*reinterpret_cast<const V*>(row + tq), e);
 #pragma unroll
-            for (int i = 0; i < VPL; i++) {
-                size_t t0 = base + (size_t)(i * 64 + lane) * EPV;
-                T zero[EPV] = {};
-                r[i] = (t0 < Tlen) ? *reinterpret_cast<const V*>(row + t0) : pack<T>(zero);   // ld >= roundup(T, EPV)
+                for (int k = 0; k < EPV; k++) if (tq + k >= Tlen) e[k] = T(0);   // row padding may hold anything
             }
+            r[i] = pack<T>(e);
         }
     };
-    if (nseg > 0) load_seg(0);
+    if (nfull > 0) load_full(0); else if (nseg > 0) load_tail(0);
 
     for (size_t seg = 0; seg < nseg; seg++) {
         const size_t tbase = seg * SEG;
+        const size_t t0 = tbase + (size_t)lane * CK;
         // ---- coalesced registers -> LDS -> chunk-per-lane registers ---------------------------
 #pragma unroll
         for (int i = 0; i < VPL; i++) {
@@ -153,158 +375,52 @@ filter_scan_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, c
             lds[q + q / VPL] = r[i];
         }
         wave_lds_fence();
-        T y[CK];
+        bool done;
+        {
+            T y[CK];
 #pragma unroll
-        for (int k = 0; k < VPL; k++) {
-            V v = lds[lane * (VPL + 1) + k];
-            unpack<T>(v, &y[k * EPV]);
+            for (int k = 0; k < VPL; k++) {
+                V v = lds[lane * (VPL + 1) + k];
+                unpack<T>(v, &y[k * EPV]);
+            }
+            // prefetch the next segment: in flight during the arithmetic below
+            if (seg + 1 < nfull) load_full(seg + 1); else if (seg + 1 < nseg) load_tail(seg + 1);
+            if (DBG == 1) {                      // tuning probe: staging path only, no arithmetic
+                done = true;
+#pragma unroll
+                for (int k = 0; k < CK; k++) y[k] = y[k] + xin[0];
+            } else if (seg < nfull) {
+                done = fast_segment<T, D, CK, NLL, false>(y, xin, c, lane, t0, Tlen, acc, nobs);
+                if (done) nobs_uniform += SEG;
+            } else {
+                done = fast_segment<T, D, CK, NLL, true>(y, xin, c, lane, t0, Tlen, acc, nobs);
+            }
+            if (done && WRITE) {
+#pragma unroll
+                for (int k = 0; k < VPL; k++) lds[lane * (VPL + 1) + k] = pack<T>(&y[k * EPV]);
+            }
+        }
+        if (!done) generic_segment<T, D, CK, NLL>(chunk, xin, cb, lane, t0, Tlen, acc, nobs);
+
+        // ---- LDS -> coalesced stores ----------------------------------------------------------
+        if (WRITE) {
+            wave_lds_fence();
+            T* po = orow + tbase + (size_t)lane * EPV;
+            if (seg < nfull) {
+#pragma unroll
+                for (int i = 0; i < VPL; i++) {
+                    int q = i * 64 + lane;
+                    *reinterpret_cast<V*>(po + (size_t)i * 64 * EPV) = lds[q + q / VPL];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < VPL; i++) {
+                    int q = i * 64 + lane;
+                    if (tbase + (size_t)q * EPV < Tlen) *reinterpret_cast<V*>(po + (size_t)i * 64 * EPV) = lds[q + q / VPL];
+                }
+            }
         }
         wave_lds_fence();
-        if (seg + 1 < nseg) load_seg(seg + 1);   // prefetch: in flight during the arithmetic below
-
-        bool generic = (seg >= nfull);            // ragged tail
-        T z[D];
-        if (!generic) {
-            // ---- pass 1: chunk response from zero state (lane 0: from the carried-in state) ----
-#pragma unroll
-            for (int i = 0; i < D; i++) z[i] = (lane == 0) ? xin[i] : T(0);
-#pragma unroll
-            for (int k = 0; k < CK; k++) {
-                T zn[D];
-#pragma unroll
-                for (int i = 0; i < D; i++) zn[i] = kk[i] * y[k];
-                matvec_acc<T, D>(akha, z, zn);
-#pragma unroll
-                for (int i = 0; i < D; i++) z[i] = zn[i];
-            }
-            // a NaN anywhere in the chunk poisons z: route the whole segment to the generic path
-            bool bad = false;
-#pragma unroll
-            for (int i = 0; i < D; i++) bad |= (z[i] != z[i]);
-            generic = __any(bad);
-        }
-        if (!generic) {
-            // ---- Kogge-Stone scan with uniform chunk map powers ------------------------------
-#pragma unroll
-            for (int s = 0; s < 6; s++) {
-                const int o = 1 << s;
-                T t[D];
-#pragma unroll
-                for (int i = 0; i < D; i++) t[i] = __shfl_up(z[i], o);
-                if (lane >= o) matvec_acc<T, D>(mp[s], t, z);
-            }
-            T xs[D];
-#pragma unroll
-            for (int i = 0; i < D; i++) {
-                T up = __shfl_up(z[i], 1);
-                xs[i] = (lane == 0) ? xin[i] : up;
-                xin[i] = __shfl(z[i], 63);
-            }
-            // ---- pass 2: replay the chunk from its true start state ---------------------------
-#pragma unroll
-            for (int k = 0; k < CK; k++) {
-                if (NLL) {
-                    T hx = 0;
-#pragma unroll
-                    for (int i = 0; i < D; i++) hx = fma(ha[i], xs[i], hx);
-                    double v = (double)(y[k] - hx);
-                    acc = fma(v, v, acc);
-                }
-                T xn[D];
-#pragma unroll
-                for (int i = 0; i < D; i++) xn[i] = kk[i] * y[k];
-                matvec_acc<T, D>(akha, xs, xn);
-#pragma unroll
-                for (int i = 0; i < D; i++) xs[i] = xn[i];
-                y[k] = xs[0];
-            }
-            nobs_uniform += SEG;
-        } else {
-            // ---- generic path: lane-dependent chunk maps (missing ticks, ragged tail) ----------
-            const size_t t0 = tbase + (size_t)lane * CK;
-            T mj[D * D];
-#pragma unroll
-            for (int i = 0; i < D * D; i++) mj[i] = (i % (D + 1) == 0) ? T(1) : T(0);
-#pragma unroll
-            for (int i = 0; i < D; i++) z[i] = (lane == 0) ? xin[i] : T(0);
-#pragma unroll
-            for (int k = 0; k < CK; k++) {
-                const bool valid = (t0 + k) < Tlen;
-                const T yk = y[k];
-                const bool miss = (yk != yk);
-                if (valid) {
-                    T b[D * D], zn[D];
-#pragma unroll
-                    for (int i = 0; i < D * D; i++) b[i] = miss ? aa[i] : akha[i];
-#pragma unroll
-                    for (int i = 0; i < D; i++) zn[i] = miss ? T(0) : kk[i] * yk;
-                    matvec_acc<T, D>(b, z, zn);
-#pragma unroll
-                    for (int i = 0; i < D; i++) z[i] = zn[i];
-                    matmul<T, D>(b, mj, mj);
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < 6; s++) {
-                const int o = 1 << s;
-                T zp[D], mq[D * D];
-#pragma unroll
-                for (int i = 0; i < D; i++) zp[i] = __shfl_up(z[i], o);
-#pragma unroll
-                for (int i = 0; i < D * D; i++) mq[i] = __shfl_up(mj[i], o);
-                if (lane >= o) {
-                    matvec_acc<T, D>(mj, zp, z);
-                    matmul<T, D>(mj, mq, mj);
-                }
-            }
-            T xs[D];
-#pragma unroll
-            for (int i = 0; i < D; i++) {
-                T up = __shfl_up(z[i], 1);
-                xs[i] = (lane == 0) ? xin[i] : up;
-                xin[i] = __shfl(z[i], 63);
-            }
-#pragma unroll
-            for (int k = 0; k < CK; k++) {
-                const bool valid = (t0 + k) < Tlen;
-                const T yk = y[k];
-                const bool miss = (yk != yk);
-                if (valid) {
-                    if (NLL && !miss) {
-                        T hx = 0;
-#pragma unroll
-                        for (int i = 0; i < D; i++) hx = fma(ha[i], xs[i], hx);
-                        double v = (double)(yk - hx);
-                        acc = fma(v, v, acc);
-                        nobs++;
-                    }
-                    T b[D * D], xn[D];
-#pragma unroll
-                    for (int i = 0; i < D * D; i++) b[i] = miss ? aa[i] : akha[i];
-#pragma unroll
-                    for (int i = 0; i < D; i++) xn[i] = miss ? T(0) : kk[i] * yk;
-                    matvec_acc<T, D>(b, xs, xn);
-#pragma unroll
-                    for (int i = 0; i < D; i++) xs[i] = xn[i];
-                    y[k] = xs[0];
-                }
-            }
-        }
-
-        // ---- chunk-per-lane registers -> LDS -> coalesced stores ------------------------------
-        if (WRITE) {
-#pragma unroll
-            for (int k = 0; k < VPL; k++) lds[lane * (VPL + 1) + k] = pack<T>(&y[k * EPV]);
-            wave_lds_fence();
-#pragma unroll
-            for (int i = 0; i < VPL; i++) {
-                int q = i * 64 + lane;
-                V o = lds[q + q / VPL];
-                size_t tq = tbase + (size_t)q * EPV;
-                if (seg < nfull || tq < Tlen) *reinterpret_cast<V*>(orow + tq) = o;
-            }
-            wave_lds_fence();
-        }
     }
 
     // ---- epilogue: carried-out state and the latent's NLL ---------------------------------------
@@ -400,21 +516,22 @@ grad_seq_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
     for (int p = 0; p < P; p++) grad[l * P + p] = g[p];
 }
 
-template <typename T, int D, int CK>
+template <typename T, int D, int CK, int MINW>
 int launch_filter_t(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, const double* cb64, void* x,
-                    void* yhat, double* nll, hipStream_t stream) {
+                    void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     dim3 block(64 * kWavesPerBlock), grid((unsigned)((L + kWavesPerBlock - 1) / kWavesPerBlock));
     const T* ty = static_cast<const T*>(Ty);
     T* xs = static_cast<T*>(x);
     T* yh = static_cast<T*>(yhat);
+    // hipExtLaunchKernelGGL attaches the (optional) events to the dispatch itself: kernel-exact timing
     if (yhat && nll)
-        hipLaunchKernelGGL((filter_scan_kernel<T, D, CK, true, true>), grid, block, 0, stream, ty, Tlen, ld, L, cbT, cb64, xs, yh, nll);
+        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, true, true, MINW>), grid, block, 0, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xs, yh, nll);
     else if (yhat)
-        hipLaunchKernelGGL((filter_scan_kernel<T, D, CK, true, false>), grid, block, 0, stream, ty, Tlen, ld, L, cbT, cb64, xs, yh, nll);
+        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, true, false, MINW>), grid, block, 0, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xs, yh, nll);
     else if (nll)
-        hipLaunchKernelGGL((filter_scan_kernel<T, D, CK, false, true>), grid, block, 0, stream, ty, Tlen, ld, L, cbT, cb64, xs, yh, nll);
+        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, false, true, MINW>), grid, block, 0, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xs, yh, nll);
     else
-        hipLaunchKernelGGL((filter_scan_kernel<T, D, CK, false, false>), grid, block, 0, stream, ty, Tlen, ld, L, cbT, cb64, xs, yh, nll);
+        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, false, false, MINW>), grid, block, 0, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xs, yh, nll);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_last_error("filter_scan_kernel launch: %s", hipGetErrorString(e)); return 2; }
     return 0;
@@ -423,14 +540,31 @@ int launch_filter_t(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* c
 }  // namespace
 
 int launch_filter_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* cb64,
-                         const float* cb32, void* x, void* yhat, double* nll, hipStream_t stream) {
+                         const float* cb32, void* x, void* yhat, double* nll, hipStream_t stream, int variant,
+                         hipEvent_t ev0, hipEvent_t ev1) {
     if (L == 0) return 0;
+#define MOIHGP_FILTER_CASE(TT, DD, CKK, MW, CB) return launch_filter_t<TT, DD, CKK, MW>(Ty, T, ld, L, CB, cb64, x, yhat, nll, stream, ev0, ev1)
     if (dtype == 0) {
-        if (d == 2) return launch_filter_t<double, 2, 8>(Ty, T, ld, L, cb64, cb64, x, yhat, nll, stream);
-        return launch_filter_t<double, 3, 8>(Ty, T, ld, L, cb64, cb64, x, yhat, nll, stream);
+        if (d == 2) { MOIHGP_FILTER_CASE(double, 2, kChunk64, 1, cb64); }
+        switch (variant) {
+            case 1: MOIHGP_FILTER_CASE(double, 3, kChunk64, 3, cb64);
+            case 2: MOIHGP_FILTER_CASE(double, 3, kChunk64, 4, cb64);
+            default: MOIHGP_FILTER_CASE(double, 3, kChunk64, 1, cb64);
+        }
     }
-    if (d == 2) return launch_filter_t<float, 2, 16>(Ty, T, ld, L, cb32, cb64, x, yhat, nll, stream);
-    return launch_filter_t<float, 3, 16>(Ty, T, ld, L, cb32, cb64, x, yhat, nll, stream);
+    if (d == 2) { MOIHGP_FILTER_CASE(float, 2, kChunk32, 1, cb32); }
+    switch (variant) {
+        case 1: MOIHGP_FILTER_CASE(float, 3, kChunk32, 3, cb32);
+        case 2: MOIHGP_FILTER_CASE(float, 3, kChunk32, 4, cb32);
+        case 9: {   // tuning probe (staging only)
+            dim3 block(64 * kWavesPerBlock), grid((unsigned)((L + kWavesPerBlock - 1) / kWavesPerBlock));
+            hipExtLaunchKernelGGL((filter_scan_kernel<float, 3, kChunk32, true, true, 1, 1>), grid, block, 0, stream, ev0, ev1, 0,
+                                  (const float*)Ty, T, ld, L, cb32, cb64, (float*)x, (float*)yhat, nll);
+            return 0;
+        }
+        default: MOIHGP_FILTER_CASE(float, 3, kChunk32, 1, cb32);
+    }
+#undef MOIHGP_FILTER_CASE
 }
 
 int launch_grad_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* cb64,

@@ -381,7 +381,38 @@ __global__ void __launch_bounds__(64) ihgp_update_kernel(int kernel, double dt, 
     }
     double* o64 = cb64 + l * L::SIZE;
     float* o32 = cb32 + l * L::SIZE;
-    for (int i = 0; i < L::SIZE; i++) { o64[i] = out[i]; o32[i] = (float)out[i]; }
+    for (int i = 0; i < L::G; i++) { o64[i] = out[i]; o32[i] = (float)out[i]; }
+    // tables of the segment solve (recursion.hip), one set per stream dtype because the chunk length differs
+    for (int pass = 0; pass < 2; pass++) {
+        const int ck = pass == 0 ? kChunk64 : kChunk32;
+        double tab[L::SIZE - L::G];
+        for (int i = 0; i < L::SIZE - L::G; i++) tab[i] = 0.0;
+        double* G = tab;                       // [16][D]
+        double* SP = tab + (L::SP - L::G);      // [4][NN]
+        double* PJ = tab + (L::PJ - L::G);      // [16][NN]
+        const double* AKHA = out + L::AKHA;
+        double g[D], M[NN];
+        for (int i = 0; i < D; i++) g[i] = K[i];
+        for (int k = ck - 1; k >= 0; k--) {      // g_k = AKHA^(ck-1-k) K
+            for (int i = 0; i < D; i++) G[k * D + i] = g[i];
+            mv<D>(AKHA, g, g);
+        }
+        for (int i = 0; i < NN; i++) M[i] = AKHA[i];
+        for (int q = 1; q < ck; q <<= 1) mm<D>(M, M, M);   // M = AKHA^ck
+        double Pw[NN];
+        for (int i = 0; i < NN; i++) Pw[i] = M[i];
+        for (int lv = 0; lv < 4; lv++) {
+            for (int i = 0; i < NN; i++) SP[lv * NN + i] = Pw[i];
+            mm<D>(Pw, Pw, Pw);
+        }
+        for (int i = 0; i < NN; i++) Pw[i] = M[i];
+        for (int r = 0; r < 16; r++) {
+            for (int i = 0; i < NN; i++) PJ[r * NN + i] = Pw[i];
+            mm<D>(Pw, M, Pw);
+        }
+        if (pass == 0) for (int i = 0; i < L::SIZE - L::G; i++) o64[L::G + i] = tab[i];
+        else for (int i = 0; i < L::SIZE - L::G; i++) o32[L::G + i] = (float)tab[i];
+    }
 }
 
 }  // namespace

@@ -97,6 +97,18 @@ class LatentBank:
         out["iters"] = list(iters)
         return out
 
+    def profile_enable(self, max_launches: int):
+        """Attach HIP event pairs to the next `max_launches` filter dispatches (kernel-exact timing)."""
+        _check(self._lib.moihgp_profile_enable(self._h, int(max_launches)), self._lib)
+        self._prof_cap = int(max_launches)
+
+    def profile_read(self):
+        """Per-launch kernel durations (ms) of the filter dispatches since the last read."""
+        n = getattr(self, "_prof_cap", 0)
+        buf = (C.c_float * max(n, 1))()
+        cnt = self._lib.moihgp_profile_read(self._h, buf, n)
+        return [float(buf[i]) for i in range(max(cnt, 0))]
+
     # ---------------------------------------------------------------------------------------
     def _check_stream(self, Ty: torch.Tensor, T: Optional[int]):
         if not Ty.is_cuda or Ty.dtype not in _DT or Ty.dim() != 2 or Ty.shape[0] != self.L or Ty.stride(1) != 1:

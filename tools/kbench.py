@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Kernel-level A/B of the filter_scan_kernel tiling variants (MOIHGP_FILTER_VARIANT), one process,
+interleaved rounds, kernel-exact durations from dispatch-attached HIP events (moihgp_profile_*).
+usage: python tools/kbench.py [--dtype f32|f64] [--L 4096] [--T 10000] [--variants 0,1,2,...] [--rounds 5] [--nan 0.0]"""
+import argparse, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from bench import synth_params, synth_stream, SEED
+from multioutputihgp_amd.streams import LatentBank
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--dtype", default="f32"); ap.add_argument("--L", type=int, default=4096); ap.add_argument("--T", type=int, default=10000)
+ap.add_argument("--variants", default="0,1,2,3,4,5"); ap.add_argument("--rounds", type=int, default=5); ap.add_argument("--per", type=int, default=10)
+ap.add_argument("--nan", type=float, default=0.0); ap.add_argument("--mode", default="fn", help="f=yhat, n=nll")
+a = ap.parse_args()
+dtype = torch.float32 if a.dtype == "f32" else torch.float64
+dev = torch.device("cuda", 0); torch.cuda.set_device(0)
+prm = synth_params(a.L, 0, np.random.default_rng(SEED))
+bank = LatentBank(0.1, prm, kernel="Matern52ss")
+Ty = synth_stream(a.L, 0, a.T, dtype, dev, SEED + 1)
+if a.nan > 0:
+    Ty[torch.rand(Ty.shape, device=dev) < a.nan] = float("nan")
+yhat = torch.empty_like(Ty); nll = torch.empty((a.L,), dtype=torch.float64, device=dev)
+x = torch.zeros((a.L, 3), dtype=dtype, device=dev)
+variants = [int(v) for v in a.variants.split(",")]
+es = 4 if dtype == torch.float32 else 8
+nbytes = (("f" in a.mode) + 1) * es * a.L * a.T
+times = {v: [] for v in variants}; ref = None
+bank.profile_enable(a.per)
+for rnd in range(a.rounds):
+    for v in variants:
+        os.environ["MOIHGP_FILTER_VARIANT"] = str(v)
+        for _ in range(a.per):
+            x.zero_()
+            bank.filter(Ty, T=a.T, x=x, yhat=yhat, nll=nll, want_yhat="f" in a.mode, want_nll="n" in a.mode)
+        times[v] += bank.profile_read()
+        torch.cuda.synchronize()
+        if "n" in a.mode:
+            tot = nll.sum().item()
+            if ref is None: ref = tot
+            assert v == 9 or abs(tot - ref) <= 1e-5 * abs(ref), (v, tot, ref)
+print(f"dtype={a.dtype} L={a.L} T={a.T} mode={a.mode} nan={a.nan} bytes/launch={nbytes/1e6:.1f} MB")
+for v in variants:
+    t = np.array(times[v]) * 1e3
+    print(f"variant {v}: min {t.min():7.1f} us  median {np.median(t):7.1f} us  -> {nbytes/np.median(t)/1e6:6.2f} TB/s ({nbytes/np.median(t)/1e6/8*100:4.1f}% of 8 TB/s)")
