@@ -401,7 +401,21 @@ int moihgp_filter_stream(moihgp_gp* gp, int dtype, const void* Ty, size_t T, siz
         e1 = gp->prof_ev[2 * gp->prof_n + 1];
         gp->prof_n++;
     }
-    return launch_filter_stream(gp->d, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cb32, x, yhat, nll, (hipStream_t)stream, variant, e0, e1);
+    // time split across the wavefronts of a workgroup when there are too few latents to fill the chip
+    int nsplit = 1; size_t Tslice = T;
+    filter_split_plan(dtype, T, gp->L, &nsplit, &Tslice);
+    if (const char* se = std::getenv("MOIHGP_FILTER_SPLIT")) {          // tuning hook: force the slice count (1 = off)
+        int n = std::atoi(se);
+        const size_t seg = 64 * (size_t)(dtype == 0 ? kChunk64 : kChunk32);
+        if (n <= 1 || T == 0) { nsplit = 1; Tslice = T; }
+        else {
+            if (n > 8) n = 8;
+            size_t per = ((T + seg - 1) / seg + n - 1) / n; if (per < 1) per = 1;
+            Tslice = per * seg; nsplit = (int)((T + Tslice - 1) / Tslice);
+        }
+    }
+    return launch_filter_stream(gp->d, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cb32, x, yhat, nll, (hipStream_t)stream, variant, e0, e1,
+                                nsplit, Tslice);
 }
 
 int moihgp_profile_enable(moihgp_gp* gp, int max_launches) {

@@ -62,7 +62,10 @@ void launch_ihgp_update(int kernel, int d, double dt, const double* params_dev, 
 // recursion.hip: batched sweeps over series-major streams.
 int launch_filter_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, size_t L,
                          const double* cb64, const float* cb32, void* x, void* yhat, double* nll,
-                         hipStream_t stream, int variant = 0, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+                         hipStream_t stream, int variant = 0, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
+                         int nsplit = 1, size_t Tslice = 0);
+// Time split for small L (slices of one latent = wavefronts of one workgroup): nsplit == 1 means none.
+void filter_split_plan(int dtype, size_t T, size_t L, int* nsplit, size_t* Tslice);
 int launch_grad_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, size_t L,
                        const double* cb64, const float* cb32, void* x, void* dx, void* yhat,
                        double* nll, double* grad, hipStream_t stream);

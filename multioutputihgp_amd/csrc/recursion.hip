@@ -127,7 +127,7 @@ struct FastConst {
 //   replay is masked per tick.
 // Returns false (wave-uniform) without touching xin / acc when a NaN was met: the caller then runs
 // generic_segment() on the chunk still parked in LDS.
-template <typename T, int D, int CK, bool NLL, bool TAIL>
+template <typename T, int D, int CK, bool NLL, bool TAIL, bool ENDONLY = false>
 __device__ inline bool fast_segment(T* y, T* xin, const FastConst<T, D, CK>& c, int lane, size_t t0, size_t Tlen,
                                     double& acc, unsigned& nobs) {
     // ---- 1. chunk response ----------------------------------------------------------------------
@@ -172,6 +172,11 @@ __device__ inline bool fast_segment(T* y, T* xin, const FastConst<T, D, CK>& c, 
 #pragma unroll
         for (int i = 0; i < D; i++) t[i] = dpp0<DPP_ROW_BCAST15, 0x8>(z[i]);
         matvec_acc<T, D>(c.pj, t, z);
+    }
+    if (ENDONLY) {                           // only the state after the (full) segment is wanted: no replay
+#pragma unroll
+        for (int i = 0; i < D; i++) xin[i] = read_lane(z[i], 63);
+        return true;
     }
     // exclusive state: lane j starts from the inclusive result of lane j-1, lane 0 from xin
     T xs[D];
@@ -222,7 +227,8 @@ __device__ inline bool fast_segment(T* y, T* xin, const FastConst<T, D, CK>& c, 
 // and its own constant loads keep it out of the register budget of the fast path.
 template <typename T, int D, int CK, bool NLL>
 __device__ inline void generic_segment(T* ch, T* xin, const T* cb /* this latent's constant block */,
-                                       int lane, size_t t0, size_t Tlen, double& acc, unsigned& nobs) {
+                                       int lane, size_t t0, size_t Tlen, double& acc, unsigned& nobs,
+                                       T* mseg = nullptr /* out: transition matrix of the whole segment */) {
     using Lay = CB<D>;
     T aa[D * D], akha[D * D], kk[D], ha[D], mj[D * D], z[D];
 #pragma unroll
@@ -257,6 +263,10 @@ __device__ inline void generic_segment(T* ch, T* xin, const T* cb /* this latent
             matvec_acc<T, D>(mj, zp, z);
             matmul<T, D>(mj, mq, mj);
         }
+    }
+    if (mseg) {                                       // lanes past the end hold identity maps
+#pragma unroll
+        for (int i = 0; i < D * D; i++) mseg[i] = __shfl(mj[i], 63);
     }
     T xs[D];
 #pragma unroll
@@ -296,52 +306,30 @@ __device__ inline void generic_segment(T* ch, T* xin, const T* cb /* this latent
 }
 
 // ---------------------------------------------------------------------------------------------
-template <typename T, int D, int CK, bool WRITE, bool NLL, int MINW, int DBG = 0>
-__global__ void __launch_bounds__(64 * kWavesPerBlock, MINW)
-filter_scan_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, const T* __restrict__ cbT,
-                   const double* __restrict__ cb64, T* __restrict__ x, T* __restrict__ yhat, double* __restrict__ nll) {
+// One sweep over `Tlen` ticks of one stream (`row`) by one wavefront, segment by segment.
+//   SLICEMAP = false: the real sweep (filtered means to `orow` if WRITE, sum of v^2 in acc/nobs if NLL)
+//   SLICEMAP = true : no replay and no outputs; xin ends as the state reached from the given start and msl as
+//                     the transition matrix of the whole sweep (x_end = msl * x_start + [x_end from zero]),
+//                     exact also across missing ticks.  Used by the time split below.
+template <typename T, int D, int CK, bool WRITE, bool NLL, bool SLICEMAP, int DBG>
+__device__ inline void sweep(const T* __restrict__ row, T* __restrict__ orow, size_t Tlen, T* xin, const FastConst<T, D, CK>& c,
+                             const T* __restrict__ cb, typename VecOf<T>::type* lds, int lane, double& acc, unsigned& nobs,
+                             size_t& nobs_uniform, T* msl) {
     using V = typename VecOf<T>::type;
-    using Lay = CB<D>;
     constexpr int EPV = 16 / sizeof(T);        // elements per 16-byte vector
     constexpr int VPL = CK / EPV;              // vectors per lane per segment
     constexpr int SEG = 64 * CK;               // ticks per segment
-    constexpr int NVP = 64 * (VPL + 1);        // padded vectors per wave tile (one pad vector per lane row)
-    static_assert(CK % EPV == 0 && CK <= 16, "CK must be a multiple of 16 bytes and fit the G table");
-    __shared__ V lds_all[kWavesPerBlock][NVP];
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const size_t l = (size_t)blockIdx.x * kWavesPerBlock + wave;
-    if (l >= L) return;
-    V* lds = lds_all[wave];
     T* chunk = reinterpret_cast<T*>(&lds[lane * (VPL + 1)]);   // this lane's CK elements inside the tile
-
-    // ---- per-latent constants: wave-uniform scalar loads, plus this lane's cross-row power ----------
-    const T* cb = cbT + l * Lay::SIZE;
-    FastConst<T, D, CK> c;
-#pragma unroll
-    for (int i = 0; i < D * D; i++) c.a[i] = cb[Lay::A + i];
-#pragma unroll
-    for (int i = 0; i < D; i++) c.k[i] = cb[Lay::K + i];
-#pragma unroll
-    for (int i = 0; i < CK * D; i++) c.g[i] = cb[Lay::G + i];
-#pragma unroll
-    for (int i = 0; i < 4 * D * D; i++) c.sp[i] = cb[Lay::SP + i];
-#pragma unroll
-    for (int i = 0; i < D * D; i++) c.pj[i] = cb[Lay::PJ + (lane & 15) * D * D + i];
-
-    const T* row = Ty + l * ld;
-    T* orow = WRITE ? yhat + l * ld : nullptr;
-    T xin[D];
-#pragma unroll
-    for (int i = 0; i < D; i++) xin[i] = x[l * D + i];
-
-    double acc = 0.0;          // per-lane sum of v^2 over observed ticks
-    unsigned nobs = 0;         // per-lane count of observed ticks (tail / generic segments)
-    size_t nobs_uniform = 0;   // observed ticks of full fast-path segments (every lane contributes CK)
-
     const size_t nfull = Tlen / SEG;
     const size_t nseg = (Tlen + SEG - 1) / SEG;
+    T mfull[D * D];                            // SLICEMAP: transition of one full NaN-free segment, AKHA^SEG = M^64
+    if (SLICEMAP) {
+#pragma unroll
+        for (int i = 0; i < D * D; i++) { msl[i] = (i % (D + 1) == 0) ? T(1) : T(0); mfull[i] = c.sp[3 * D * D + i]; }
+        matmul<T, D>(mfull, mfull, mfull);   // M^16
+        matmul<T, D>(mfull, mfull, mfull);   // M^32
+        matmul<T, D>(mfull, mfull, mfull);   // M^64
+    }
 
     V r[VPL];
     auto load_full = [&](size_t seg) {
@@ -390,8 +378,11 @@ filter_scan_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, c
 #pragma unroll
                 for (int k = 0; k < CK; k++) y[k] = y[k] + xin[0];
             } else if (seg < nfull) {
-                done = fast_segment<T, D, CK, NLL, false>(y, xin, c, lane, t0, Tlen, acc, nobs);
+                done = fast_segment<T, D, CK, NLL, false, SLICEMAP>(y, xin, c, lane, t0, Tlen, acc, nobs);
                 if (done) nobs_uniform += SEG;
+                if (done && SLICEMAP) matmul<T, D>(mfull, msl, msl);
+            } else if (SLICEMAP) {
+                done = false;                    // ragged tail: the generic path also yields its map
             } else {
                 done = fast_segment<T, D, CK, NLL, true>(y, xin, c, lane, t0, Tlen, acc, nobs);
             }
@@ -400,7 +391,15 @@ filter_scan_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, c
                 for (int k = 0; k < VPL; k++) lds[lane * (VPL + 1) + k] = pack<T>(&y[k * EPV]);
             }
         }
-        if (!done) generic_segment<T, D, CK, NLL>(chunk, xin, cb, lane, t0, Tlen, acc, nobs);
+        if (!done) {
+            if (SLICEMAP) {
+                T mseg[D * D];
+                generic_segment<T, D, CK, NLL>(chunk, xin, cb, lane, t0, Tlen, acc, nobs, mseg);
+                matmul<T, D>(mseg, msl, msl);
+            } else {
+                generic_segment<T, D, CK, NLL>(chunk, xin, cb, lane, t0, Tlen, acc, nobs);
+            }
+        }
 
         // ---- LDS -> coalesced stores ----------------------------------------------------------
         if (WRITE) {
@@ -422,6 +421,112 @@ filter_scan_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, c
         }
         wave_lds_fence();
     }
+}
+
+constexpr int kMaxSplit = 8;    // slices per latent = waves per workgroup in split mode (512 threads: 256-VGPR budget)
+
+// ---------------------------------------------------------------------------------------------
+// SPLIT = false: 4 waves per workgroup, wave w of block b owns latent 4b + w and sweeps all T ticks.
+// SPLIT = true (few latents): workgroup b owns latent b; its nsplit (<= 16) waves own consecutive time slices
+//   of Tslice ticks (a whole number of segments).  Every wave first computes the affine map of its slice
+//   (SLICEMAP sweep, stream read #1), parks it in LDS, the workgroup synchronises once, every wave folds the
+//   maps of the slices before it into its start state, and then runs the real sweep of its slice (stream
+//   read #2 comes from L2: the slice was touched microseconds ago by the same CU).  One launch, no global
+//   synchronisation, no workspace.
+template <typename T, int D, int CK, bool WRITE, bool NLL, int MINW, bool SPLIT, int DBG = 0>
+__global__ void __launch_bounds__(SPLIT ? 64 * kMaxSplit : 64 * kWavesPerBlock, SPLIT ? 1 : MINW)
+filter_scan_kernel(const T* __restrict__ Ty, size_t Ttot, size_t ld, size_t L, const T* __restrict__ cbT,
+                   const double* __restrict__ cb64, T* __restrict__ x, T* __restrict__ yhat, double* __restrict__ nll,
+                   int nsplit, size_t Tslice) {
+    using V = typename VecOf<T>::type;
+    using Lay = CB<D>;
+    constexpr int EPV = 16 / sizeof(T);
+    constexpr int VPL = CK / EPV;
+    constexpr int NVP = 64 * (VPL + 1);        // padded vectors per wave tile (one pad vector per lane row)
+    static_assert(CK % EPV == 0 && CK <= 16, "CK must be a multiple of 16 bytes and fit the G table");
+    // LDS: one padded tile per wave (dynamic: 4 or nsplit waves), then in split mode the per-slice carry records
+    // [map (D*D), end-from-zero (D), sum v^2, n_obs] as doubles
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    V (*lds_all)[NVP] = reinterpret_cast<V (*)[NVP]>(smem);
+    constexpr int CR = D * D + D + 2;
+    double (*carry)[CR] = reinterpret_cast<double (*)[CR]>(smem + (size_t)(SPLIT ? nsplit : kWavesPerBlock) * NVP * sizeof(V));
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t l = SPLIT ? (size_t)blockIdx.x : (size_t)blockIdx.x * kWavesPerBlock + wave;
+    if (!SPLIT && l >= L) return;
+    const size_t toff = SPLIT ? (size_t)wave * Tslice : 0;
+    const size_t Tlen = SPLIT ? (toff >= Ttot ? 0 : ((Ttot - toff) < Tslice ? (Ttot - toff) : Tslice)) : Ttot;
+    V* lds = lds_all[wave];
+
+    // ---- per-latent constants: wave-uniform scalar loads, plus this lane's cross-row power ----------
+    const T* cb = cbT + l * Lay::SIZE;
+    FastConst<T, D, CK> c;
+#pragma unroll
+    for (int i = 0; i < D * D; i++) c.a[i] = cb[Lay::A + i];
+#pragma unroll
+    for (int i = 0; i < D; i++) c.k[i] = cb[Lay::K + i];
+#pragma unroll
+    for (int i = 0; i < CK * D; i++) c.g[i] = cb[Lay::G + i];
+#pragma unroll
+    for (int i = 0; i < 4 * D * D; i++) c.sp[i] = cb[Lay::SP + i];
+#pragma unroll
+    for (int i = 0; i < D * D; i++) c.pj[i] = cb[Lay::PJ + (lane & 15) * D * D + i];
+
+    const T* row = Ty + l * ld + toff;
+    T* orow = WRITE ? yhat + l * ld + toff : nullptr;
+    T xin[D];
+    double acc = 0.0;          // per-lane sum of v^2 over observed ticks
+    unsigned nobs = 0;         // per-lane count of observed ticks (tail / generic segments)
+    size_t nobs_uniform = 0;   // observed ticks of full fast-path segments (every lane contributes CK)
+
+    if (SPLIT) {
+        // ---- pass 1: affine map of this slice, from a zero start.  Nobody consumes the map of the LAST
+        // slice, so it skips this pass (it is also the only slice that can be ragged: Tslice is a whole
+        // number of segments, hence pass 1 never meets a tail).
+        if (wave < nsplit - 1) {
+            T msl[D * D];
+#pragma unroll
+            for (int i = 0; i < D; i++) xin[i] = T(0);
+            sweep<T, D, CK, false, false, true, 0>(row, nullptr, Tlen, xin, c, cb, lds, lane, acc, nobs, nobs_uniform, msl);
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < D * D; i++) carry[wave][i] = (double)msl[i];
+#pragma unroll
+                for (int i = 0; i < D; i++) carry[wave][D * D + i] = (double)xin[i];
+            }
+        }
+        __syncthreads();
+        // ---- fold the slices before this one into its start state (uniform, <= 7 small mat-vecs) ----
+        double xc[D];
+#pragma unroll
+        for (int i = 0; i < D; i++) xc[i] = (double)x[l * D + i];
+        for (int s = 0; s < wave; s++) {
+            double xn[D];
+#pragma unroll
+            for (int i = 0; i < D; i++) {
+                double a = carry[s][D * D + i];
+#pragma unroll
+                for (int j = 0; j < D; j++) a = fma(carry[s][i * D + j], xc[j], a);
+                xn[i] = a;
+            }
+#pragma unroll
+            for (int i = 0; i < D; i++) xc[i] = xn[i];
+        }
+#pragma unroll
+        for (int i = 0; i < D; i++) xin[i] = (T)xc[i];
+        acc = 0.0; nobs = 0; nobs_uniform = 0;
+        __syncthreads();       // everyone has read x[l] and the maps before anything is overwritten
+    } else {
+#pragma unroll
+        for (int i = 0; i < D; i++) xin[i] = x[l * D + i];
+    }
+
+    // ---- the real sweep (split + state only: just the last slice needs it) -------------------------
+    if (WRITE || NLL || !SPLIT || wave == nsplit - 1) {
+        T unused[D * D];
+        sweep<T, D, CK, WRITE, NLL, false, DBG>(row, orow, Tlen, xin, c, cb, lds, lane, acc, nobs, nobs_uniform, unused);
+    }
 
     // ---- epilogue: carried-out state and the latent's NLL ---------------------------------------
     if (NLL) {
@@ -431,11 +536,25 @@ filter_scan_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, c
             nobs += __shfl_xor(nobs, o);
         }
     }
-    if (lane == 0) {
+    const double* c64 = cb64 + l * Lay::SIZE;
+    if (SPLIT) {
+        if (NLL) {
+            if (lane == 0) { carry[wave][D * D + D] = acc; carry[wave][D * D + D + 1] = (double)nobs_uniform + (double)nobs; }
+            __syncthreads();
+        }
+        if (lane == 0 && wave == nsplit - 1) {
+#pragma unroll
+            for (int i = 0; i < D; i++) x[l * D + i] = xin[i];
+        }
+        if (NLL && lane == 0 && wave == 0) {
+            double a = 0.0, n = 0.0;
+            for (int s = 0; s < nsplit; s++) { a += carry[s][D * D + D]; n += carry[s][D * D + D + 1]; }
+            nll[l] = 0.5 * (a / c64[Lay::S] + n * c64[Lay::LOGS]);
+        }
+    } else if (lane == 0) {
 #pragma unroll
         for (int i = 0; i < D; i++) x[l * D + i] = xin[i];
         if (NLL) {
-            const double* c64 = cb64 + l * Lay::SIZE;
             double n = (double)nobs_uniform + (double)nobs;
             nll[l] = 0.5 * (acc / c64[Lay::S] + n * c64[Lay::LOGS]);   // sum of ihgp.h:207 terms
         }
@@ -516,22 +635,25 @@ grad_seq_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
     for (int p = 0; p < P; p++) grad[l * P + p] = g[p];
 }
 
-template <typename T, int D, int CK, int MINW>
+template <typename T, int D, int CK, int MINW, bool SPLIT>
 int launch_filter_t(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, const double* cb64, void* x,
-                    void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
-    dim3 block(64 * kWavesPerBlock), grid((unsigned)((L + kWavesPerBlock - 1) / kWavesPerBlock));
+                    void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, int nsplit, size_t Tslice) {
+    dim3 block(SPLIT ? 64 * nsplit : 64 * kWavesPerBlock);
+    dim3 grid(SPLIT ? (unsigned)L : (unsigned)((L + kWavesPerBlock - 1) / kWavesPerBlock));
+    constexpr size_t tile = 64 * (CK / (16 / sizeof(T)) + 1) * 16;                    // padded LDS tile per wave
+    const size_t smem = SPLIT ? (size_t)nsplit * (tile + (D * D + D + 2) * sizeof(double)) : (size_t)kWavesPerBlock * tile;
     const T* ty = static_cast<const T*>(Ty);
     T* xs = static_cast<T*>(x);
     T* yh = static_cast<T*>(yhat);
     // hipExtLaunchKernelGGL attaches the (optional) events to the dispatch itself: kernel-exact timing
     if (yhat && nll)
-        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, true, true, MINW>), grid, block, 0, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xs, yh, nll);
+        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, true, true, MINW, SPLIT>), grid, block, smem, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xs, yh, nll, nsplit, Tslice);
     else if (yhat)
-        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, true, false, MINW>), grid, block, 0, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xs, yh, nll);
+        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, true, false, MINW, SPLIT>), grid, block, smem, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xs, yh, nll, nsplit, Tslice);
     else if (nll)
-        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, false, true, MINW>), grid, block, 0, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xs, yh, nll);
+        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, false, true, MINW, SPLIT>), grid, block, smem, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xs, yh, nll, nsplit, Tslice);
     else
-        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, false, false, MINW>), grid, block, 0, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xs, yh, nll);
+        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, false, false, MINW, SPLIT>), grid, block, smem, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xs, yh, nll, nsplit, Tslice);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_last_error("filter_scan_kernel launch: %s", hipGetErrorString(e)); return 2; }
     return 0;
@@ -539,31 +661,47 @@ int launch_filter_t(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* c
 
 }  // namespace
 
+// Slices per latent for the time split: enough wavefronts to occupy the chip when L is small, each slice a whole
+// number of segments so that only a latent's last slice is ragged; at most kMaxSplit slices (one workgroup).
+void filter_split_plan(int dtype, size_t T, size_t L, int* nsplit, size_t* Tslice) {
+    const size_t seg = 64 * (size_t)(dtype == 0 ? kChunk64 : kChunk32);
+    *nsplit = 1; *Tslice = T;
+    if (L == 0 || L >= 1024 || T < 2 * seg) return;        // measured: pays below ~1024 latents (1 wave/SIMD)
+    size_t want = (2048 + L - 1) / L;                      // aim for >= 2048 wavefronts
+    if (want > (size_t)kMaxSplit) want = kMaxSplit;
+    size_t segs = (T + seg - 1) / seg;
+    size_t per = (segs + want - 1) / want;                   // segments per slice
+    size_t n = (segs + per - 1) / per;
+    if (n < 2) return;
+    *nsplit = (int)n; *Tslice = per * seg;
+}
+
 int launch_filter_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* cb64,
                          const float* cb32, void* x, void* yhat, double* nll, hipStream_t stream, int variant,
-                         hipEvent_t ev0, hipEvent_t ev1) {
+                         hipEvent_t ev0, hipEvent_t ev1, int nsplit, size_t Tslice) {
     if (L == 0) return 0;
-#define MOIHGP_FILTER_CASE(TT, DD, CKK, MW, CB) return launch_filter_t<TT, DD, CKK, MW>(Ty, T, ld, L, CB, cb64, x, yhat, nll, stream, ev0, ev1)
+    if (nsplit > kMaxSplit) { set_last_error("nsplit > %d", kMaxSplit); return 1; }
+#define MOIHGP_FILTER_CASE(TT, DD, CKK, MW, CB)                                                                                   \
+    do {                                                                                                                          \
+        if (nsplit > 1) return launch_filter_t<TT, DD, CKK, 1, true>(Ty, T, ld, L, CB, cb64, x, yhat, nll, stream, ev0, ev1, nsplit, Tslice); \
+        return launch_filter_t<TT, DD, CKK, MW, false>(Ty, T, ld, L, CB, cb64, x, yhat, nll, stream, ev0, ev1, 1, T);             \
+    } while (0)
+    // register caps: fp32 <= 128 VGPRs (4 waves/SIMD: all 4096 wavefronts of a 4096-latent shard resident),
+    // fp64 uncapped (188 VGPRs, 2 waves/SIMD: capping it to 168 spills and is 35 % slower)
     if (dtype == 0) {
-        if (d == 2) { MOIHGP_FILTER_CASE(double, 2, kChunk64, 1, cb64); }
-        switch (variant) {
-            case 1: MOIHGP_FILTER_CASE(double, 3, kChunk64, 3, cb64);
-            case 2: MOIHGP_FILTER_CASE(double, 3, kChunk64, 4, cb64);
-            default: MOIHGP_FILTER_CASE(double, 3, kChunk64, 1, cb64);
-        }
+        if (d == 2) MOIHGP_FILTER_CASE(double, 2, kChunk64, 1, cb64);
+        if (variant == 1) MOIHGP_FILTER_CASE(double, 3, kChunk64, 3, cb64);
+        MOIHGP_FILTER_CASE(double, 3, kChunk64, 1, cb64);
     }
-    if (d == 2) { MOIHGP_FILTER_CASE(float, 2, kChunk32, 1, cb32); }
-    switch (variant) {
-        case 1: MOIHGP_FILTER_CASE(float, 3, kChunk32, 3, cb32);
-        case 2: MOIHGP_FILTER_CASE(float, 3, kChunk32, 4, cb32);
-        case 9: {   // tuning probe (staging only)
-            dim3 block(64 * kWavesPerBlock), grid((unsigned)((L + kWavesPerBlock - 1) / kWavesPerBlock));
-            hipExtLaunchKernelGGL((filter_scan_kernel<float, 3, kChunk32, true, true, 1, 1>), grid, block, 0, stream, ev0, ev1, 0,
-                                  (const float*)Ty, T, ld, L, cb32, cb64, (float*)x, (float*)yhat, nll);
-            return 0;
-        }
-        default: MOIHGP_FILTER_CASE(float, 3, kChunk32, 1, cb32);
+    if (d == 2) MOIHGP_FILTER_CASE(float, 2, kChunk32, 4, cb32);
+    if (variant == 9) {   // tuning probe (staging only)
+        dim3 block(64 * kWavesPerBlock), grid((unsigned)((L + kWavesPerBlock - 1) / kWavesPerBlock));
+        hipExtLaunchKernelGGL((filter_scan_kernel<float, 3, kChunk32, true, true, 1, false, 1>), grid, block, (size_t)kWavesPerBlock * 64 * 5 * 16, stream, ev0, ev1, 0,
+                              (const float*)Ty, T, ld, L, cb32, cb64, (float*)x, (float*)yhat, nll, 1, T);
+        return 0;
     }
+    if (variant == 1) MOIHGP_FILTER_CASE(float, 3, kChunk32, 1, cb32);
+    MOIHGP_FILTER_CASE(float, 3, kChunk32, 4, cb32);
 #undef MOIHGP_FILTER_CASE
 }
 

@@ -314,3 +314,35 @@ def test_project_unproject_stream(env, dtype, M, L, T):
     for t in range(nt):
         x, yh = gp.step(x, Y[t])
         assert rel_err(yh, Yhat_f[t].cpu().numpy()) < (1e-10 if dtype == torch.float64 else 1e-4)
+
+
+# ------------------------------------------------------------------------------------------ time split (small L)
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("L,T,nan", [(3, 5000, 0.0), (16, 10000, 0.0), (7, 4097, 0.03), (256, 10000, 0.0), (5, 2047, 0.0)])
+def test_time_split_matches_unsplit(env, dtype, L, T, nan, monkeypatch):
+    """With few latents the filter splits each stream into slices handled by different wavefronts (slice
+    affine maps + carry).  Results must equal the unsplit sweep to rounding, and the oracle."""
+    rng = np.random.default_rng(L * 7 + T)
+    prm = synth_params(L, rng)
+    bank = env["streams"].LatentBank(0.1, prm, kernel="Matern52ss")
+    Ty = synth(L, T, rng, nan)
+    x0 = 0.3 * rng.standard_normal((L, 3))
+    o = env["cref"].filter_stream(env["cref"].ihgp_array("Matern52", 0.1, prm), Ty, x0=x0)
+    Tyd = to_dev(Ty, dtype)
+    res = {}
+    for split in ("1", "0", "5"):                  # off, automatic, forced 5 slices
+        if split == "0":
+            monkeypatch.delenv("MOIHGP_FILTER_SPLIT", raising=False)
+        else:
+            monkeypatch.setenv("MOIHGP_FILTER_SPLIT", split)
+        yhat, xT, nll = bank.filter(Tyd, T=T, x=torch.from_numpy(x0).to(dtype).cuda())
+        _, xT2, _ = bank.filter(Tyd, T=T, x=torch.from_numpy(x0).to(dtype).cuda(), want_yhat=False, want_nll=False)
+        torch.cuda.synchronize()
+        res[split] = (yhat[:, :T].cpu().numpy(), xT.cpu().numpy(), nll.cpu().numpy())
+        tol = FP64_TIGHT if dtype == torch.float64 else FP32_TOL
+        assert rel_err(res[split][0], o["yhat"]) < tol and rel_err(res[split][1], o["x"]) < tol
+        assert rel_err(res[split][2], o["nll_per_latent"]) < tol
+        assert rel_err(xT2.cpu().numpy(), o["x"]) < tol
+    tight = 1e-11 if dtype == torch.float64 else 2e-4
+    for split in ("0", "5"):
+        assert rel_err(res[split][0], res["1"][0]) < tight and rel_err(res[split][2], res["1"][2]) < tight
