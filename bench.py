@@ -122,11 +122,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     assert torch.cuda.is_available(), "bench.py needs a GPU; there is no CPU fallback"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # Rehearsal on a 1-GPU box: BENCH_REHEARSAL=1 lets all ranks share device 0 and moves the 8-byte exchange to
+    # gloo (RCCL refuses two ranks on one device).  Never used for reported numbers.
+    rehearsal = os.environ.get("BENCH_REHEARSAL", "0") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from multioutputihgp_amd.sharded import allreduce_nll, shard_bounds
     from multioutputihgp_amd.streams import LatentBank
@@ -167,7 +174,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else device)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = tmax.item()
@@ -198,6 +205,8 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "frac_of_measured_copy_peak": achieved / HBM_COPY_GBPS},
             "nll_total": float(total.item()),
         }
+        if rehearsal:
+            out["rehearsal"] = "all ranks on one GPU, gloo exchange: numbers are not comparable"
         if world == 1 and not args.no_cpu:
             sub = np.arange(0, L, max(1, L // 64))[:64]
             cb, nll_rel, mean_rel = cpu_baseline(prm, Ty[:, :T].cpu().numpy(), T, float(total.item()), yhat[sub][:, :T].double().cpu().numpy(), sub)

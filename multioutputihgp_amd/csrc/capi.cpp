@@ -116,6 +116,7 @@ struct moihgp_gp {
     double *dx = nullptr, *dy = nullptr, *ddx = nullptr, *dxnew = nullptr, *dyhat = nullptr, *ddxnew = nullptr;
     double *dTy = nullptr, *dUty = nullptr, *dTyhat = nullptr, *dloss = nullptr, *dgrad = nullptr, *dscratch = nullptr;
     double* dwork = nullptr;   // L*L + L, lazily (missing-output projection)
+    double* dpolar = nullptr;  // M*L + 2*L*L + 8, lazily (device polar factor)
     // optional kernel-exact timing of filter launches (moihgp_profile_enable)
     std::vector<hipEvent_t> prof_ev;
     int prof_n = 0;
@@ -126,7 +127,7 @@ struct moihgp_gp {
 static void gp_free(moihgp_gp* g) {
     if (!g) return;
     void* ptrs[] = {g->dU, g->dS, g->dsigma, g->dparams, g->cb64, g->cb32, g->dx, g->dy, g->ddx, g->dxnew, g->dyhat,
-                    g->ddxnew, g->dTy, g->dUty, g->dTyhat, g->dloss, g->dgrad, g->dscratch, g->dwork};
+                    g->ddxnew, g->dTy, g->dUty, g->dTyhat, g->dloss, g->dgrad, g->dscratch, g->dwork, g->dpolar};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : g->prof_ev) (void)hipEventDestroy(e);
@@ -147,6 +148,7 @@ static void run_ihgp_update(moihgp_gp* g) {
     MOIHGP_HIP_FATAL(hipStreamSynchronize(g->stream));
 }
 
+static bool compute_polar_fwd(moihgp_gp* g, const double* Uparam);
 static void draw_U(moihgp_gp* g, unsigned long long seed, bool use_seed) {
     // moihgp.h:103-125: U = polar(I + N(0, 1e-3))
     std::mt19937 gen;
@@ -156,7 +158,7 @@ static void draw_U(moihgp_gp* g, unsigned long long seed, bool use_seed) {
     std::vector<double> I(g->M * g->L, 0.0);
     for (size_t r = 0; r < g->M; r++)
         for (size_t c = 0; c < g->L; c++) I[r * g->L + c] = (r == c ? 1.0 : 0.0) + distr(gen);
-    polar_factor(g->M, g->L, I.data(), g->U.data());
+    if (g->dU) compute_polar_fwd(g, I.data()); else polar_factor(g->M, g->L, I.data(), g->U.data());
 }
 
 static moihgp_gp* gp_create(int kernel, double dt, size_t M, size_t L, bool latents_only, const double* params_LP) {
@@ -194,8 +196,8 @@ static moihgp_gp* gp_create(int kernel, double dt, size_t M, size_t L, bool late
         g->U.assign(M * L, 0.0);
         g->S.assign(L, 1.0);                                             // moihgp.h:126
         g->sigma = 1e-2;                                                 // moihgp.h:127
-        draw_U(g, 0, false);
         g->dU = dev_alloc<double>(M * L);
+        draw_U(g, 0, false);
         g->dS = dev_alloc<double>(L);
         g->dsigma = dev_alloc<double>(1);
         g->dx = dev_alloc<double>(L * g->d);
@@ -265,9 +267,27 @@ static double do_lik(moihgp_gp* g, const double* x, const double* y, const doubl
     return loss;
 }
 
+// U = polar(Uparam) (moihgp.h:433-447).  Large matrices: Newton-Schulz on the device (polar.hip); small ones: the
+// host Jacobi routine above, whose microseconds beat a dozen kernel launches.  MOIHGP_POLAR=device|host forces one.
+static bool compute_polar(moihgp_gp* g, const double* Uparam);
+static bool compute_polar_fwd(moihgp_gp* g, const double* Uparam) { return compute_polar(g, Uparam); }
+static bool compute_polar(moihgp_gp* g, const double* Uparam) {
+    const size_t M = g->M, L = g->L;
+    bool on_device = (double)M * (double)L * (double)L > 2.0e7;
+    if (const char* e = std::getenv("MOIHGP_POLAR")) on_device = (e[0] == 'd');
+    if (!on_device) return polar_factor(M, L, Uparam, g->U.data());
+    if (!g->dpolar) g->dpolar = dev_alloc<double>(M * L + 2 * L * L + 8);
+    MOIHGP_HIP_FATAL(hipMemcpyAsync(g->dU, Uparam, sizeof(double) * M * L, hipMemcpyHostToDevice, g->stream));
+    const int its = polar_factor_device(g->dU, M, L, g->dpolar, g->stream);
+    if (its < 0) return false;
+    MOIHGP_HIP_FATAL(hipMemcpyAsync(g->U.data(), g->dU, sizeof(double) * M * L, hipMemcpyDeviceToHost, g->stream));
+    MOIHGP_HIP_FATAL(hipStreamSynchronize(g->stream));
+    return true;
+}
+
 static void do_update(moihgp_gp* g, const double* params) {          // moihgp.h:431-457
     const size_t M = g->M, L = g->L, sizeU = M * L;
-    if (!polar_factor(M, L, params, g->U.data())) {
+    if (!compute_polar(g, params)) {
         set_last_error("update: mixing matrix is rank deficient");
         std::fprintf(stderr, "libmoihgp: %s\n", g_last_error);
         for (auto& u : g->U) u = std::nan("");

@@ -88,10 +88,17 @@ void launch_unproject_tick(const TickArgs& a, const double* Tyhat, double* yhat,
 void launch_nll_tick(const TickArgs& a, const double* x, const double* y, const double* Ty, const double* Uty,
                      const double* dx, double* loss, double* grad, double* scratch, hipStream_t s);
 
-// oilmm.hip: whole-stream projection GEMMs.
+// gemm_mfma.hip: MFMA GEMMs (whole-stream projection, Gram / update products of the polar factor).
 int launch_project_stream(int dtype, const void* Y, size_t T, size_t M, size_t L, const double* U, const double* S,
                           void* Ty, size_t ld, hipStream_t s);
 int launch_unproject_stream(int dtype, const void* Tyhat, size_t T, size_t ld, size_t M, size_t L, const double* U,
                             const double* S, void* Yhat, hipStream_t s);
+int launch_gram(const double* X, size_t M, size_t L, double* G, hipStream_t s);                       // G = X^T X
+int launch_matmul_nn(const double* X, size_t M, size_t L, const double* W, double* C, hipStream_t s);   // C = X W
+
+// polar.hip: polar factor of an M x L matrix on the device (Newton-Schulz), moihgp.h:433-447.
+// A_dev is overwritten with the factor; work needs M*L + 2*L*L + 8 doubles.  Returns the iteration count, or
+// -1 if it did not converge (rank-deficient input).
+int polar_factor_device(double* A_dev, size_t M, size_t L, double* work, hipStream_t s);
 
 }  // namespace moihgp

@@ -1,0 +1,217 @@
+// gemm_mfma.hip -- LDS-staged MFMA GEMM for the dense products around the recursion:
+//   * OILMM projection / un-projection of whole streams (reference moihgp.h:181, :222-225, per tick there)
+//   * the Gram / update products of the Newton-Schulz polar factor in MOIHGP::update (moihgp.h:433-447)
+//
+//   C(i,j) = rs(i) * sum_k A(i,k) * ks(k) * B(k,j)                i < Mi, j < Nj, k < Kk
+//
+// Operand layouts are given by which index is contiguous in memory:
+//   A_ICONTIG: A(i,k) = A[k*lda + i]   else  A(i,k) = A[i*lda + k]
+//   B_KCONTIG: B(k,j) = B[j*ldb + k]   else  B(k,j) = B[k*ldb + j]
+//   C(i,j) = C[i*ldc + j]
+// so every product needed here runs without a transpose pass.
+//
+// Tile: 128 x 128 x 16 per 256-thread workgroup; 4 waves as 2 x 2, each wave 64 x 64 = 4 x 4 MFMA tiles of
+// 16 x 16 (v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32: one element of A and of B per lane per
+// instruction).  Both operands are staged k-major in LDS (As[k][i], Bs[k][j], row stride 128 + 16 elements so that
+// the two 16-lane halves of a ds_read hit disjoint bank halves), the next tile is fetched into registers while
+// the current one is multiplied.  Workgroup ids are remapped so that the 8 tiles sharing an XCD's L2 are
+// neighbours in the output.
+//
+// Roofline: MFMA (fp64 and fp32-input MFMA both run at 64 FLOP/clk/SIMD on gfx950).
+#include "common.h"
+
+namespace moihgp {
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16, LDT = BM + 16;
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Acc;
+template <> struct Acc<double> {
+    using type = double4_t;
+    static __device__ inline type mfma(double a, double b, type c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    // C/D map of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+    static __device__ inline int row(int lane, int r) { return (lane >> 4) + 4 * r; }
+};
+template <> struct Acc<float> {
+    using type = float4_t;
+    static __device__ inline type mfma(float a, float b, type c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    // C/D map of v_mfma_f32_16x16x4_f32: col = lane & 15, row = (lane >> 4) * 4 + reg
+    static __device__ inline int row(int lane, int r) { return (lane >> 4) * 4 + r; }
+};
+
+template <typename TC, typename TA, typename TB, bool A_ICONTIG, bool B_KCONTIG>
+__global__ void __launch_bounds__(256)
+gemm_mfma_kernel(size_t Mi, size_t Nj, size_t Kk, const TA* __restrict__ A, size_t lda, const TB* __restrict__ B, size_t ldb,
+                 TC* __restrict__ C, size_t ldc, const double* __restrict__ rs, int rs_mode, const double* __restrict__ ks, int ks_mode,
+                 unsigned tiles_m, unsigned tiles_n) {
+    __shared__ TC As[BK][LDT];
+    __shared__ TC Bs[BK][LDT];
+    // ---- XCD-aware tile order: workgroups b, b+8, b+16.. share an XCD; give each XCD a contiguous run of tiles ----
+    const unsigned nwg = tiles_m * tiles_n;
+    unsigned bid = blockIdx.x;
+    {
+        const unsigned q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    // column-panel order with groups of 8 row tiles (keeps a B panel and 8 A panels hot in L2)
+    constexpr unsigned GROUP = 8;
+    const unsigned per_group = GROUP * tiles_n;
+    const unsigned g = bid / per_group, first_m = g * GROUP;
+    const unsigned gsz = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+    const unsigned tm = first_m + (bid % per_group) % gsz, tn = (bid % per_group) / gsz;
+    const size_t i0 = (size_t)tm * BM, j0 = (size_t)tn * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    typename Acc<TC>::type acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[a][b][r] = 0;
+
+    // register staging of one 128 x 16 tile of each operand: 8 elements per thread each
+    TC ra[8], rb[8];
+    auto fetch = [&](size_t k0) {
+        if (A_ICONTIG) {      // rows of As are contiguous in memory: thread -> (k = tid / 16 .. , 8 consecutive i)
+            const int kk = tid >> 4, ii = (tid & 15) * 8;
+            const size_t gk = k0 + kk;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const size_t gi = i0 + ii + e;
+                ra[e] = (gk < Kk && gi < Mi) ? (TC)A[gk * lda + gi] : TC(0);
+            }
+        } else {              // A(i,k) = A[i*lda + k]: thread -> (i = tid / 2, 8 consecutive k)
+            const int ii = tid >> 1, kk = (tid & 1) * 8;
+            const size_t gi = i0 + ii;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const size_t gk = k0 + kk + e;
+                ra[e] = (gk < Kk && gi < Mi) ? (TC)A[gi * lda + gk] : TC(0);
+            }
+        }
+        if (B_KCONTIG) {      // B(k,j) = B[j*ldb + k]: thread -> (j = tid / 2, 8 consecutive k)
+            const int jj = tid >> 1, kk = (tid & 1) * 8;
+            const size_t gj = j0 + jj;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const size_t gk = k0 + kk + e;
+                TC v = (gk < Kk && gj < Nj) ? (TC)B[gj * ldb + gk] : TC(0);
+                if (ks_mode == 1 && gk < Kk) v *= (TC)sqrt(ks[gk]);
+                rb[e] = v;
+            }
+        } else {              // B(k,j) = B[k*ldb + j]: thread -> (k = tid / 16, 8 consecutive j)
+            const int kk = tid >> 4, jj = (tid & 15) * 8;
+            const size_t gk = k0 + kk;
+            TC sc = TC(1);
+            if (ks_mode == 1 && gk < Kk) sc = (TC)sqrt(ks[gk]);
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const size_t gj = j0 + jj + e;
+                rb[e] = (gk < Kk && gj < Nj) ? (TC)B[gk * ldb + gj] * sc : TC(0);
+            }
+        }
+    };
+    auto stash = [&]() {
+        if (A_ICONTIG) {
+            const int kk = tid >> 4, ii = (tid & 15) * 8;
+#pragma unroll
+            for (int e = 0; e < 8; e++) As[kk][ii + e] = ra[e];
+        } else {
+            const int ii = tid >> 1, kk = (tid & 1) * 8;
+#pragma unroll
+            for (int e = 0; e < 8; e++) As[kk + e][ii] = ra[e];
+        }
+        if (B_KCONTIG) {
+            const int jj = tid >> 1, kk = (tid & 1) * 8;
+#pragma unroll
+            for (int e = 0; e < 8; e++) Bs[kk + e][jj] = rb[e];
+        } else {
+            const int kk = tid >> 4, jj = (tid & 15) * 8;
+#pragma unroll
+            for (int e = 0; e < 8; e++) Bs[kk][jj + e] = rb[e];
+        }
+    };
+
+    fetch(0);
+    for (size_t k0 = 0; k0 < Kk; k0 += BK) {
+        __syncthreads();                 // previous tile fully consumed
+        stash();
+        __syncthreads();
+        if (k0 + BK < Kk) fetch(k0 + BK);   // in flight during the MFMAs below
+#pragma unroll
+        for (int s = 0; s < BK / 4; s++) {
+            TC af[4], bf[4];
+            const int kr = s * 4 + (lane >> 4), c = lane & 15;
+#pragma unroll
+            for (int a = 0; a < 4; a++) af[a] = As[kr][wm * 64 + a * 16 + c];
+#pragma unroll
+            for (int b = 0; b < 4; b++) bf[b] = Bs[kr][wn * 64 + b * 16 + c];
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) acc[a][b] = Acc<TC>::mfma(af[a], bf[b], acc[a][b]);
+        }
+    }
+
+    // ---- epilogue ----------------------------------------------------------------------------------------
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const size_t gi = i0 + wm * 64 + a * 16 + Acc<TC>::row(lane, r);
+            if (gi >= Mi) continue;
+            TC scale = TC(1);
+            if (rs_mode == 1) scale = (TC)(1.0 / sqrt(rs[gi]));
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const size_t gj = j0 + wn * 64 + b * 16 + (lane & 15);
+                if (gj < Nj) C[gi * ldc + gj] = scale * acc[a][b][r];
+            }
+        }
+}
+
+template <typename TC, typename TA, typename TB, bool AI, bool BK_>
+int launch(size_t Mi, size_t Nj, size_t Kk, const TA* A, size_t lda, const TB* B, size_t ldb, TC* C, size_t ldc, const double* rs,
+           int rs_mode, const double* ks, int ks_mode, hipStream_t s) {
+    const unsigned tm = (unsigned)((Mi + BM - 1) / BM), tn = (unsigned)((Nj + BN - 1) / BN);
+    if (tm == 0 || tn == 0) return 0;
+    hipLaunchKernelGGL((gemm_mfma_kernel<TC, TA, TB, AI, BK_>), dim3(tm * tn), dim3(256), 0, s, Mi, Nj, Kk, A, lda, B, ldb, C, ldc, rs,
+                       rs_mode, ks, ks_mode, tm, tn);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_last_error("gemm_mfma launch: %s", hipGetErrorString(e)); return 2; }
+    return 0;
+}
+
+}  // namespace
+
+// Ty[l][t] = S_l^-1/2 * sum_m U[m][l] Y[t][m]:  i = l, j = t, k = m;  A = U (i-contiguous, lda = L);  B = Y (k-contiguous, ldb = M)
+int launch_project_stream(int dtype, const void* Y, size_t T, size_t M, size_t L, const double* U, const double* S, void* Ty, size_t ld,
+                          hipStream_t s) {
+    if (dtype == 0) return launch<double, double, double, true, true>(L, T, M, U, L, (const double*)Y, M, (double*)Ty, ld, S, 1, nullptr, 0, s);
+    return launch<float, double, float, true, true>(L, T, M, U, L, (const float*)Y, M, (float*)Ty, ld, S, 1, nullptr, 0, s);
+}
+
+// Yhat[t][m] = sum_l Tyhat[l][t] * sqrt(S_l) * U[m][l]:  i = t, j = m, k = l;  A = Tyhat (i-contiguous, lda = ld);  B = U (k-contiguous, ldb = L)
+int launch_unproject_stream(int dtype, const void* Tyhat, size_t T, size_t ld, size_t M, size_t L, const double* U, const double* S,
+                            void* Yhat, hipStream_t s) {
+    if (dtype == 0) return launch<double, double, double, true, true>(T, M, L, (const double*)Tyhat, ld, U, L, (double*)Yhat, M, nullptr, 0, S, 1, s);
+    return launch<float, float, double, true, true>(T, M, L, (const float*)Tyhat, ld, U, L, (float*)Yhat, M, nullptr, 0, S, 1, s);
+}
+
+// G[a][b] = sum_m X[m][a] X[m][b]  (X is M x L row-major):  A i-contiguous (lda = L), B j-contiguous (ldb = L)
+int launch_gram(const double* X, size_t M, size_t L, double* G, hipStream_t s) {
+    return launch<double, double, double, true, false>(L, L, M, X, L, X, L, G, L, nullptr, 0, nullptr, 0, s);
+}
+
+// C[m][b] = sum_a X[m][a] W[a][b]  (X M x L, W L x L, row-major):  A k-contiguous (lda = L), B j-contiguous (ldb = L)
+int launch_matmul_nn(const double* X, size_t M, size_t L, const double* W, double* C, hipStream_t s) {
+    return launch<double, double, double, false, false>(M, L, L, X, L, W, L, C, L, nullptr, 0, nullptr, 0, s);
+}
+
+}  // namespace moihgp

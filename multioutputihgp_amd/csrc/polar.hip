@@ -1,0 +1,92 @@
+// polar.hip -- polar factor  svdU * svdV^T  of the mixing matrix on the device (reference moihgp.h:433-447,
+// where Eigen's BDCSVD/JacobiSVD is used only to form that product).  The factor is unique for full column
+// rank, so any convergent method reproduces it to rounding; here Newton-Schulz:
+//     X_0 = A / s  (s >= sigma_max),   X_{k+1} = X_k (3/2 I - 1/2 X_k^T X_k)
+// two MFMA GEMMs per step (gemm_mfma.hip), quadratic convergence once ||X^T X - I|| < 1; for the near-orthonormal
+// matrices L-BFGS hands to update() that is 4-6 steps.  s^2 = min(||G||_inf, trace G) with G = A^T A is a
+// rigorous upper bound of sigma_max^2.
+#include "common.h"
+
+namespace moihgp {
+namespace {
+
+// out[0] = max_i sum_j |G_ij| ; out[1] = trace(G) ; out[2] = max_ij |G_ij - delta_ij|     (one workgroup)
+__global__ void __launch_bounds__(256) gram_stats_kernel(const double* __restrict__ G, size_t L, double* __restrict__ out) {
+    __shared__ double r0[256], r1[256], r2[256];
+    const int tid = threadIdx.x;
+    double mx = 0.0, tr = 0.0, dev = 0.0;
+    for (size_t i = tid; i < L; i += 256) {
+        double s = 0.0;
+        for (size_t j = 0; j < L; j++) {
+            const double g = G[i * L + j];
+            s += fabs(g);
+            const double d = fabs(g - (i == j ? 1.0 : 0.0));
+            if (d > dev) dev = d;
+        }
+        if (s > mx) mx = s;
+        tr += G[i * L + i];
+    }
+    r0[tid] = mx; r1[tid] = tr; r2[tid] = dev;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { r0[tid] = fmax(r0[tid], r0[tid + o]); r1[tid] += r1[tid + o]; r2[tid] = fmax(r2[tid], r2[tid + o]); }
+        __syncthreads();
+    }
+    if (tid == 0) { out[0] = r0[0]; out[1] = r1[0]; out[2] = r2[0]; }
+}
+
+__global__ void scale_kernel(double* __restrict__ X, size_t n, const double* __restrict__ stats) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double s2 = fmin(stats[0], stats[1]);
+    X[i] *= 1.0 / sqrt(s2);
+}
+
+// W = 3/2 I - 1/2 G
+__global__ void ns_weight_kernel(const double* __restrict__ G, double* __restrict__ W, size_t L) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= L * L) return;
+    const size_t i = idx / L, j = idx % L;
+    W[idx] = (i == j ? 1.5 : 0.0) - 0.5 * G[idx];
+}
+
+}  // namespace
+
+int polar_factor_device(double* X, size_t M, size_t L, double* work, hipStream_t s) {
+    double* G = work;                 // L*L
+    double* W = G + L * L;            // L*L
+    double* Xn = W + L * L;           // M*L
+    double* stats = Xn + M * L;       // 8
+    double h[3];
+    const unsigned nbLL = (unsigned)((L * L + 255) / 256), nbML = (unsigned)((M * L + 255) / 256);
+    if (launch_gram(X, M, L, G, s)) return -1;
+    hipLaunchKernelGGL(gram_stats_kernel, dim3(1), dim3(256), 0, s, G, L, stats);
+    hipLaunchKernelGGL(scale_kernel, dim3(nbML), dim3(256), 0, s, X, M * L, stats);
+    MOIHGP_HIP_FATAL(hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, s));
+    MOIHGP_HIP_FATAL(hipStreamSynchronize(s));
+    if (!(fmin(h[0], h[1]) > 0.0) || h[0] != h[0]) return -1;
+    double prev = 1e300;
+    double* cur = X;
+    double* nxt = Xn;
+    for (int it = 1; it <= 200; it++) {
+        if (launch_gram(cur, M, L, G, s)) return -1;
+        hipLaunchKernelGGL(gram_stats_kernel, dim3(1), dim3(256), 0, s, G, L, stats);
+        MOIHGP_HIP_FATAL(hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, s));
+        MOIHGP_HIP_FATAL(hipStreamSynchronize(s));
+        const double err = h[2];
+        if (err != err) return -1;
+        // converged: orthonormal to rounding (the error floor of an fp64 Gram matrix is ~ K eps), or no longer improving
+        if (err < 1e-14 || (err < 1e-11 && err >= 0.5 * prev)) {
+            if (cur != X) MOIHGP_HIP_FATAL(hipMemcpyAsync(X, cur, sizeof(double) * M * L, hipMemcpyDeviceToDevice, s));
+            return it - 1;
+        }
+        if (it > 60 && err >= prev) break;       // stagnating far from orthonormal: rank deficient
+        prev = err;
+        hipLaunchKernelGGL(ns_weight_kernel, dim3(nbLL), dim3(256), 0, s, G, W, L);
+        if (launch_matmul_nn(cur, M, L, W, nxt, s)) return -1;
+        double* t = cur; cur = nxt; nxt = t;
+    }
+    return -1;
+}
+
+}  // namespace moihgp

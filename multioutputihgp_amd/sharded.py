@@ -25,6 +25,10 @@ def allreduce_nll(nll_local: torch.Tensor, group=None) -> torch.Tensor:
     """Sum of the per-latent NLLs over all shards: one fp64 scalar all-reduce (SUM)."""
     total = nll_local.sum(dtype=torch.float64).reshape(1)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if total.is_cuda and dist.get_backend(group) == "gloo":      # CPU rehearsal of the exchange
+            t = total.cpu()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            return t.to(total.device)
         dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
     return total
 

@@ -59,3 +59,15 @@ def test_fails_loudly_without_gpu(hip_built):
     from multioutputihgp_amd.streams import LatentBank
     with pytest.raises(MoihgpError):
         LatentBank(0.1, [[1.0, 1.0, 0.1]])
+
+
+def test_reference_pywrapper_binds_only_symbols_we_export(hip_built):
+    """In this container the reference checkout is readable: every `gpXX_*` attribute its ctypes class resolves
+    (moihgp/pywrapper.py:28-83) must be exported by our library.  Skipped where /root/reference is absent."""
+    ref = "/root/reference/moihgp/pywrapper.py"
+    if not os.path.exists(ref):
+        pytest.skip("reference checkout not present (GPU box)")
+    names = set(re.findall(r"\b(gp(?:32|52)_[a-z0-9_]+)\b", open(ref).read()))
+    assert len(names) == 26
+    lib = C.CDLL(hip_built)
+    assert all(hasattr(lib, n) for n in names)

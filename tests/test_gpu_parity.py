@@ -346,3 +346,22 @@ def test_time_split_matches_unsplit(env, dtype, L, T, nan, monkeypatch):
     tight = 1e-11 if dtype == torch.float64 else 2e-4
     for split in ("0", "5"):
         assert rel_err(res[split][0], res["1"][0]) < tight and rel_err(res[split][2], res["1"][2]) < tight
+
+
+# ------------------------------------------------------------------------------------------ A8: polar factor on the device
+@pytest.mark.parametrize("M,L,noise", [(8, 4, 0.3), (100, 70, 0.2), (300, 300, 0.05), (1024, 512, 0.02), (64, 64, 2.0)])
+def test_polar_factor_device_vs_svd(env, M, L, noise, monkeypatch):
+    """MOIHGP::update (moihgp.h:433-447) forms U = svdU svdV^T; the device path is Newton-Schulz on MFMA GEMMs."""
+    monkeypatch.setenv("MOIHGP_POLAR", "device")
+    rng = np.random.default_rng(M + L)
+    gp = env["MOIHGP"](0.1, M, L, kernel="Matern32")
+    A = np.eye(M, L) + noise * rng.standard_normal((M, L))
+    params = np.concatenate([A.ravel(), rng.uniform(0.5, 2, L), [0.03], synth_params(L, rng).ravel()])
+    gp.update(params)
+    U = gp.params[:M * L].reshape(M, L)
+    u, _, vt = np.linalg.svd(A, full_matrices=False)
+    assert rel_err(U, u @ vt) < 1e-11
+    assert np.max(np.abs(U.T @ U - np.eye(L))) < 1e-12
+    monkeypatch.setenv("MOIHGP_POLAR", "host")
+    gp.update(params)
+    assert rel_err(gp.params[:M * L].reshape(M, L), U) < 1e-11
