@@ -117,6 +117,7 @@ struct moihgp_gp {
     double *dTy = nullptr, *dUty = nullptr, *dTyhat = nullptr, *dloss = nullptr, *dgrad = nullptr, *dscratch = nullptr;
     double* dwork = nullptr;   // L*L + L, lazily (missing-output projection)
     double* dpolar = nullptr;  // M*L + 2*L*L + 8, lazily (device polar factor)
+    int* dfallback = nullptr;  // [L] flags of latents redone by the sequential gradient kernel
     // optional kernel-exact timing of filter launches (moihgp_profile_enable)
     std::vector<hipEvent_t> prof_ev;
     int prof_n = 0;
@@ -127,7 +128,7 @@ struct moihgp_gp {
 static void gp_free(moihgp_gp* g) {
     if (!g) return;
     void* ptrs[] = {g->dU, g->dS, g->dsigma, g->dparams, g->cb64, g->cb32, g->dx, g->dy, g->ddx, g->dxnew, g->dyhat,
-                    g->ddxnew, g->dTy, g->dUty, g->dTyhat, g->dloss, g->dgrad, g->dscratch, g->dwork, g->dpolar};
+                    g->ddxnew, g->dTy, g->dUty, g->dTyhat, g->dloss, g->dgrad, g->dscratch, g->dwork, g->dpolar, g->dfallback};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : g->prof_ev) (void)hipEventDestroy(e);
@@ -187,6 +188,7 @@ static moihgp_gp* gp_create(int kernel, double dt, size_t M, size_t L, bool late
     g->dparams = dev_alloc<double>(L * g->P);
     g->cb64 = dev_alloc<double>(L * cbs);
     g->cb32 = dev_alloc<float>(L * cbs);
+    g->dfallback = dev_alloc<int>(L);
     g->igp.resize(L * g->P);
     for (size_t l = 0; l < L; l++) {
         if (params_LP) for (int p = 0; p < g->P; p++) g->igp[l * g->P + p] = params_LP[l * g->P + p];
@@ -466,7 +468,7 @@ int moihgp_grad_stream(moihgp_gp* gp, int dtype, const void* Ty, size_t T, size_
                        double* grad, void* stream) {
     if (int rc = check_stream_args(gp, dtype, Ty, T, ld, x)) return rc;
     if (!dx || !grad) { set_last_error("grad_stream: dx and grad are required"); return 1; }
-    return launch_grad_stream(gp->d, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cb32, x, dx, yhat, nll, grad, (hipStream_t)stream);
+    return launch_grad_stream(gp->d, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cb32, x, dx, yhat, nll, grad, gp->dfallback, (hipStream_t)stream);
 }
 
 int moihgp_project_stream(moihgp_gp* gp, int dtype, const void* Y, size_t T, void* Ty, size_t ld, void* stream) {

@@ -68,7 +68,7 @@ int launch_filter_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, 
 void filter_split_plan(int dtype, size_t T, size_t L, int* nsplit, size_t* Tslice);
 int launch_grad_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, size_t L,
                        const double* cb64, const float* cb32, void* x, void* dx, void* yhat,
-                       double* nll, double* grad, hipStream_t stream);
+                       double* nll, double* grad, int* fallback /* int[L] scratch */, hipStream_t stream);
 
 // tick.hip: one-tick kernels behind the reference ABI (all fp64, device pointers).
 struct TickArgs {

@@ -1,0 +1,464 @@
+// grad.hip -- sensitivity sweep over whole streams: the step with hyper-parameter sensitivities
+// (reference include/moihgp/ihgp.h:37-57) and the per-latent NLL gradient (ihgp.h:212-222), accumulated over
+// ticks in the order of the learners' loops (moihgp_online.h:61-70, moihgp_regression.h:42-50):
+//     v = y - HA x ;  nll += 1/2 (v^2/S + log S) ;  dv_p = -HdA_p x - HA dx_p ;
+//     grad_p += (v dv_p - 1/2 (v^2/S - 1) dS_p) / S                                   (pre-step x, dx)
+//     x' = AKHA x + K y ;  dx_p' = dAKHA_p x + AKHA dx_p + dK_p y
+//
+// grad_scan_kernel: one wavefront owns one latent, lanes are consecutive time chunks of CK ticks, as in
+// recursion.hip.  The mean x is solved per segment by the chunk response + DPP scan of the filter.  Each
+// sensitivity dx_p obeys the SAME linear time-invariant recursion (transition AKHA) driven by the input
+// u_t = dAKHA_p x_t + dK_p y_t, which is known once the true x trajectory of the chunk is replayed; so its chunk
+// response is accumulated during a first replay, the three dx_p are scanned with the very same powers of
+// M = AKHA^CK, and a second replay from the true (x, dx) start states emits the gradient terms.  Sums over ticks:
+//     grad_p = (sum v dv_p)/S - 1/2 (sum v^2 / S - n) dS_p / S
+// VALU-bound (about 200 vector ops per tick at d = 3, P = 3 against 4-8 bytes of stream): its roofline is the
+// vector ALU, not HBM.
+//
+// Streams with missing ticks (NaN; ihgp.h:39-47 swaps AKHA, dAKHA, dK for A, dA, 0) break the uniform chunk maps:
+// the scan kernel flags such a latent and grad_seq_kernel (one lane per latent, sequential, loads prefetched in
+// 16-byte vectors) recomputes it.  The reference never feeds a NaN to IHGP through MOIHGP (SURVEY 8a notes).
+#include "kernels_common.h"
+
+namespace moihgp {
+namespace {
+
+constexpr int P = kNumIgpParam;
+
+template <typename T, int D>
+struct GradConst {
+    T a[D * D], k[D], akha[D * D], dakha[P][D * D], dk[P][D], hda[P][D];
+};
+
+template <typename T, int D>
+__device__ inline void load_grad_const(GradConst<T, D>& c, const T* cb) {
+    using Lay = CB<D>;
+#pragma unroll
+    for (int i = 0; i < D * D; i++) { c.a[i] = cb[Lay::A + i]; c.akha[i] = cb[Lay::AKHA + i]; }
+#pragma unroll
+    for (int i = 0; i < D; i++) c.k[i] = cb[Lay::K + i];
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+#pragma unroll
+        for (int i = 0; i < D * D; i++) c.dakha[p][i] = cb[Lay::DAKHA + p * D * D + i];
+#pragma unroll
+        for (int i = 0; i < D; i++) { c.dk[p][i] = cb[Lay::DK + p * D + i]; c.hda[p][i] = cb[Lay::HDA + p * D + i]; }
+    }
+}
+
+// one tick of the mean in innovation form (H = e0^T: HA is row 0 of A); returns v, writes yhat
+template <typename T, int D>
+__device__ inline T tick_mean(const GradConst<T, D>& c, T* xs, T y, T& hx_out) {
+    T hx = 0;
+#pragma unroll
+    for (int j = 0; j < D; j++) hx = fma(c.a[j], xs[j], hx);
+    const T v = y - hx;
+    T xn[D];
+    xn[0] = fma(c.k[0], v, hx);
+#pragma unroll
+    for (int i = 1; i < D; i++) {
+        T s = c.k[i] * v;
+#pragma unroll
+        for (int j = 0; j < D; j++) s = fma(c.a[i * D + j], xs[j], s);
+        xn[i] = s;
+    }
+#pragma unroll
+    for (int i = 0; i < D; i++) xs[i] = xn[i];
+    hx_out = hx;
+    return v;
+}
+
+template <typename T, int D, int CK, bool WRITE>
+__global__ void __launch_bounds__(64 * kWavesPerBlock)
+grad_scan_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, const T* __restrict__ cbT,
+                 const double* __restrict__ cb64, T* __restrict__ x, T* __restrict__ dx, T* __restrict__ yhat,
+                 double* __restrict__ nll, double* __restrict__ grad, int* __restrict__ fallback) {
+    using V = typename VecOf<T>::type;
+    using Lay = CB<D>;
+    constexpr int EPV = 16 / sizeof(T), VPL = CK / EPV, SEG = 64 * CK, NVP = 64 * (VPL + 1);
+    constexpr int NTAB = CK * D + 4 * D * D;                     // g table + scan powers, per wave, in LDS
+    static_assert(CK % EPV == 0, "CK must be a multiple of 16 bytes");
+    __shared__ V lds_all[kWavesPerBlock][NVP];
+    __shared__ T tab_all[kWavesPerBlock][NTAB];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t l = (size_t)blockIdx.x * kWavesPerBlock + wave;
+    if (l >= L) return;
+    V* lds = lds_all[wave];
+    T* tab = tab_all[wave];
+    const T* cb = cbT + l * Lay::SIZE;
+    const double* c64 = cb64 + l * Lay::SIZE;
+
+    // ---- tables of the segment solve for THIS chunk length, from the fp64 master copy: g_k = AKHA^(CK-1-k) K,
+    //      sp = M^(1,2,4,8) with M = AKHA^CK (parked in LDS, re-read per segment), pj = M^(lane%16+1) (registers)
+    T pj[D * D];
+    {
+        double ak[D * D], g[D], m[D * D], pw[D * D];
+#pragma unroll
+        for (int i = 0; i < D * D; i++) ak[i] = c64[Lay::AKHA + i];
+#pragma unroll
+        for (int i = 0; i < D; i++) g[i] = c64[Lay::K + i];
+#pragma unroll
+        for (int k = CK - 1; k >= 0; k--) {
+#pragma unroll
+            for (int i = 0; i < D; i++) if (lane == i) tab[k * D + i] = (T)g[i];
+            double gn[D];
+#pragma unroll
+            for (int i = 0; i < D; i++) { double s = 0; for (int j = 0; j < D; j++) s = fma(ak[i * D + j], g[j], s); gn[i] = s; }
+#pragma unroll
+            for (int i = 0; i < D; i++) g[i] = gn[i];
+        }
+#pragma unroll
+        for (int i = 0; i < D * D; i++) m[i] = ak[i];
+#pragma unroll
+        for (int q = 1; q < CK; q <<= 1) matmul<double, D>(m, m, m);          // CK is a power of two
+#pragma unroll
+        for (int i = 0; i < D * D; i++) pw[i] = m[i];
+#pragma unroll
+        for (int lv = 0; lv < 4; lv++) {
+#pragma unroll
+            for (int i = 0; i < D * D; i++) if (lane == i) tab[CK * D + lv * D * D + i] = (T)pw[i];
+            matmul<double, D>(pw, pw, pw);
+        }
+        // pj = M^(r+1), r = lane & 15, by binary powering on the bits of r
+        double acc[D * D], sq[D * D];
+#pragma unroll
+        for (int i = 0; i < D * D; i++) { acc[i] = m[i]; sq[i] = m[i]; }
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            double t[D * D];
+            matmul<double, D>(acc, sq, t);
+            const bool take = ((lane & 15) >> b) & 1;
+#pragma unroll
+            for (int i = 0; i < D * D; i++) acc[i] = take ? t[i] : acc[i];
+            matmul<double, D>(sq, sq, sq);
+        }
+#pragma unroll
+        for (int i = 0; i < D * D; i++) pj[i] = (T)acc[i];
+        wave_lds_fence();
+    }
+    static_assert((CK & (CK - 1)) == 0, "CK must be a power of two");
+
+    GradConst<T, D> c;
+    load_grad_const<T, D>(c, cb);
+
+    const T* row = Ty + l * ld;
+    T* orow = WRITE ? yhat + l * ld : nullptr;
+    T xin[D], dxin[P][D];
+#pragma unroll
+    for (int i = 0; i < D; i++) xin[i] = x[l * D + i];
+#pragma unroll
+    for (int p = 0; p < P; p++)
+#pragma unroll
+        for (int i = 0; i < D; i++) dxin[p][i] = dx[(l * P + p) * D + i];
+
+    double sv2 = 0.0, svdv[P] = {0.0, 0.0, 0.0};     // per-lane sums over ticks
+    unsigned nobs = 0;
+    bool has_nan = false;
+
+    const size_t nfull = Tlen / SEG, nseg = (Tlen + SEG - 1) / SEG;
+    for (size_t seg = 0; seg < nseg && !has_nan; seg++) {
+        const size_t tbase = seg * SEG, t0 = tbase + (size_t)lane * CK;
+        const bool tail = seg >= nfull;
+        // ---- coalesced loads -> LDS -> chunk-per-lane registers (padding past Tlen reads as zero) --------
+#pragma unroll
+        for (int i = 0; i < VPL; i++) {
+            const int q = i * 64 + lane;
+            const size_t tq = tbase + (size_t)q * EPV;
+            T e[EPV] = {};
+            if (!tail || tq < Tlen) {
+                unpack<T>(*reinterpret_cast<const V*>(row + tq), e);
+                if (tail) {
+#pragma unroll
+                    for (int k = 0; k < EPV; k++) if (tq + k >= Tlen) e[k] = T(0);
+                }
+            }
+            lds[q + q / VPL] = pack<T>(e);
+        }
+        wave_lds_fence();
+        T y[CK];
+#pragma unroll
+        for (int k = 0; k < VPL; k++) unpack<T>(lds[lane * (VPL + 1) + k], &y[k * EPV]);
+
+        // ---- (a) mean: chunk response + scan -------------------------------------------------------------
+        T sp[4 * D * D];
+#pragma unroll
+        for (int i = 0; i < 4 * D * D; i++) sp[i] = tab[CK * D + i];
+        T z[D];
+#pragma unroll
+        for (int i = 0; i < D; i++) z[i] = T(0);
+#pragma unroll
+        for (int k = 0; k < CK; k++)
+#pragma unroll
+            for (int i = 0; i < D; i++) z[i] = fma(tab[k * D + i], y[k], z[i]);
+        bool bad = false;
+#pragma unroll
+        for (int i = 0; i < D; i++) bad |= (z[i] != z[i]);
+        if (__any(bad)) { has_nan = true; break; }                 // missing ticks: hand the latent to grad_seq_kernel
+        {
+            T x0[D];
+#pragma unroll
+            for (int i = 0; i < D; i++) x0[i] = (lane == 0) ? xin[i] : T(0);
+            matvec_acc<T, D>(sp, x0, z);
+        }
+        dpp_scan<T, D>(z, sp, pj);
+        T xs[D];
+#pragma unroll
+        for (int i = 0; i < D; i++) xs[i] = wave_shr1(z[i], xin[i]);
+
+        // ---- (b) replay 1: true mean trajectory -> zero-state chunk response of every sensitivity -------------
+        T dz[P][D];
+        {
+            T xr[D];
+#pragma unroll
+            for (int i = 0; i < D; i++) xr[i] = xs[i];
+#pragma unroll
+            for (int p = 0; p < P; p++)
+#pragma unroll
+                for (int i = 0; i < D; i++) dz[p][i] = T(0);
+#pragma unroll
+            for (int k = 0; k < CK; k++) {
+                const bool valid = !tail || (t0 + k) < Tlen;
+#pragma unroll
+                for (int p = 0; p < P; p++) {
+                    T u[D];
+#pragma unroll
+                    for (int i = 0; i < D; i++) u[i] = c.dk[p][i] * y[k];
+                    matvec_acc<T, D>(c.dakha[p], xr, u);            // u = dAKHA_p x + dK_p y   (pre-step x, ihgp.h:54)
+                    matvec_acc<T, D>(c.akha, dz[p], u);             // + AKHA dz
+#pragma unroll
+                    for (int i = 0; i < D; i++) dz[p][i] = valid ? u[i] : dz[p][i];
+                }
+                T xo[D], hx;
+#pragma unroll
+                for (int i = 0; i < D; i++) xo[i] = xr[i];
+                tick_mean<T, D>(c, xr, y[k], hx);
+                if (tail) {
+#pragma unroll
+                    for (int i = 0; i < D; i++) xr[i] = valid ? xr[i] : xo[i];
+                }
+            }
+        }
+        // ---- (c) scan the sensitivities with the same powers; lane 0 carries dx_in ---------------------------
+        T dxs[P][D];
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            T d0[D];
+#pragma unroll
+            for (int i = 0; i < D; i++) d0[i] = (lane == 0) ? dxin[p][i] : T(0);
+            matvec_acc<T, D>(sp, d0, dz[p]);
+            dpp_scan<T, D>(dz[p], sp, pj);
+#pragma unroll
+            for (int i = 0; i < D; i++) dxs[p][i] = wave_shr1(dz[p][i], dxin[p][i]);
+        }
+        // ---- (d) replay 2 from the true start states: gradient terms, filtered means ----------------------------
+        T pv2 = 0, pvdv[P] = {0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < CK; k++) {
+            const bool valid = !tail || (t0 + k) < Tlen;
+            T xo[D], hx;
+#pragma unroll
+            for (int i = 0; i < D; i++) xo[i] = xs[i];
+            T dxn[P][D];
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+#pragma unroll
+                for (int i = 0; i < D; i++) dxn[p][i] = c.dk[p][i] * y[k];
+                matvec_acc<T, D>(c.dakha[p], xs, dxn[p]);
+                matvec_acc<T, D>(c.akha, dxs[p], dxn[p]);           // ihgp.h:54
+            }
+            T v = tick_mean<T, D>(c, xs, y[k], hx);                 // xs <- AKHA x + K y (ihgp.h:50), v = y - HA x
+            if (tail) v = valid ? v : T(0);
+            pv2 = fma(v, v, pv2);
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                T a = 0, b = 0;
+#pragma unroll
+                for (int i = 0; i < D; i++) { a = fma(c.hda[p][i], xo[i], a); b = fma(c.a[i], dxs[p][i], b); }
+                pvdv[p] = fma(v, -a - b, pvdv[p]);                  // v * dv_p, dv_p = -HdA_p x - HA dx_p (ihgp.h:218)
+            }
+            if (tail) {
+                nobs += valid ? 1u : 0u;
+#pragma unroll
+                for (int i = 0; i < D; i++) xs[i] = valid ? xs[i] : xo[i];
+            }
+#pragma unroll
+            for (int p = 0; p < P; p++)
+#pragma unroll
+                for (int i = 0; i < D; i++) dxs[p][i] = (tail && !valid) ? dxs[p][i] : dxn[p][i];
+            y[k] = xs[0];
+        }
+        if (!tail) nobs += CK;
+        sv2 += (double)pv2;
+#pragma unroll
+        for (int p = 0; p < P; p++) svdv[p] += (double)pvdv[p];
+        // state after the last valid tick
+        int jl = 63;
+        if (tail) jl = (int)((Tlen - 1 - tbase) / CK);
+#pragma unroll
+        for (int i = 0; i < D; i++) xin[i] = read_lane(xs[i], jl);
+#pragma unroll
+        for (int p = 0; p < P; p++)
+#pragma unroll
+            for (int i = 0; i < D; i++) dxin[p][i] = read_lane(dxs[p][i], jl);
+
+        if (WRITE) {
+#pragma unroll
+            for (int k = 0; k < VPL; k++) lds[lane * (VPL + 1) + k] = pack<T>(&y[k * EPV]);
+            wave_lds_fence();
+#pragma unroll
+            for (int i = 0; i < VPL; i++) {
+                const int q = i * 64 + lane;
+                const size_t tq = tbase + (size_t)q * EPV;
+                if (!tail || tq < Tlen) *reinterpret_cast<V*>(orow + tq) = lds[q + q / VPL];
+            }
+        }
+        wave_lds_fence();
+    }
+
+    if (has_nan) {                                                  // nothing has been written for this latent's state yet
+        if (lane == 0) fallback[l] = 1;
+        return;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sv2 += __shfl_xor(sv2, o);
+        nobs += __shfl_xor(nobs, o);
+#pragma unroll
+        for (int p = 0; p < P; p++) svdv[p] += __shfl_xor(svdv[p], o);
+    }
+    if (lane == 0) {
+        fallback[l] = 0;
+#pragma unroll
+        for (int i = 0; i < D; i++) x[l * D + i] = xin[i];
+#pragma unroll
+        for (int p = 0; p < P; p++)
+#pragma unroll
+            for (int i = 0; i < D; i++) dx[(l * P + p) * D + i] = dxin[p][i];
+        const double S = c64[Lay::S], n = (double)nobs;
+        if (nll) nll[l] = 0.5 * (sv2 / S + n * c64[Lay::LOGS]);
+#pragma unroll
+        for (int p = 0; p < P; p++) grad[l * P + p] = svdv[p] / S - 0.5 * (sv2 / S - n) * c64[Lay::DS + p] / S;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// One lane per latent, sequential in time (ihgp.h:37-57, :212-222 literally, including the missing-data branch).
+// Runs only the latents flagged in `only` (NULL: all).  y is fetched one 16-byte vector at a time.
+template <typename T, int D>
+__global__ void __launch_bounds__(64)
+grad_seq_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, const T* __restrict__ cbT,
+                const double* __restrict__ cb64, T* __restrict__ x, T* __restrict__ dx, T* __restrict__ yhat,
+                double* __restrict__ nll, double* __restrict__ grad, const int* __restrict__ only) {
+    using V = typename VecOf<T>::type;
+    using Lay = CB<D>;
+    constexpr int EPV = 16 / sizeof(T);
+    size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= L) return;
+    if (only && !only[l]) return;
+    const T* c = cbT + l * Lay::SIZE;
+    const double* c64 = cb64 + l * Lay::SIZE;
+    T akha[D * D], aa[D * D], kk[D], ha[D], dakha[P][D * D], da[P][D * D], dk[P][D], hda[P][D];
+    for (int i = 0; i < D * D; i++) { akha[i] = c[Lay::AKHA + i]; aa[i] = c[Lay::A + i]; }
+    for (int i = 0; i < D; i++) { kk[i] = c[Lay::K + i]; ha[i] = c[Lay::HA + i]; }
+    for (int p = 0; p < P; p++) {
+        for (int i = 0; i < D * D; i++) { dakha[p][i] = c[Lay::DAKHA + p * D * D + i]; da[p][i] = c[Lay::DA + p * D * D + i]; }
+        for (int i = 0; i < D; i++) { dk[p][i] = c[Lay::DK + p * D + i]; hda[p][i] = c[Lay::HDA + p * D + i]; }
+    }
+    const double S = c64[Lay::S], logS = c64[Lay::LOGS];
+    double dS[P];
+    for (int p = 0; p < P; p++) dS[p] = c64[Lay::DS + p];
+    T xs[D], dxs[P][D];
+    for (int i = 0; i < D; i++) xs[i] = x[l * D + i];
+    for (int p = 0; p < P; p++)
+        for (int i = 0; i < D; i++) dxs[p][i] = dx[(l * P + p) * D + i];
+    double acc = 0.0, g[P] = {0.0, 0.0, 0.0};
+    const T* row = Ty + l * ld;
+    for (size_t tb = 0; tb < Tlen; tb += EPV) {
+        T yv[EPV];
+        unpack<T>(*reinterpret_cast<const V*>(row + tb), yv);       // ld >= roundup(T, EPV)
+        for (int e = 0; e < EPV && tb + e < Tlen; e++) {
+            const T y = yv[e];
+            const bool miss = (y != y);
+            T xn[D], dxn[P][D];
+            if (!miss) {
+                T hx = 0;
+                for (int i = 0; i < D; i++) hx = fma(ha[i], xs[i], hx);
+                double v = (double)(y - hx);
+                acc += 0.5 * (v * v / S + logS);                        // ihgp.h:215
+                for (int p = 0; p < P; p++) {
+                    T a = 0, b = 0;
+                    for (int i = 0; i < D; i++) { a = fma(hda[p][i], xs[i], a); b = fma(ha[i], dxs[p][i], b); }
+                    double dv = (double)(-a - b);                       // ihgp.h:218
+                    g[p] += (v * dv - 0.5 * (v * v / S - 1.0) * dS[p]) / S;   // ihgp.h:219
+                }
+                for (int i = 0; i < D; i++) xn[i] = kk[i] * y;
+                matvec_acc<T, D>(akha, xs, xn);                         // ihgp.h:50
+                for (int p = 0; p < P; p++) {
+                    for (int i = 0; i < D; i++) dxn[p][i] = dk[p][i] * y;
+                    matvec_acc<T, D>(dakha[p], xs, dxn[p]);
+                    matvec_acc<T, D>(akha, dxs[p], dxn[p]);             // ihgp.h:54
+                }
+            } else {
+                for (int i = 0; i < D; i++) xn[i] = 0;
+                matvec_acc<T, D>(aa, xs, xn);                           // ihgp.h:41
+                for (int p = 0; p < P; p++) {
+                    for (int i = 0; i < D; i++) dxn[p][i] = 0;
+                    matvec_acc<T, D>(da[p], xs, dxn[p]);
+                    matvec_acc<T, D>(aa, dxs[p], dxn[p]);               // ihgp.h:45
+                }
+            }
+            for (int i = 0; i < D; i++) xs[i] = xn[i];
+            for (int p = 0; p < P; p++)
+                for (int i = 0; i < D; i++) dxs[p][i] = dxn[p][i];
+            if (yhat) yhat[l * ld + tb + e] = xn[0];
+        }
+    }
+    for (int i = 0; i < D; i++) x[l * D + i] = xs[i];
+    for (int p = 0; p < P; p++)
+        for (int i = 0; i < D; i++) dx[(l * P + p) * D + i] = dxs[p][i];
+    if (nll) nll[l] = acc;
+    for (int p = 0; p < P; p++) grad[l * P + p] = g[p];
+}
+
+template <typename T, int D, int CK>
+int launch_grad_t(const T* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, const double* cb64, T* x, T* dx, T* yhat,
+                  double* nll, double* grad, int* fallback, hipStream_t stream) {
+    dim3 block(64 * kWavesPerBlock), grid((unsigned)((L + kWavesPerBlock - 1) / kWavesPerBlock));
+    if (yhat)
+        hipLaunchKernelGGL((grad_scan_kernel<T, D, CK, true>), grid, block, 0, stream, Ty, Tlen, ld, L, cbT, cb64, x, dx, yhat, nll, grad, fallback);
+    else
+        hipLaunchKernelGGL((grad_scan_kernel<T, D, CK, false>), grid, block, 0, stream, Ty, Tlen, ld, L, cbT, cb64, x, dx, yhat, nll, grad, fallback);
+    // latents whose stream holds missing ticks are redone sequentially (their x / dx were left untouched)
+    hipLaunchKernelGGL((grad_seq_kernel<T, D>), dim3((unsigned)((L + 63) / 64)), dim3(64), 0, stream, Ty, Tlen, ld, L, cbT, cb64, x, dx, yhat, nll,
+                       grad, (const int*)fallback);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_last_error("grad kernels launch: %s", hipGetErrorString(e)); return 2; }
+    return 0;
+}
+
+}  // namespace
+
+// fallback: device int[L] scratch (flags of latents with missing ticks)
+int launch_grad_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* cb64,
+                       const float* cb32, void* x, void* dx, void* yhat, double* nll, double* grad, int* fallback,
+                       hipStream_t stream) {
+    if (L == 0) return 0;
+    // short windows (the online learner's W <= 128 ticks, moihgp_online.h:61-70) use 16-byte chunks so that a
+    // window still spreads over the lanes of the wave; long streams use 64-byte chunks
+    const bool shortw = T <= (dtype == 0 ? 256 : 512);
+#define MOIHGP_GRAD_CASE(TT, DD, CKK, CB) \
+    return launch_grad_t<TT, DD, CKK>((const TT*)Ty, T, ld, L, CB, cb64, (TT*)x, (TT*)dx, (TT*)yhat, nll, grad, fallback, stream)
+    if (dtype == 0) {
+        if (d == 2) { if (shortw) MOIHGP_GRAD_CASE(double, 2, 2, cb64); MOIHGP_GRAD_CASE(double, 2, 8, cb64); }
+        if (shortw) MOIHGP_GRAD_CASE(double, 3, 2, cb64);
+        MOIHGP_GRAD_CASE(double, 3, 8, cb64);
+    }
+    if (d == 2) { if (shortw) MOIHGP_GRAD_CASE(float, 2, 4, cb32); MOIHGP_GRAD_CASE(float, 2, 16, cb32); }
+    if (shortw) MOIHGP_GRAD_CASE(float, 3, 4, cb32);
+    MOIHGP_GRAD_CASE(float, 3, 16, cb32);
+#undef MOIHGP_GRAD_CASE
+}
+
+}  // namespace moihgp

@@ -18,90 +18,11 @@
 //
 // Missing data (NaN y, ihgp.h:83-87: x <- A x) and the ragged tail segment make chunk maps
 // lane-dependent; those segments take the generic path that scans (M_j, z_j) pairs.
-#include "common.h"
+#include "kernels_common.h"
 #include <hip/hip_ext.h>
 
 namespace moihgp {
 namespace {
-
-template <typename T> struct VecOf;
-template <> struct VecOf<float> { using type = float4; };
-template <> struct VecOf<double> { using type = double2; };
-
-template <typename T> __device__ inline void unpack(const typename VecOf<T>::type& v, T* out);
-template <> __device__ inline void unpack<float>(const float4& v, float* o) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
-template <> __device__ inline void unpack<double>(const double2& v, double* o) { o[0] = v.x; o[1] = v.y; }
-template <typename T> __device__ inline typename VecOf<T>::type pack(const T* in);
-template <> __device__ inline float4 pack<float>(const float* i) { return make_float4(i[0], i[1], i[2], i[3]); }
-template <> __device__ inline double2 pack<double>(const double* i) { return make_double2(i[0], i[1]); }
-
-__device__ inline void wave_lds_fence() {
-    // LDS operations of one wave execute in program order; this only stops the compiler from
-    // moving LDS accesses across the hand-over between lanes of the same wave.
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
-template <typename T, int D>
-__device__ inline void matvec_acc(const T* m, const T* v, T* out /* out = m v + out */) {
-#pragma unroll
-    for (int i = 0; i < D; i++) {
-        T s = out[i];
-#pragma unroll
-        for (int j = 0; j < D; j++) s = fma(m[i * D + j], v[j], s);
-        out[i] = s;
-    }
-}
-
-template <typename T, int D>
-__device__ inline void matmul(const T* a, const T* b, T* c) {
-    T t[D * D];
-#pragma unroll
-    for (int i = 0; i < D; i++)
-#pragma unroll
-        for (int j = 0; j < D; j++) {
-            T s = 0;
-#pragma unroll
-            for (int k = 0; k < D; k++) s = fma(a[i * D + k], b[k * D + j], s);
-            t[i * D + j] = s;
-        }
-#pragma unroll
-    for (int i = 0; i < D * D; i++) c[i] = t[i];
-}
-
-constexpr int kWavesPerBlock = 4;
-
-// ---- DPP lane movement (no LDS, no ds_bpermute) --------------------------------------------------
-// v_mov_b32_dpp with `old` = 0: lanes that the control leaves without a source (or that row_mask
-// excludes) read 0, which is exactly the "no contribution" value of the scan below.
-template <int CTRL, int ROW_MASK>
-__device__ inline float dpp0(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
-}
-template <int CTRL, int ROW_MASK>
-__device__ inline double dpp0(double v) {
-    unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-    unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, ROW_MASK, 0xF, false);
-    unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, ROW_MASK, 0xF, false);
-    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-}
-// wave_shr:1 with lane 0 keeping `first`
-__device__ inline float wave_shr1(float v, float first) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, first), __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, false));
-}
-__device__ inline double wave_shr1(double v, double first) {
-    unsigned long long u = __builtin_bit_cast(unsigned long long, v), f = __builtin_bit_cast(unsigned long long, first);
-    unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)f, (int)(unsigned)u, 0x138, 0xF, 0xF, false);
-    unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(f >> 32), (int)(unsigned)(u >> 32), 0x138, 0xF, 0xF, false);
-    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-}
-__device__ inline float read_lane(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
-__device__ inline double read_lane(double v, int l) {
-    unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-    unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), l);
-    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-}
-constexpr int DPP_ROW_SHR = 0x110, DPP_ROW_BCAST15 = 0x142;
 
 // Per-latent constants of the fast path.  sp / g / a / k are wave-uniform; pj is per lane.
 template <typename T, int D, int CK>
@@ -149,30 +70,7 @@ __device__ inline bool fast_segment(T* y, T* xin, const FastConst<T, D, CK>& c, 
         matvec_acc<T, D>(c.sp, x0, z);      // lane 0: + M xin
     }
     // ---- 2. scan --------------------------------------------------------------------------------
-    {
-        T t[D];
-#pragma unroll
-        for (int i = 0; i < D; i++) t[i] = dpp0<DPP_ROW_SHR + 1, 0xF>(z[i]);
-        matvec_acc<T, D>(c.sp + 0 * D * D, t, z);
-#pragma unroll
-        for (int i = 0; i < D; i++) t[i] = dpp0<DPP_ROW_SHR + 2, 0xF>(z[i]);
-        matvec_acc<T, D>(c.sp + 1 * D * D, t, z);
-#pragma unroll
-        for (int i = 0; i < D; i++) t[i] = dpp0<DPP_ROW_SHR + 4, 0xF>(z[i]);
-        matvec_acc<T, D>(c.sp + 2 * D * D, t, z);
-#pragma unroll
-        for (int i = 0; i < D; i++) t[i] = dpp0<DPP_ROW_SHR + 8, 0xF>(z[i]);
-        matvec_acc<T, D>(c.sp + 3 * D * D, t, z);
-#pragma unroll
-        for (int i = 0; i < D; i++) t[i] = dpp0<DPP_ROW_BCAST15, 0x2>(z[i]);
-        matvec_acc<T, D>(c.pj, t, z);
-#pragma unroll
-        for (int i = 0; i < D; i++) t[i] = dpp0<DPP_ROW_BCAST15, 0x4>(z[i]);
-        matvec_acc<T, D>(c.pj, t, z);
-#pragma unroll
-        for (int i = 0; i < D; i++) t[i] = dpp0<DPP_ROW_BCAST15, 0x8>(z[i]);
-        matvec_acc<T, D>(c.pj, t, z);
-    }
+    dpp_scan<T, D>(z, c.sp, c.pj);
     if (ENDONLY) {                           // only the state after the (full) segment is wanted: no replay
 #pragma unroll
         for (int i = 0; i < D; i++) xin[i] = read_lane(z[i], 63);
@@ -561,80 +459,6 @@ filter_scan_kernel(const T* __restrict__ Ty, size_t Ttot, size_t ld, size_t L, c
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Sensitivity sweep (ihgp.h:37-57 step with dx, :212-222 NLL gradient), one lane per latent,
-// sequential in time.  First correct version for the learning sweeps (short windows W <= 128,
-// moihgp_online.h:61-70); the long-stream form reuses the scan structure above in a later round.
-template <typename T, int D>
-__global__ void __launch_bounds__(64)
-grad_seq_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, const T* __restrict__ cbT,
-                const double* __restrict__ cb64, T* __restrict__ x, T* __restrict__ dx, T* __restrict__ yhat,
-                double* __restrict__ nll, double* __restrict__ grad) {
-    using Lay = CB<D>;
-    constexpr int P = kNumIgpParam;
-    size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= L) return;
-    const T* c = cbT + l * Lay::SIZE;
-    const double* c64 = cb64 + l * Lay::SIZE;
-    T akha[D * D], aa[D * D], kk[D], ha[D], dakha[P][D * D], da[P][D * D], dk[P][D], hda[P][D];
-    for (int i = 0; i < D * D; i++) { akha[i] = c[Lay::AKHA + i]; aa[i] = c[Lay::A + i]; }
-    for (int i = 0; i < D; i++) { kk[i] = c[Lay::K + i]; ha[i] = c[Lay::HA + i]; }
-    for (int p = 0; p < P; p++) {
-        for (int i = 0; i < D * D; i++) { dakha[p][i] = c[Lay::DAKHA + p * D * D + i]; da[p][i] = c[Lay::DA + p * D * D + i]; }
-        for (int i = 0; i < D; i++) { dk[p][i] = c[Lay::DK + p * D + i]; hda[p][i] = c[Lay::HDA + p * D + i]; }
-    }
-    const double S = c64[Lay::S], logS = c64[Lay::LOGS];
-    double dS[P];
-    for (int p = 0; p < P; p++) dS[p] = c64[Lay::DS + p];
-    T xs[D], dxs[P][D];
-    for (int i = 0; i < D; i++) xs[i] = x[l * D + i];
-    for (int p = 0; p < P; p++)
-        for (int i = 0; i < D; i++) dxs[p][i] = dx[(l * P + p) * D + i];
-    double acc = 0.0, g[P] = {0.0, 0.0, 0.0};
-    const T* row = Ty + l * ld;
-    for (size_t t = 0; t < Tlen; t++) {
-        const T y = row[t];
-        const bool miss = (y != y);
-        T xn[D], dxn[P][D];
-        if (!miss) {
-            T hx = 0;
-            for (int i = 0; i < D; i++) hx = fma(ha[i], xs[i], hx);
-            double v = (double)(y - hx);
-            acc += 0.5 * (v * v / S + logS);                            // ihgp.h:215
-            for (int p = 0; p < P; p++) {
-                T a = 0, b = 0;
-                for (int i = 0; i < D; i++) { a = fma(hda[p][i], xs[i], a); b = fma(ha[i], dxs[p][i], b); }
-                double dv = (double)(-a - b);                           // ihgp.h:218
-                g[p] += (v * dv - 0.5 * (v * v / S - 1.0) * dS[p]) / S;   // ihgp.h:219
-            }
-            for (int i = 0; i < D; i++) xn[i] = kk[i] * y;
-            matvec_acc<T, D>(akha, xs, xn);                             // ihgp.h:50
-            for (int p = 0; p < P; p++) {
-                for (int i = 0; i < D; i++) dxn[p][i] = dk[p][i] * y;
-                matvec_acc<T, D>(dakha[p], xs, dxn[p]);
-                matvec_acc<T, D>(akha, dxs[p], dxn[p]);                 // ihgp.h:54
-            }
-        } else {
-            for (int i = 0; i < D; i++) xn[i] = 0;
-            matvec_acc<T, D>(aa, xs, xn);                               // ihgp.h:41
-            for (int p = 0; p < P; p++) {
-                for (int i = 0; i < D; i++) dxn[p][i] = 0;
-                matvec_acc<T, D>(da[p], xs, dxn[p]);
-                matvec_acc<T, D>(aa, dxs[p], dxn[p]);                   // ihgp.h:45
-            }
-        }
-        for (int i = 0; i < D; i++) xs[i] = xn[i];
-        for (int p = 0; p < P; p++)
-            for (int i = 0; i < D; i++) dxs[p][i] = dxn[p][i];
-        if (yhat) yhat[l * ld + t] = xn[0];
-    }
-    for (int i = 0; i < D; i++) x[l * D + i] = xs[i];
-    for (int p = 0; p < P; p++)
-        for (int i = 0; i < D; i++) dx[(l * P + p) * D + i] = dxs[p][i];
-    if (nll) nll[l] = acc;
-    for (int p = 0; p < P; p++) grad[l * P + p] = g[p];
-}
-
 template <typename T, int D, int CK, int MINW, bool SPLIT>
 int launch_filter_t(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, const double* cb64, void* x,
                     void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, int nsplit, size_t Tslice) {
@@ -703,26 +527,6 @@ int launch_filter_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, 
     if (variant == 1) MOIHGP_FILTER_CASE(float, 3, kChunk32, 1, cb32);
     MOIHGP_FILTER_CASE(float, 3, kChunk32, 4, cb32);
 #undef MOIHGP_FILTER_CASE
-}
-
-int launch_grad_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* cb64,
-                       const float* cb32, void* x, void* dx, void* yhat, double* nll, double* grad, hipStream_t stream) {
-    if (L == 0) return 0;
-    dim3 block(64), grid((unsigned)((L + 63) / 64));
-    if (dtype == 0) {
-        if (d == 2)
-            hipLaunchKernelGGL((grad_seq_kernel<double, 2>), grid, block, 0, stream, (const double*)Ty, T, ld, L, cb64, cb64, (double*)x, (double*)dx, (double*)yhat, nll, grad);
-        else
-            hipLaunchKernelGGL((grad_seq_kernel<double, 3>), grid, block, 0, stream, (const double*)Ty, T, ld, L, cb64, cb64, (double*)x, (double*)dx, (double*)yhat, nll, grad);
-    } else {
-        if (d == 2)
-            hipLaunchKernelGGL((grad_seq_kernel<float, 2>), grid, block, 0, stream, (const float*)Ty, T, ld, L, cb32, cb64, (float*)x, (float*)dx, (float*)yhat, nll, grad);
-        else
-            hipLaunchKernelGGL((grad_seq_kernel<float, 3>), grid, block, 0, stream, (const float*)Ty, T, ld, L, cb32, cb64, (float*)x, (float*)dx, (float*)yhat, nll, grad);
-    }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { set_last_error("grad_seq_kernel launch: %s", hipGetErrorString(e)); return 2; }
-    return 0;
 }
 
 }  // namespace moihgp

@@ -365,3 +365,30 @@ def test_polar_factor_device_vs_svd(env, M, L, noise, monkeypatch):
     monkeypatch.setenv("MOIHGP_POLAR", "host")
     gp.update(params)
     assert rel_err(gp.params[:M * L].reshape(M, L), U) < 1e-11
+
+
+# ------------------------------------------------------------------------------------------ A2/A5 scan-structured gradient sweep
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("kern,L,T,nan", [("Matern52", 5, 16, 0.0), ("Matern32", 9, 128, 0.0), ("Matern52", 3, 129, 0.0),
+                                         ("Matern52", 6, 1500, 0.0), ("Matern32", 4, 2600, 0.0), ("Matern52", 70, 1030, 0.0),
+                                         ("Matern52", 8, 700, 0.01)])
+def test_gradstream_vs_oracle(env, dtype, kern, L, T, nan):
+    rng = np.random.default_rng(L * 31 + T)
+    prm = synth_params(L, rng)
+    bank = env["streams"].LatentBank(0.1, prm, kernel=KMAP[kern])
+    d = bank.d
+    Ty = synth(L, T, rng, nan)
+    if nan:
+        Ty[:L // 2] = np.nan_to_num(Ty[:L // 2], nan=0.1)        # half of the latents clean: mixes scan and fallback paths
+    x0 = 0.2 * rng.standard_normal((L, d)); dx0 = 0.05 * rng.standard_normal((L, 3, d))
+    o = env["cref"].grad_stream(env["cref"].ihgp_array(kern, 0.1, prm), Ty, x0=x0, dx0=dx0)
+    r = bank.grad(to_dev(Ty, dtype), T=T, x=torch.from_numpy(x0).to(dtype).cuda(), dx=torch.from_numpy(dx0).to(dtype).cuda(), want_yhat=True)
+    torch.cuda.synchronize()
+    tol = 1e-9 if dtype == torch.float64 else FP32_TOL
+    assert rel_err(r["yhat"][:, :T].cpu().numpy(), o["yhat"]) < tol
+    assert rel_err(r["x"].cpu().numpy(), o["x"]) < tol and rel_err(r["dx"].cpu().numpy(), o["dx"]) < tol * 10
+    assert rel_err(r["nll"].cpu().numpy(), o["nll_per_latent"]) < tol
+    assert rel_err(r["grad"].cpu().numpy(), o["grad"]) < tol * 10
+    r2 = bank.grad(to_dev(Ty, dtype), T=T, x=torch.from_numpy(x0).to(dtype).cuda(), dx=torch.from_numpy(dx0).to(dtype).cuda(), want_yhat=False)
+    torch.cuda.synchronize()
+    assert torch.equal(r2["grad"], r["grad"]) and torch.equal(r2["nll"], r["nll"])
