@@ -153,6 +153,18 @@ int moihgp_grad_stream(moihgp_gp* gp, int dtype, const void* Ty, size_t T, size_
 int moihgp_project_stream(moihgp_gp* gp, int dtype, const void* Y, size_t T, void* Ty, size_t ld, void* stream);
 int moihgp_unproject_stream(moihgp_gp* gp, int dtype, const void* Tyhat, size_t T, size_t ld, void* Yhat, void* stream);
 
+/* ---- the learners' windowed objective as one call (HOST pointers, fp64) -----------------------------
+ * One evaluation of the loop of moihgp_online.h:61-70 / moihgp_regression.h:42-50 / online_learning.py:83-89:
+ *     for t < W:  step(x, y_t, dx, xnew, dxnew);  loss += negLogLikelihood(x, y_t, dx, g);  grad += g;  x = xnew;  dx = dxnew
+ * with the object's current parameters (set them with gpXX_update first, moihgp_online.h:43).
+ * moihgp_window_set uploads the window Y [W][M] (tick-major, already de-meaned by the caller) once; it stays
+ * resident for all evaluations of one L-BFGS solve.  Returns 3 if Y contains NaN (missing outputs need the
+ * per-tick least-squares projection, moihgp.h:167-178: use the per-tick ABI for such windows).
+ * moihgp_window_eval:  x [L][d], dx [L][P][d] state before the window;  *loss, grad [M*L+L+1+L*P] summed over the
+ * W ticks;  xnew / dxnew (may be NULL) state after the window. */
+int moihgp_window_set(moihgp_gp* gp, const double* Y, size_t W);
+int moihgp_window_eval(moihgp_gp* gp, const double* x, const double* dx, double* loss, double* grad, double* xnew, double* dxnew);
+
 /* Kernel-exact timing of moihgp_filter_stream launches (bench / diagnosis).  After
  * moihgp_profile_enable(gp, n) the next n launches on this handle are bracketed by a HIP event pair
  * attached to the dispatch itself (hipExtLaunchKernel), not to the stream.  moihgp_profile_read waits

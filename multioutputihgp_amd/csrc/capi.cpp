@@ -118,6 +118,10 @@ struct moihgp_gp {
     double* dwork = nullptr;   // L*L + L, lazily (missing-output projection)
     double* dpolar = nullptr;  // M*L + 2*L*L + 8, lazily (device polar factor)
     int* dfallback = nullptr;  // [L] flags of latents redone by the sequential gradient kernel
+    // window objective (moihgp_window_set / moihgp_window_eval)
+    WindowBufs win{};
+    double* dwin = nullptr;
+    size_t win_cap = 0;
     // optional kernel-exact timing of filter launches (moihgp_profile_enable)
     std::vector<hipEvent_t> prof_ev;
     int prof_n = 0;
@@ -128,7 +132,7 @@ struct moihgp_gp {
 static void gp_free(moihgp_gp* g) {
     if (!g) return;
     void* ptrs[] = {g->dU, g->dS, g->dsigma, g->dparams, g->cb64, g->cb32, g->dx, g->dy, g->ddx, g->dxnew, g->dyhat,
-                    g->ddxnew, g->dTy, g->dUty, g->dTyhat, g->dloss, g->dgrad, g->dscratch, g->dwork, g->dpolar, g->dfallback};
+                    g->ddxnew, g->dTy, g->dUty, g->dTyhat, g->dloss, g->dgrad, g->dscratch, g->dwork, g->dpolar, g->dfallback, g->dwin};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : g->prof_ev) (void)hipEventDestroy(e);
@@ -269,13 +273,13 @@ static double do_lik(moihgp_gp* g, const double* x, const double* y, const doubl
     return loss;
 }
 
-// U = polar(Uparam) (moihgp.h:433-447).  Large matrices: Newton-Schulz on the device (polar.hip); small ones: the
-// host Jacobi routine above, whose microseconds beat a dozen kernel launches.  MOIHGP_POLAR=device|host forces one.
+// U = polar(Uparam) (moihgp.h:433-447).  Newton-Schulz on the device (polar.hip) except for tiny matrices (M L^2 <= 2e4,
+// e.g. the 8x4 demo of example.py), where the host Jacobi routine above costs microseconds against a dozen launches.  MOIHGP_POLAR=device|host forces one.
 static bool compute_polar(moihgp_gp* g, const double* Uparam);
 static bool compute_polar_fwd(moihgp_gp* g, const double* Uparam) { return compute_polar(g, Uparam); }
 static bool compute_polar(moihgp_gp* g, const double* Uparam) {
     const size_t M = g->M, L = g->L;
-    bool on_device = (double)M * (double)L * (double)L > 2.0e7;
+    bool on_device = (double)M * (double)L * (double)L > 2.0e4;   // measured: 256x256 host Jacobi 384 ms vs 1024x1024 device 3.7 ms
     if (const char* e = std::getenv("MOIHGP_POLAR")) on_device = (e[0] == 'd');
     if (!on_device) return polar_factor(M, L, Uparam, g->U.data());
     if (!g->dpolar) g->dpolar = dev_alloc<double>(M * L + 2 * L * L + 8);
@@ -481,6 +485,46 @@ int moihgp_unproject_stream(moihgp_gp* gp, int dtype, const void* Tyhat, size_t 
     if (!gp || gp->latents_only) { set_last_error("unproject_stream needs a full MOIHGP object"); return 1; }
     if (ld < T) { set_last_error("ld < T"); return 1; }
     return launch_unproject_stream(dtype, Tyhat, T, ld, gp->M, gp->L, gp->dU, gp->dS, Yhat, (hipStream_t)stream);
+}
+
+int moihgp_window_set(moihgp_gp* gp, const double* Y, size_t W) {
+    if (!gp || gp->latents_only) { set_last_error("window_set needs a full MOIHGP object"); return 1; }
+    if (!Y || W == 0) { set_last_error("window_set: empty window"); return 1; }
+    const size_t M = gp->M, L = gp->L, d = gp->d, P = gp->P, ldw = (W + 1) / 2 * 2;
+    for (size_t i = 0; i < W * M; i++)
+        if (Y[i] != Y[i]) { set_last_error("window_set: missing outputs (NaN) are not supported by the batched objective; use the per-tick ABI"); return 3; }
+    const size_t need = 2 * W * M + 3 * L * ldw + W + 2 * L + L * P + L * d + L * P * d + 16;
+    if (gp->win_cap < need) {
+        if (gp->dwin) MOIHGP_HIP_FATAL(hipFree(gp->dwin));
+        gp->dwin = dev_alloc<double>(need);
+        gp->win_cap = need;
+    }
+    double* p = gp->dwin;
+    WindowBufs& w = gp->win;
+    w.W = W; w.ldw = ldw;
+    w.Y = p; p += W * M;  w.UU = p; p += W * M;
+    w.Ty = p; p += L * ldw;  w.hx = p; p += L * ldw;  w.Z = p; p += L * ldw;
+    w.rt = p; p += W;  w.spu = p; p += L;  w.nll = p; p += L;  w.gl = p; p += L * P;
+    w.x = p; p += L * d;  w.dx = p; p += L * P * d;
+    MOIHGP_HIP_FATAL(hipMemcpyAsync(w.Y, Y, sizeof(double) * W * M, hipMemcpyHostToDevice, gp->stream));
+    MOIHGP_HIP_FATAL(hipStreamSynchronize(gp->stream));
+    return 0;
+}
+
+int moihgp_window_eval(moihgp_gp* gp, const double* x, const double* dx, double* loss, double* grad, double* xnew, double* dxnew) {
+    if (!gp || gp->latents_only || gp->win.W == 0) { set_last_error("window_eval: call moihgp_window_set first"); return 1; }
+    if (!x || !dx || !loss || !grad) { set_last_error("window_eval: null argument"); return 1; }
+    const size_t L = gp->L, d = gp->d, P = gp->P;
+    WindowBufs& w = gp->win;
+    MOIHGP_HIP_FATAL(hipMemcpyAsync(w.x, x, sizeof(double) * L * d, hipMemcpyHostToDevice, gp->stream));
+    MOIHGP_HIP_FATAL(hipMemcpyAsync(w.dx, dx, sizeof(double) * L * P * d, hipMemcpyHostToDevice, gp->stream));
+    if (int rc = launch_window_objective(gp->tick(), gp->cb64, gp->cb32, w, gp->dfallback, gp->dloss, gp->dgrad, gp->stream)) return rc;
+    MOIHGP_HIP_FATAL(hipMemcpyAsync(loss, gp->dloss, sizeof(double), hipMemcpyDeviceToHost, gp->stream));
+    MOIHGP_HIP_FATAL(hipMemcpyAsync(grad, gp->dgrad, sizeof(double) * gp->num_param, hipMemcpyDeviceToHost, gp->stream));
+    if (xnew) MOIHGP_HIP_FATAL(hipMemcpyAsync(xnew, w.x, sizeof(double) * L * d, hipMemcpyDeviceToHost, gp->stream));
+    if (dxnew) MOIHGP_HIP_FATAL(hipMemcpyAsync(dxnew, w.dx, sizeof(double) * L * P * d, hipMemcpyDeviceToHost, gp->stream));
+    MOIHGP_HIP_FATAL(hipStreamSynchronize(gp->stream));
+    return 0;
 }
 
 int moihgp_stream_sync(void* stream) {

@@ -68,7 +68,8 @@ int launch_filter_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, 
 void filter_split_plan(int dtype, size_t T, size_t L, int* nsplit, size_t* Tslice);
 int launch_grad_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, size_t L,
                        const double* cb64, const float* cb32, void* x, void* dx, void* yhat,
-                       double* nll, double* grad, int* fallback /* int[L] scratch */, hipStream_t stream);
+                       double* nll, double* grad, int* fallback /* int[L] scratch */, hipStream_t stream,
+                       int out_mode = 1 /* 1: yhat holds filtered means, 2: predicted means HA x_t */);
 
 // tick.hip: one-tick kernels behind the reference ABI (all fp64, device pointers).
 struct TickArgs {
@@ -93,6 +94,8 @@ int launch_project_stream(int dtype, const void* Y, size_t T, size_t M, size_t L
                           void* Ty, size_t ld, hipStream_t s);
 int launch_unproject_stream(int dtype, const void* Tyhat, size_t T, size_t ld, size_t M, size_t L, const double* U,
                             const double* S, void* Yhat, hipStream_t s);
+// gradU[r][c] = sum_t Y[t][r] Z[c][t]   (Y tick-major [W][M], Z series-major [L][ldz])
+int launch_ugrad_gemm(const double* Y, size_t W, size_t M, const double* Z, size_t ldz, size_t L, double* gradU, hipStream_t s);
 int launch_gram(const double* X, size_t M, size_t L, double* G, hipStream_t s);                       // G = X^T X
 int launch_matmul_nn(const double* X, size_t M, size_t L, const double* W, double* C, hipStream_t s);   // C = X W
 
@@ -100,5 +103,23 @@ int launch_matmul_nn(const double* X, size_t M, size_t L, const double* W, doubl
 // A_dev is overwritten with the factor; work needs M*L + 2*L*L + 8 doubles.  Returns the iteration count, or
 // -1 if it did not converge (rank-deficient input).
 int polar_factor_device(double* A_dev, size_t M, size_t L, double* work, hipStream_t s);
+
+// window.hip: the learners' windowed objective (moihgp_online.h:61-70) as one device pipeline.
+struct WindowBufs {
+    size_t W, ldw;            // ticks in the window, row stride of the [L][ldw] streams
+    double* Y;                // [W][M]  observations (tick-major)
+    double* Ty;               // [L][ldw] projected stream
+    double* hx;               // [L][ldw] predicted means HA x_t
+    double* Z;                // [L][ldw] pv/sqrt(S) - U^T y / sigma
+    double* UU;               // [W][M]  U U^T y_t
+    double* rt;               // [W]     ||y_t - U U^T y_t||
+    double* spu;              // [L]     sum_t pv * (U^T y)
+    double* nll;              // [L]
+    double* gl;               // [L][P]
+    double* x;                // [L][d]
+    double* dx;               // [L][P][d]
+};
+int launch_window_objective(const TickArgs& a, const double* cb64, const float* cb32, const WindowBufs& w, int* fallback,
+                            double* loss /* device scalar */, double* grad /* device [M*L+L+1+L*P] */, hipStream_t s);
 
 }  // namespace moihgp

@@ -204,6 +204,11 @@ int launch_unproject_stream(int dtype, const void* Tyhat, size_t T, size_t ld, s
     return launch<float, float, double, true, true>(T, M, L, (const float*)Tyhat, ld, U, L, (float*)Yhat, M, nullptr, 0, S, 1, s);
 }
 
+// gradU[r][c] = sum_t Y[t][r] Z[c][t]:  i = r, j = c, k = t;  A = Y (i-contiguous, lda = M);  B = Z (k-contiguous, ldb = ldz)
+int launch_ugrad_gemm(const double* Y, size_t W, size_t M, const double* Z, size_t ldz, size_t L, double* gradU, hipStream_t s) {
+    return launch<double, double, double, true, true>(M, L, W, Y, M, Z, ldz, gradU, L, nullptr, 0, nullptr, 0, s);
+}
+
 // G[a][b] = sum_m X[m][a] X[m][b]  (X is M x L row-major):  A i-contiguous (lda = L), B j-contiguous (ldb = L)
 int launch_gram(const double* X, size_t M, size_t L, double* G, hipStream_t s) {
     return launch<double, double, double, true, false>(L, L, M, X, L, X, L, G, L, nullptr, 0, nullptr, 0, s);

@@ -68,7 +68,9 @@ __device__ inline T tick_mean(const GradConst<T, D>& c, T* xs, T y, T& hx_out) {
     return v;
 }
 
-template <typename T, int D, int CK, bool WRITE>
+// WRITE: 0 no stream output, 1 filtered means yhat_t = x_{t+1}[0] (ihgp.h:51), 2 predicted means hx_t = HA x_t (pre-step; what
+// MOIHGP::negLogLikelihood needs for `pv`, moihgp.h:505-512)
+template <typename T, int D, int CK, int WRITE>
 __global__ void __launch_bounds__(64 * kWavesPerBlock)
 grad_scan_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, const T* __restrict__ cbT,
                  const double* __restrict__ cb64, T* __restrict__ x, T* __restrict__ dx, T* __restrict__ yhat,
@@ -287,7 +289,7 @@ grad_scan_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, con
             for (int p = 0; p < P; p++)
 #pragma unroll
                 for (int i = 0; i < D; i++) dxs[p][i] = (tail && !valid) ? dxs[p][i] : dxn[p][i];
-            y[k] = xs[0];
+            y[k] = (WRITE == 2) ? hx : xs[0];
         }
         if (!tail) nobs += CK;
         sv2 += (double)pv2;
@@ -350,7 +352,7 @@ template <typename T, int D>
 __global__ void __launch_bounds__(64)
 grad_seq_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, const T* __restrict__ cbT,
                 const double* __restrict__ cb64, T* __restrict__ x, T* __restrict__ dx, T* __restrict__ yhat,
-                double* __restrict__ nll, double* __restrict__ grad, const int* __restrict__ only) {
+                double* __restrict__ nll, double* __restrict__ grad, const int* __restrict__ only, int write_mode) {
     using V = typename VecOf<T>::type;
     using Lay = CB<D>;
     constexpr int EPV = 16 / sizeof(T);
@@ -382,9 +384,9 @@ grad_seq_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
             const T y = yv[e];
             const bool miss = (y != y);
             T xn[D], dxn[P][D];
+            T hx = 0;
+            for (int i = 0; i < D; i++) hx = fma(ha[i], xs[i], hx);
             if (!miss) {
-                T hx = 0;
-                for (int i = 0; i < D; i++) hx = fma(ha[i], xs[i], hx);
                 double v = (double)(y - hx);
                 acc += 0.5 * (v * v / S + logS);                        // ihgp.h:215
                 for (int p = 0; p < P; p++) {
@@ -412,7 +414,7 @@ grad_seq_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
             for (int i = 0; i < D; i++) xs[i] = xn[i];
             for (int p = 0; p < P; p++)
                 for (int i = 0; i < D; i++) dxs[p][i] = dxn[p][i];
-            if (yhat) yhat[l * ld + tb + e] = xn[0];
+            if (yhat) yhat[l * ld + tb + e] = (write_mode == 2) ? hx : xn[0];
         }
     }
     for (int i = 0; i < D; i++) x[l * D + i] = xs[i];
@@ -424,15 +426,17 @@ grad_seq_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
 
 template <typename T, int D, int CK>
 int launch_grad_t(const T* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, const double* cb64, T* x, T* dx, T* yhat,
-                  double* nll, double* grad, int* fallback, hipStream_t stream) {
+                  double* nll, double* grad, int* fallback, int out_mode, hipStream_t stream) {
     dim3 block(64 * kWavesPerBlock), grid((unsigned)((L + kWavesPerBlock - 1) / kWavesPerBlock));
-    if (yhat)
-        hipLaunchKernelGGL((grad_scan_kernel<T, D, CK, true>), grid, block, 0, stream, Ty, Tlen, ld, L, cbT, cb64, x, dx, yhat, nll, grad, fallback);
+    if (yhat && out_mode == 2)
+        hipLaunchKernelGGL((grad_scan_kernel<T, D, CK, 2>), grid, block, 0, stream, Ty, Tlen, ld, L, cbT, cb64, x, dx, yhat, nll, grad, fallback);
+    else if (yhat)
+        hipLaunchKernelGGL((grad_scan_kernel<T, D, CK, 1>), grid, block, 0, stream, Ty, Tlen, ld, L, cbT, cb64, x, dx, yhat, nll, grad, fallback);
     else
-        hipLaunchKernelGGL((grad_scan_kernel<T, D, CK, false>), grid, block, 0, stream, Ty, Tlen, ld, L, cbT, cb64, x, dx, yhat, nll, grad, fallback);
+        hipLaunchKernelGGL((grad_scan_kernel<T, D, CK, 0>), grid, block, 0, stream, Ty, Tlen, ld, L, cbT, cb64, x, dx, yhat, nll, grad, fallback);
     // latents whose stream holds missing ticks are redone sequentially (their x / dx were left untouched)
     hipLaunchKernelGGL((grad_seq_kernel<T, D>), dim3((unsigned)((L + 63) / 64)), dim3(64), 0, stream, Ty, Tlen, ld, L, cbT, cb64, x, dx, yhat, nll,
-                       grad, (const int*)fallback);
+                       grad, (const int*)fallback, out_mode);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_last_error("grad kernels launch: %s", hipGetErrorString(e)); return 2; }
     return 0;
@@ -443,13 +447,13 @@ int launch_grad_t(const T* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, c
 // fallback: device int[L] scratch (flags of latents with missing ticks)
 int launch_grad_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* cb64,
                        const float* cb32, void* x, void* dx, void* yhat, double* nll, double* grad, int* fallback,
-                       hipStream_t stream) {
+                       hipStream_t stream, int out_mode) {
     if (L == 0) return 0;
     // short windows (the online learner's W <= 128 ticks, moihgp_online.h:61-70) use 16-byte chunks so that a
     // window still spreads over the lanes of the wave; long streams use 64-byte chunks
     const bool shortw = T <= (dtype == 0 ? 256 : 512);
 #define MOIHGP_GRAD_CASE(TT, DD, CKK, CB) \
-    return launch_grad_t<TT, DD, CKK>((const TT*)Ty, T, ld, L, CB, cb64, (TT*)x, (TT*)dx, (TT*)yhat, nll, grad, fallback, stream)
+    return launch_grad_t<TT, DD, CKK>((const TT*)Ty, T, ld, L, CB, cb64, (TT*)x, (TT*)dx, (TT*)yhat, nll, grad, fallback, out_mode, stream)
     if (dtype == 0) {
         if (d == 2) { if (shortw) MOIHGP_GRAD_CASE(double, 2, 2, cb64); MOIHGP_GRAD_CASE(double, 2, 8, cb64); }
         if (shortw) MOIHGP_GRAD_CASE(double, 3, 2, cb64);

@@ -122,6 +122,25 @@ class MOIHGP(object):
         res = self.__lik1(self.__obj, self.__x_p, self.__y_p, self.__dx_p, self.__grad_p)
         return np.float64(res), self.__grad.astype(np.float64)
 
+    def window_objective(self, Y, x, dx, set_window=True):
+        """The learners' windowed objective in ONE call (include/moihgp.h `moihgp_window_*`): equivalent to
+        `for y in Y: (xn, _, dxn) = step(x, y, dx); l, g = negLogLikelihood(x, y, dx); loss += l; grad += g; x, dx = xn, dxn`
+        (online_learning.py:83-89).  Returns (loss, grad, xnew, dxnew).  Raises if Y holds NaN."""
+        lib = self.__lib
+        if set_window:
+            Yc = np.ascontiguousarray(Y, dtype=np.float64).reshape(-1, self.num_output)
+            rc = lib.moihgp_window_set(self.__obj, Yc.ctypes.data_as(c_double_p), Yc.shape[0])
+            if rc != 0:
+                raise MoihgpError(last_error(lib) or "moihgp_window_set failed")
+        xc = np.ascontiguousarray(x, dtype=np.float64).reshape(self.num_latent, self.igp_dim)
+        dxc = np.ascontiguousarray(dx, dtype=np.float64).reshape(self.num_latent, self.num_igp_param, self.igp_dim)
+        loss = np.zeros(1); grad = np.zeros(self.num_param); xn = np.zeros_like(xc); dxn = np.zeros_like(dxc)
+        rc = lib.moihgp_window_eval(self.__obj, xc.ctypes.data_as(c_double_p), dxc.ctypes.data_as(c_double_p), loss.ctypes.data_as(c_double_p),
+                                    grad.ctypes.data_as(c_double_p), xn.ctypes.data_as(c_double_p), dxn.ctypes.data_as(c_double_p))
+        if rc != 0:
+            raise MoihgpError(last_error(lib) or "moihgp_window_eval failed")
+        return float(loss[0]), grad, xn, dxn
+
     @property
     def num_output(self):
         return self.__num_output

@@ -392,3 +392,39 @@ def test_gradstream_vs_oracle(env, dtype, kern, L, T, nan):
     r2 = bank.grad(to_dev(Ty, dtype), T=T, x=torch.from_numpy(x0).to(dtype).cuda(), dx=torch.from_numpy(dx0).to(dtype).cuda(), want_yhat=False)
     torch.cuda.synchronize()
     assert torch.equal(r2["grad"], r["grad"]) and torch.equal(r2["nll"], r["nll"])
+
+
+# ------------------------------------------------------------------------------------------ windowed objective in one call
+@pytest.mark.parametrize("kern,M,L,W", [("Matern32", 6, 3, 5), ("Matern52", 8, 8, 16), ("Matern52", 70, 33, 128), ("Matern32", 300, 200, 40)])
+def test_window_objective_vs_oracle_loop(env, kern, M, L, W):
+    """moihgp_window_set/eval == the learners' loop (moihgp_online.h:61-70): step with sensitivities, NLL + gradient on the
+    pre-step state, summed over the window; checked against the oracle's per-tick calls and against our own per-tick ABI."""
+    rng = np.random.default_rng(M + 3 * L + W)
+    gp = env["MOIHGP"](0.1, M, L, kernel=KMAP[kern])
+    ref = env["cref"].GP(0.1, M, L, kern); ref.set_literal_ugrad(0)
+    d, P = gp.igp_dim, 3
+    params = np.concatenate([(np.eye(M, L) + 0.2 * rng.standard_normal((M, L))).ravel(), rng.uniform(0.5, 2, L), [0.04], synth_params(L, rng).ravel()])
+    gp.update(params); ref.update(params)
+    Y = rng.standard_normal((W, M)) * 0.5
+    x0 = 0.2 * rng.standard_normal((L, d)); dx0 = 0.05 * rng.standard_normal((L, P, d))
+    loss, grad, xT, dxT = gp.window_objective(Y, x0, dx0)
+    x, dx, lref, gref = x0, dx0, 0.0, np.zeros(gp.num_param)
+    for t in range(W):
+        l1, g1 = ref.negLogLikelihood(x, Y[t], dx)
+        xn, _, dxn = ref.step(x, Y[t], dx)
+        lref += l1; gref += g1; x, dx = xn, dxn
+    assert abs(loss - lref) < 1e-9 * abs(lref)
+    assert rel_err(grad, gref) < 1e-8
+    assert rel_err(xT, x) < 1e-9 and rel_err(dxT, dx) < 1e-8
+    # the same through our own per-tick ABI for the first ticks (consistency of the two product paths)
+    x, dx, lp = x0, dx0, 0.0
+    for t in range(min(W, 4)):
+        l1, _ = gp.negLogLikelihood(x, Y[t], dx)
+        xn, _, dxn = gp.step(x, Y[t], dx)
+        lp += l1; x, dx = xn, dxn
+    l4, _, x4, _ = gp.window_objective(Y[:min(W, 4)], x0, dx0)
+    assert abs(l4 - lp) < 1e-10 * abs(lp) and rel_err(x4, x) < 1e-10
+    from multioutputihgp_amd import MoihgpError
+    Yn = Y.copy(); Yn[0, 0] = np.nan
+    with pytest.raises(MoihgpError):
+        gp.window_objective(Yn, x0, dx0)
