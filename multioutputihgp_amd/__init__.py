@@ -10,6 +10,7 @@ There is no CPU fallback: importing works anywhere, constructing an object witho
 usable GPU raises.
 """
 from .pywrapper import MOIHGP
+from .online_learning import MOIHGPOnlineLearning
 from ._lib import load_library, library_path, MoihgpError
 
-__all__ = ["MOIHGP", "load_library", "library_path", "MoihgpError"]
+__all__ = ["MOIHGP", "MOIHGPOnlineLearning", "load_library", "library_path", "MoihgpError"]
