@@ -110,7 +110,7 @@ struct moihgp_gp {
     double sigma = 1e-2;
     // device state
     hipStream_t stream = nullptr;
-    double *dU = nullptr, *dS = nullptr, *dsigma = nullptr, *dparams = nullptr, *cb64 = nullptr;
+    double *dU = nullptr, *dS = nullptr, *dsqrtS = nullptr, *dinvsqrtS = nullptr, *dsigma = nullptr, *dparams = nullptr, *cb64 = nullptr;
     float* cb32 = nullptr;
     // per-tick staging
     double *dx = nullptr, *dy = nullptr, *ddx = nullptr, *dxnew = nullptr, *dyhat = nullptr, *ddxnew = nullptr;
@@ -126,12 +126,12 @@ struct moihgp_gp {
     std::vector<hipEvent_t> prof_ev;
     int prof_n = 0;
 
-    TickArgs tick() const { return TickArgs{d, M, L, cb64, dU, dS, dsigma}; }
+    TickArgs tick() const { return TickArgs{d, M, L, cb64, dU, dS, dsqrtS, dinvsqrtS, dsigma}; }
 };
 
 static void gp_free(moihgp_gp* g) {
     if (!g) return;
-    void* ptrs[] = {g->dU, g->dS, g->dsigma, g->dparams, g->cb64, g->cb32, g->dx, g->dy, g->ddx, g->dxnew, g->dyhat,
+    void* ptrs[] = {g->dU, g->dS, g->dsqrtS, g->dinvsqrtS, g->dsigma, g->dparams, g->cb64, g->cb32, g->dx, g->dy, g->ddx, g->dxnew, g->dyhat,
                     g->ddxnew, g->dTy, g->dUty, g->dTyhat, g->dloss, g->dgrad, g->dscratch, g->dwork, g->dpolar, g->dfallback, g->dwin};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -144,6 +144,7 @@ static void upload_mixing(moihgp_gp* g) {
     if (g->latents_only) return;
     MOIHGP_HIP_FATAL(hipMemcpyAsync(g->dU, g->U.data(), sizeof(double) * g->M * g->L, hipMemcpyHostToDevice, g->stream));
     MOIHGP_HIP_FATAL(hipMemcpyAsync(g->dS, g->S.data(), sizeof(double) * g->L, hipMemcpyHostToDevice, g->stream));
+    launch_scales(g->dS, g->L, g->dsqrtS, g->dinvsqrtS, g->stream);
     MOIHGP_HIP_FATAL(hipMemcpyAsync(g->dsigma, &g->sigma, sizeof(double), hipMemcpyHostToDevice, g->stream));
 }
 
@@ -205,6 +206,8 @@ static moihgp_gp* gp_create(int kernel, double dt, size_t M, size_t L, bool late
         g->dU = dev_alloc<double>(M * L);
         draw_U(g, 0, false);
         g->dS = dev_alloc<double>(L);
+        g->dsqrtS = dev_alloc<double>(L);
+        g->dinvsqrtS = dev_alloc<double>(L);
         g->dsigma = dev_alloc<double>(1);
         g->dx = dev_alloc<double>(L * g->d);
         g->dxnew = dev_alloc<double>(L * g->d);
@@ -282,7 +285,7 @@ static bool compute_polar(moihgp_gp* g, const double* Uparam) {
     bool on_device = (double)M * (double)L * (double)L > 2.0e4;   // measured: 256x256 host Jacobi 384 ms vs 1024x1024 device 3.7 ms
     if (const char* e = std::getenv("MOIHGP_POLAR")) on_device = (e[0] == 'd');
     if (!on_device) return polar_factor(M, L, Uparam, g->U.data());
-    if (!g->dpolar) g->dpolar = dev_alloc<double>(M * L + 2 * L * L + 8);
+    if (!g->dpolar) g->dpolar = dev_alloc<double>(M * L + 2 * L * L + 8 + 3 * L);
     MOIHGP_HIP_FATAL(hipMemcpyAsync(g->dU, Uparam, sizeof(double) * M * L, hipMemcpyHostToDevice, g->stream));
     const int its = polar_factor_device(g->dU, M, L, g->dpolar, g->stream);
     if (its < 0) return false;
@@ -478,13 +481,13 @@ int moihgp_grad_stream(moihgp_gp* gp, int dtype, const void* Ty, size_t T, size_
 int moihgp_project_stream(moihgp_gp* gp, int dtype, const void* Y, size_t T, void* Ty, size_t ld, void* stream) {
     if (!gp || gp->latents_only) { set_last_error("project_stream needs a full MOIHGP object"); return 1; }
     if (ld < T) { set_last_error("ld < T"); return 1; }
-    return launch_project_stream(dtype, Y, T, gp->M, gp->L, gp->dU, gp->dS, Ty, ld, (hipStream_t)stream);
+    return launch_project_stream(dtype, Y, T, gp->M, gp->L, gp->dU, gp->dinvsqrtS, Ty, ld, (hipStream_t)stream);
 }
 
 int moihgp_unproject_stream(moihgp_gp* gp, int dtype, const void* Tyhat, size_t T, size_t ld, void* Yhat, void* stream) {
     if (!gp || gp->latents_only) { set_last_error("unproject_stream needs a full MOIHGP object"); return 1; }
     if (ld < T) { set_last_error("ld < T"); return 1; }
-    return launch_unproject_stream(dtype, Tyhat, T, ld, gp->M, gp->L, gp->dU, gp->dS, Yhat, (hipStream_t)stream);
+    return launch_unproject_stream(dtype, Tyhat, T, ld, gp->M, gp->L, gp->dU, gp->dsqrtS, Yhat, (hipStream_t)stream);
 }
 
 int moihgp_window_set(moihgp_gp* gp, const double* Y, size_t W) {

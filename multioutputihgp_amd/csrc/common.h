@@ -77,6 +77,8 @@ struct TickArgs {
     const double* cb64;      // [L] constant blocks
     const double* U;         // [M][L]
     const double* S;         // [L]
+    const double* sqrtS;     // [L] S^1/2
+    const double* invsqrtS;  // [L] S^-1/2
     const double* sigma;     // [1]
 };
 void launch_project_tick(const TickArgs& a, const double* y, double* Ty, double* Uty, int* n_nan, hipStream_t s);
@@ -90,17 +92,19 @@ void launch_nll_tick(const TickArgs& a, const double* x, const double* y, const 
                      const double* dx, double* loss, double* grad, double* scratch, hipStream_t s);
 
 // gemm_mfma.hip: MFMA GEMMs (whole-stream projection, Gram / update products of the polar factor).
-int launch_project_stream(int dtype, const void* Y, size_t T, size_t M, size_t L, const double* U, const double* S,
+// invsqrtS / sqrtS: the device vectors S^-1/2 and S^1/2 (launch_scales)
+void launch_scales(const double* S, size_t L, double* sqrtS, double* invsqrtS, hipStream_t s);
+int launch_project_stream(int dtype, const void* Y, size_t T, size_t M, size_t L, const double* U, const double* invsqrtS,
                           void* Ty, size_t ld, hipStream_t s);
 int launch_unproject_stream(int dtype, const void* Tyhat, size_t T, size_t ld, size_t M, size_t L, const double* U,
-                            const double* S, void* Yhat, hipStream_t s);
+                            const double* sqrtS, void* Yhat, hipStream_t s);
 // gradU[r][c] = sum_t Y[t][r] Z[c][t]   (Y tick-major [W][M], Z series-major [L][ldz])
 int launch_ugrad_gemm(const double* Y, size_t W, size_t M, const double* Z, size_t ldz, size_t L, double* gradU, hipStream_t s);
 int launch_gram(const double* X, size_t M, size_t L, double* G, hipStream_t s);                       // G = X^T X
 int launch_matmul_nn(const double* X, size_t M, size_t L, const double* W, double* C, hipStream_t s);   // C = X W
 
 // polar.hip: polar factor of an M x L matrix on the device (Newton-Schulz), moihgp.h:433-447.
-// A_dev is overwritten with the factor; work needs M*L + 2*L*L + 8 doubles.  Returns the iteration count, or
+// A_dev is overwritten with the factor; work needs M*L + 2*L*L + 8 + 3*L doubles.  Returns the iteration count, or
 // -1 if it did not converge (rank-deficient input).
 int polar_factor_device(double* A_dev, size_t M, size_t L, double* work, hipStream_t s);
 

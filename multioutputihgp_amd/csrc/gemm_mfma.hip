@@ -42,6 +42,24 @@ template <> struct Acc<float> {
     static __device__ inline int row(int lane, int r) { return (lane >> 4) * 4 + r; }
 };
 
+// 8 contiguous source elements (16-byte aligned) -> 8 compute-type registers
+template <typename TS, typename TC> __device__ inline void load8(const TS* p, TC* out);
+template <> __device__ inline void load8<double, double>(const double* p, double* o) {
+    const double2* q = reinterpret_cast<const double2*>(p);
+#pragma unroll
+    for (int v = 0; v < 4; v++) { double2 t = q[v]; o[2 * v] = t.x; o[2 * v + 1] = t.y; }
+}
+template <> __device__ inline void load8<double, float>(const double* p, float* o) {
+    const double2* q = reinterpret_cast<const double2*>(p);
+#pragma unroll
+    for (int v = 0; v < 4; v++) { double2 t = q[v]; o[2 * v] = (float)t.x; o[2 * v + 1] = (float)t.y; }
+}
+template <> __device__ inline void load8<float, float>(const float* p, float* o) {
+    const float4* q = reinterpret_cast<const float4*>(p);
+#pragma unroll
+    for (int v = 0; v < 2; v++) { float4 t = q[v]; o[4 * v] = t.x; o[4 * v + 1] = t.y; o[4 * v + 2] = t.z; o[4 * v + 3] = t.w; }
+}
+
 template <typename TC, typename TA, typename TB, bool A_ICONTIG, bool B_KCONTIG>
 __global__ void __launch_bounds__(256)
 gemm_mfma_kernel(size_t Mi, size_t Nj, size_t Kk, const TA* __restrict__ A, size_t lda, const TB* __restrict__ B, size_t ldb,
@@ -75,45 +93,67 @@ gemm_mfma_kernel(size_t Mi, size_t Nj, size_t Kk, const TA* __restrict__ A, size
 #pragma unroll
             for (int r = 0; r < 4; r++) acc[a][b][r] = 0;
 
-    // register staging of one 128 x 16 tile of each operand: 8 elements per thread each
+    // register staging of one 128 x 16 tile of each operand: 8 elements per thread each, contiguous in memory
+    // (along i / j for the *-contiguous layouts, along k otherwise).  Interior tiles take 16-byte vector loads.
     TC ra[8], rb[8];
+    const bool a_vec = ((uintptr_t)A % 16 == 0) && (lda % (16 / sizeof(TA)) == 0);
+    const bool b_vec = ((uintptr_t)B % 16 == 0) && (ldb % (16 / sizeof(TB)) == 0);
+    const bool i_full = i0 + BM <= Mi, j_full = j0 + BN <= Nj;
     auto fetch = [&](size_t k0) {
-        if (A_ICONTIG) {      // rows of As are contiguous in memory: thread -> (k = tid / 16 .. , 8 consecutive i)
+        const bool k_full = k0 + BK <= Kk;
+        if (A_ICONTIG) {      // rows of As are contiguous in memory: thread -> (k = tid / 16, 8 consecutive i)
             const int kk = tid >> 4, ii = (tid & 15) * 8;
             const size_t gk = k0 + kk;
+            if (a_vec && i_full && k_full) load8<TA, TC>(A + gk * lda + i0 + ii, ra);
+            else {
 #pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const size_t gi = i0 + ii + e;
-                ra[e] = (gk < Kk && gi < Mi) ? (TC)A[gk * lda + gi] : TC(0);
+                for (int e = 0; e < 8; e++) {
+                    const size_t gi = i0 + ii + e;
+                    ra[e] = (gk < Kk && gi < Mi) ? (TC)A[gk * lda + gi] : TC(0);
+                }
             }
         } else {              // A(i,k) = A[i*lda + k]: thread -> (i = tid / 2, 8 consecutive k)
             const int ii = tid >> 1, kk = (tid & 1) * 8;
             const size_t gi = i0 + ii;
+            if (a_vec && i_full && k_full) load8<TA, TC>(A + gi * lda + k0 + kk, ra);
+            else {
 #pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const size_t gk = k0 + kk + e;
-                ra[e] = (gk < Kk && gi < Mi) ? (TC)A[gi * lda + gk] : TC(0);
+                for (int e = 0; e < 8; e++) {
+                    const size_t gk = k0 + kk + e;
+                    ra[e] = (gk < Kk && gi < Mi) ? (TC)A[gi * lda + gk] : TC(0);
+                }
             }
         }
         if (B_KCONTIG) {      // B(k,j) = B[j*ldb + k]: thread -> (j = tid / 2, 8 consecutive k)
             const int jj = tid >> 1, kk = (tid & 1) * 8;
             const size_t gj = j0 + jj;
+            if (b_vec && j_full && k_full) load8<TB, TC>(B + gj * ldb + k0 + kk, rb);
+            else {
 #pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const size_t gk = k0 + kk + e;
-                TC v = (gk < Kk && gj < Nj) ? (TC)B[gj * ldb + gk] : TC(0);
-                if (ks_mode == 1 && gk < Kk) v *= (TC)sqrt(ks[gk]);
-                rb[e] = v;
+                for (int e = 0; e < 8; e++) {
+                    const size_t gk = k0 + kk + e;
+                    rb[e] = (gk < Kk && gj < Nj) ? (TC)B[gj * ldb + gk] : TC(0);
+                }
+            }
+            if (ks_mode == 1) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) { const size_t gk = k0 + kk + e; if (gk < Kk) rb[e] *= (TC)ks[gk]; }
             }
         } else {              // B(k,j) = B[k*ldb + j]: thread -> (k = tid / 16, 8 consecutive j)
             const int kk = tid >> 4, jj = (tid & 15) * 8;
             const size_t gk = k0 + kk;
-            TC sc = TC(1);
-            if (ks_mode == 1 && gk < Kk) sc = (TC)sqrt(ks[gk]);
+            if (b_vec && j_full && k_full) load8<TB, TC>(B + gk * ldb + j0 + jj, rb);
+            else {
 #pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const size_t gj = j0 + jj + e;
-                rb[e] = (gk < Kk && gj < Nj) ? (TC)B[gk * ldb + gj] * sc : TC(0);
+                for (int e = 0; e < 8; e++) {
+                    const size_t gj = j0 + jj + e;
+                    rb[e] = (gk < Kk && gj < Nj) ? (TC)B[gk * ldb + gj] : TC(0);
+                }
+            }
+            if (ks_mode == 1 && gk < Kk) {
+                const TC sc = (TC)ks[gk];
+#pragma unroll
+                for (int e = 0; e < 8; e++) rb[e] *= sc;
             }
         }
     };
@@ -167,7 +207,7 @@ gemm_mfma_kernel(size_t Mi, size_t Nj, size_t Kk, const TA* __restrict__ A, size
             const size_t gi = i0 + wm * 64 + a * 16 + Acc<TC>::row(lane, r);
             if (gi >= Mi) continue;
             TC scale = TC(1);
-            if (rs_mode == 1) scale = (TC)(1.0 / sqrt(rs[gi]));
+            if (rs_mode == 1) scale = (TC)rs[gi];
 #pragma unroll
             for (int b = 0; b < 4; b++) {
                 const size_t gj = j0 + wn * 64 + b * 16 + (lane & 15);
@@ -190,15 +230,25 @@ int launch(size_t Mi, size_t Nj, size_t Kk, const TA* A, size_t lda, const TB* B
 
 }  // namespace
 
+__global__ void scales_kernel(const double* __restrict__ S, size_t L, double* __restrict__ sqrtS, double* __restrict__ invsqrtS) {
+    size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= L) return;
+    const double q = sqrt(S[l]);
+    sqrtS[l] = q;
+    invsqrtS[l] = 1.0 / q;                      // moihgp.h:163 `1 / sqrt(S(idx))`
+}
+void launch_scales(const double* S, size_t L, double* sqrtS, double* invsqrtS, hipStream_t s) {
+    hipLaunchKernelGGL(scales_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, s, S, L, sqrtS, invsqrtS);
+}
 // Ty[l][t] = S_l^-1/2 * sum_m U[m][l] Y[t][m]:  i = l, j = t, k = m;  A = U (i-contiguous, lda = L);  B = Y (k-contiguous, ldb = M)
-int launch_project_stream(int dtype, const void* Y, size_t T, size_t M, size_t L, const double* U, const double* S, void* Ty, size_t ld,
+int launch_project_stream(int dtype, const void* Y, size_t T, size_t M, size_t L, const double* U, const double* S /* invsqrtS */, void* Ty, size_t ld,
                           hipStream_t s) {
     if (dtype == 0) return launch<double, double, double, true, true>(L, T, M, U, L, (const double*)Y, M, (double*)Ty, ld, S, 1, nullptr, 0, s);
     return launch<float, double, float, true, true>(L, T, M, U, L, (const float*)Y, M, (float*)Ty, ld, S, 1, nullptr, 0, s);
 }
 
 // Yhat[t][m] = sum_l Tyhat[l][t] * sqrt(S_l) * U[m][l]:  i = t, j = m, k = l;  A = Tyhat (i-contiguous, lda = ld);  B = U (k-contiguous, ldb = L)
-int launch_unproject_stream(int dtype, const void* Tyhat, size_t T, size_t ld, size_t M, size_t L, const double* U, const double* S,
+int launch_unproject_stream(int dtype, const void* Tyhat, size_t T, size_t ld, size_t M, size_t L, const double* U, const double* S /* sqrtS */,
                             void* Yhat, hipStream_t s) {
     if (dtype == 0) return launch<double, double, double, true, true>(T, M, L, (const double*)Tyhat, ld, U, L, (double*)Yhat, M, nullptr, 0, S, 1, s);
     return launch<float, float, double, true, true>(T, M, L, (const float*)Tyhat, ld, U, L, (float*)Yhat, M, nullptr, 0, S, 1, s);

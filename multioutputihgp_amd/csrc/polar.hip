@@ -10,22 +10,27 @@
 namespace moihgp {
 namespace {
 
-// out[0] = max_i sum_j |G_ij| ; out[1] = trace(G) ; out[2] = max_ij |G_ij - delta_ij|     (one workgroup)
-__global__ void __launch_bounds__(256) gram_stats_kernel(const double* __restrict__ G, size_t L, double* __restrict__ out) {
+// per row i of G (one wave per row, coalesced): rows[3i..] = { sum_j |G_ij|, G_ii, max_j |G_ij - delta_ij| }
+__global__ void __launch_bounds__(256) gram_row_stats_kernel(const double* __restrict__ G, size_t L, double* __restrict__ rows) {
+    const int lane = threadIdx.x & 63;
+    const size_t i = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= L) return;
+    double s = 0.0, dev = 0.0;
+    for (size_t j = lane; j < L; j += 64) {
+        const double g = G[i * L + j];
+        s += fabs(g);
+        dev = fmax(dev, fabs(g - (i == j ? 1.0 : 0.0)));
+    }
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); dev = fmax(dev, __shfl_xor(dev, o)); }
+    if (lane == 0) { rows[3 * i] = s; rows[3 * i + 1] = G[i * L + i]; rows[3 * i + 2] = dev; }
+}
+
+// out[0] = max_i sum_j |G_ij| ; out[1] = trace(G) ; out[2] = max_ij |G_ij - delta_ij|     (one workgroup over the row records)
+__global__ void __launch_bounds__(256) gram_stats_kernel(const double* __restrict__ rows, size_t L, double* __restrict__ out) {
     __shared__ double r0[256], r1[256], r2[256];
     const int tid = threadIdx.x;
     double mx = 0.0, tr = 0.0, dev = 0.0;
-    for (size_t i = tid; i < L; i += 256) {
-        double s = 0.0;
-        for (size_t j = 0; j < L; j++) {
-            const double g = G[i * L + j];
-            s += fabs(g);
-            const double d = fabs(g - (i == j ? 1.0 : 0.0));
-            if (d > dev) dev = d;
-        }
-        if (s > mx) mx = s;
-        tr += G[i * L + i];
-    }
+    for (size_t i = tid; i < L; i += 256) { mx = fmax(mx, rows[3 * i]); tr += rows[3 * i + 1]; dev = fmax(dev, rows[3 * i + 2]); }
     r0[tid] = mx; r1[tid] = tr; r2[tid] = dev;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
@@ -57,10 +62,12 @@ int polar_factor_device(double* X, size_t M, size_t L, double* work, hipStream_t
     double* W = G + L * L;            // L*L
     double* Xn = W + L * L;           // M*L
     double* stats = Xn + M * L;       // 8
+    double* rows = stats + 8;         // 3*L
     double h[3];
     const unsigned nbLL = (unsigned)((L * L + 255) / 256), nbML = (unsigned)((M * L + 255) / 256);
     if (launch_gram(X, M, L, G, s)) return -1;
-    hipLaunchKernelGGL(gram_stats_kernel, dim3(1), dim3(256), 0, s, G, L, stats);
+    hipLaunchKernelGGL(gram_row_stats_kernel, dim3((unsigned)((L + 3) / 4)), dim3(256), 0, s, G, L, rows);
+    hipLaunchKernelGGL(gram_stats_kernel, dim3(1), dim3(256), 0, s, rows, L, stats);
     hipLaunchKernelGGL(scale_kernel, dim3(nbML), dim3(256), 0, s, X, M * L, stats);
     MOIHGP_HIP_FATAL(hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, s));
     MOIHGP_HIP_FATAL(hipStreamSynchronize(s));
@@ -70,7 +77,8 @@ int polar_factor_device(double* X, size_t M, size_t L, double* work, hipStream_t
     double* nxt = Xn;
     for (int it = 1; it <= 200; it++) {
         if (launch_gram(cur, M, L, G, s)) return -1;
-        hipLaunchKernelGGL(gram_stats_kernel, dim3(1), dim3(256), 0, s, G, L, stats);
+        hipLaunchKernelGGL(gram_row_stats_kernel, dim3((unsigned)((L + 3) / 4)), dim3(256), 0, s, G, L, rows);
+        hipLaunchKernelGGL(gram_stats_kernel, dim3(1), dim3(256), 0, s, rows, L, stats);
         MOIHGP_HIP_FATAL(hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, s));
         MOIHGP_HIP_FATAL(hipStreamSynchronize(s));
         const double err = h[2];
