@@ -313,7 +313,7 @@ grad_scan_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, con
             for (int i = 0; i < VPL; i++) {
                 const int q = i * 64 + lane;
                 const size_t tq = tbase + (size_t)q * EPV;
-                if (!tail || tq < Tlen) *reinterpret_cast<V*>(orow + tq) = lds[q + q / VPL];
+                if (!tail || tq < Tlen) nt_store(lds[q + q / VPL], reinterpret_cast<V*>(orow + tq));
             }
         }
         wave_lds_fence();

@@ -16,6 +16,14 @@ template <typename T> __device__ inline typename VecOf<T>::type pack(const T* in
 template <> __device__ inline float4 pack<float>(const float* i) { return make_float4(i[0], i[1], i[2], i[3]); }
 template <> __device__ inline double2 pack<double>(const double* i) { return make_double2(i[0], i[1]); }
 
+// streaming (non-temporal) 16-byte accesses
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+typedef double nt_d2 __attribute__((ext_vector_type(2)));
+__device__ inline float4 nt_load(const float4* p) { nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+__device__ inline double2 nt_load(const double2* p) { nt_d2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_d2*>(p)); return make_double2(v.x, v.y); }
+__device__ inline void nt_store(float4 v, float4* p) { nt_f4 t = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t, reinterpret_cast<nt_f4*>(p)); }
+__device__ inline void nt_store(double2 v, double2* p) { nt_d2 t = {v.x, v.y}; __builtin_nontemporal_store(t, reinterpret_cast<nt_d2*>(p)); }
+
 __device__ inline void wave_lds_fence() {
     // LDS operations of one wave execute in program order; this only stops the compiler from
     // moving LDS accesses across the hand-over between lanes of the same wave.

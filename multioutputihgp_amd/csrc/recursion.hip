@@ -233,7 +233,10 @@ __device__ inline void sweep(const T* __restrict__ row, T* __restrict__ orow, si
     auto load_full = [&](size_t seg) {
         const T* p = row + seg * SEG + (size_t)lane * EPV;
 #pragma unroll
-        for (int i = 0; i < VPL; i++) r[i] = *reinterpret_cast<const V*>(p + (size_t)i * 64 * EPV);
+        for (int i = 0; i < VPL; i++) {
+            if (DBG & 4) r[i] = nt_load(reinterpret_cast<const V*>(p + (size_t)i * 64 * EPV));
+            else r[i] = *reinterpret_cast<const V*>(p + (size_t)i * 64 * EPV);
+        }
     };
     auto load_tail = [&](size_t seg) {
         const size_t base = seg * SEG;
@@ -271,7 +274,7 @@ __device__ inline void sweep(const T* __restrict__ row, T* __restrict__ orow, si
             }
             // prefetch the next segment: in flight during the arithmetic below
             if (seg + 1 < nfull) load_full(seg + 1); else if (seg + 1 < nseg) load_tail(seg + 1);
-            if (DBG == 1) {                      // tuning probe: staging path only, no arithmetic
+            if (DBG & 1) {                       // tuning probe: staging path only, no arithmetic
                 done = true;
 #pragma unroll
                 for (int k = 0; k < CK; k++) y[k] = y[k] + xin[0];
@@ -307,13 +310,16 @@ __device__ inline void sweep(const T* __restrict__ row, T* __restrict__ orow, si
 #pragma unroll
                 for (int i = 0; i < VPL; i++) {
                     int q = i * 64 + lane;
-                    *reinterpret_cast<V*>(po + (size_t)i * 64 * EPV) = lds[q + q / VPL];
+                    // the filtered means are written once and not re-read by this kernel: stream them past the caches so that
+                    // the input stream keeps its place in L2 / Infinity Cache (DBG bit 2: plain stores, for A/B)
+                    if (DBG & 2) *reinterpret_cast<V*>(po + (size_t)i * 64 * EPV) = lds[q + q / VPL];
+                    else nt_store(lds[q + q / VPL], reinterpret_cast<V*>(po + (size_t)i * 64 * EPV));
                 }
             } else {
 #pragma unroll
                 for (int i = 0; i < VPL; i++) {
                     int q = i * 64 + lane;
-                    if (tbase + (size_t)q * EPV < Tlen) *reinterpret_cast<V*>(po + (size_t)i * 64 * EPV) = lds[q + q / VPL];
+                    if (tbase + (size_t)q * EPV < Tlen) nt_store(lds[q + q / VPL], reinterpret_cast<V*>(po + (size_t)i * 64 * EPV));
                 }
             }
         }
@@ -518,6 +524,14 @@ int launch_filter_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, 
         MOIHGP_FILTER_CASE(double, 3, kChunk64, 1, cb64);
     }
     if (d == 2) MOIHGP_FILTER_CASE(float, 2, kChunk32, 4, cb32);
+    if (variant == 2 || variant == 4 || variant == 6) {   // tuning probes: plain stores (2), nontemporal loads (4), both (6)
+        dim3 block(64 * kWavesPerBlock), grid((unsigned)((L + kWavesPerBlock - 1) / kWavesPerBlock));
+        const size_t sm = (size_t)kWavesPerBlock * 64 * 5 * 16;
+        if (variant == 2) hipExtLaunchKernelGGL((filter_scan_kernel<float, 3, kChunk32, true, true, 4, false, 2>), grid, block, sm, stream, ev0, ev1, 0, (const float*)Ty, T, ld, L, cb32, cb64, (float*)x, (float*)yhat, nll, 1, T);
+        else if (variant == 4) hipExtLaunchKernelGGL((filter_scan_kernel<float, 3, kChunk32, true, true, 4, false, 4>), grid, block, sm, stream, ev0, ev1, 0, (const float*)Ty, T, ld, L, cb32, cb64, (float*)x, (float*)yhat, nll, 1, T);
+        else hipExtLaunchKernelGGL((filter_scan_kernel<float, 3, kChunk32, true, true, 4, false, 6>), grid, block, sm, stream, ev0, ev1, 0, (const float*)Ty, T, ld, L, cb32, cb64, (float*)x, (float*)yhat, nll, 1, T);
+        return 0;
+    }
     if (variant == 9) {   // tuning probe (staging only)
         dim3 block(64 * kWavesPerBlock), grid((unsigned)((L + kWavesPerBlock - 1) / kWavesPerBlock));
         hipExtLaunchKernelGGL((filter_scan_kernel<float, 3, kChunk32, true, true, 1, false, 1>), grid, block, (size_t)kWavesPerBlock * 64 * 5 * 16, stream, ev0, ev1, 0,

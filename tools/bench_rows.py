@@ -114,13 +114,44 @@ def row_tick(a):
     return out
 
 
+def row_window(a):
+    """Config 3's objective evaluation: update(params) + the windowed NLL/gradient sweep, as the learner calls it
+    (moihgp_online.h:40-72)."""
+    from multioutputihgp_amd import MOIHGP
+    out = []
+    rng = np.random.default_rng(SEED)
+    for (M, L) in ((256, 256), (a.M, a.M)):
+        gp = MOIHGP(0.1, M, L, kernel="Matern52ss")
+        p = gp.params.copy()
+        p[:M * L] += 0.01 * rng.standard_normal(M * L)
+        p[M * L + L + 1:] = synth_params(L, 0, rng).ravel()
+        d = gp.igp_dim
+        x = np.zeros((L, d)); dx = np.zeros((L, 3, d))
+        for W in (16, 128):
+            Y = 0.5 * rng.standard_normal((W, M))
+            gp.update(p); gp.window_objective(Y, x, dx)
+            n = 5
+            t0 = time.perf_counter()
+            for _ in range(n): gp.update(p)
+            t_upd = (time.perf_counter() - t0) / n
+            gp.window_objective(Y, x, dx)
+            t0 = time.perf_counter()
+            for _ in range(n): gp.window_objective(Y, x, dx, set_window=False)
+            t_ev = (time.perf_counter() - t0) / n
+            flops = 3 * 2.0 * W * M * L + 221.0 * L * W
+            out.append(dict(row="N2 window objective", M=M, L=L, W=W, update_ms=t_upd * 1e3, eval_ms=t_ev * 1e3,
+                            eval_includes="H2D of x/dx, 3 GEMMs, sweep, reductions, D2H of loss + grad[M*L+L+1+3L]",
+                            grad_entries=gp.num_param, approx_tflops=flops / t_ev / 1e12))
+    return out
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--rows", default="update,grad,project,tick")
+    ap.add_argument("--rows", default="update,grad,project,tick,window")
     ap.add_argument("--L", type=int, default=4096); ap.add_argument("--T", type=int, default=10000); ap.add_argument("--M", type=int, default=4096)
     a = ap.parse_args()
     torch.cuda.set_device(0)
     for r in a.rows.split(","):
-        res = {"update": row_update, "grad": row_grad, "project": row_project, "tick": row_tick}[r](a)
+        res = {"update": row_update, "grad": row_grad, "project": row_project, "tick": row_tick, "window": row_window}[r](a)
         for rec in (res if isinstance(res, list) else [res]):
             print(json.dumps(rec), flush=True)

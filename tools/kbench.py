@@ -13,6 +13,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--dtype", default="f32"); ap.add_argument("--L", type=int, default=4096); ap.add_argument("--T", type=int, default=10000)
 ap.add_argument("--variants", default="0,1,2,3,4,5"); ap.add_argument("--rounds", type=int, default=5); ap.add_argument("--per", type=int, default=10)
 ap.add_argument("--nan", type=float, default=0.0); ap.add_argument("--mode", default="fn", help="f=yhat, n=nll")
+ap.add_argument("--cold", action="store_true", help="evict L2 / Infinity Cache before every launch (1 GiB write)")
 a = ap.parse_args()
 dtype = torch.float32 if a.dtype == "f32" else torch.float64
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)
@@ -24,6 +25,7 @@ if a.nan > 0:
 yhat = torch.empty_like(Ty); nll = torch.empty((a.L,), dtype=torch.float64, device=dev)
 x = torch.zeros((a.L, 3), dtype=dtype, device=dev)
 variants = [int(v) for v in a.variants.split(",")]
+evict = torch.zeros(256 * 1024 * 1024, dtype=torch.float32, device=dev) if a.cold else None
 es = 4 if dtype == torch.float32 else 8
 nbytes = (("f" in a.mode) + 1) * es * a.L * a.T
 times = {v: [] for v in variants}; ref = None
@@ -32,6 +34,8 @@ for rnd in range(a.rounds):
     for v in variants:
         os.environ["MOIHGP_FILTER_VARIANT"] = str(v)
         for _ in range(a.per):
+            if a.cold:
+                evict.add_(1.0)
             x.zero_()
             bank.filter(Ty, T=a.T, x=x, yhat=yhat, nll=nll, want_yhat="f" in a.mode, want_nll="n" in a.mode)
         times[v] += bank.profile_read()
@@ -40,7 +44,7 @@ for rnd in range(a.rounds):
             tot = nll.sum().item()
             if ref is None: ref = tot
             assert v == 9 or abs(tot - ref) <= 1e-5 * abs(ref), (v, tot, ref)
-print(f"dtype={a.dtype} L={a.L} T={a.T} mode={a.mode} nan={a.nan} bytes/launch={nbytes/1e6:.1f} MB")
+print(f"dtype={a.dtype} L={a.L} T={a.T} mode={a.mode} nan={a.nan} cold={a.cold} bytes/launch={nbytes/1e6:.1f} MB")
 for v in variants:
     t = np.array(times[v]) * 1e3
     print(f"variant {v}: min {t.min():7.1f} us  median {np.median(t):7.1f} us  -> {nbytes/np.median(t)/1e6:6.2f} TB/s ({nbytes/np.median(t)/1e6/8*100:4.1f}% of 8 TB/s)")
