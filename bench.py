@@ -208,6 +208,27 @@ def main():
         if rehearsal:
             out["rehearsal"] = "all ranks on one GPU, gloo exchange: numbers are not comparable"
         if world == 1 and not args.no_cpu:
+            # the other single-GPU configurations of BASELINE.json, measured the same way (kernel-exact events), for context
+            others = {}
+            for name in sorted(CONFIGS):
+                if name == args.config:
+                    continue
+                L2, T2, dt2, k2, desc2 = CONFIGS[name]
+                b2 = LatentBank(0.1, synth_params(L2, 0, np.random.default_rng(SEED)), kernel=k2)
+                Ty2 = synth_stream(L2, 0, T2, dt2, device, SEED + 1)
+                yh2 = torch.empty_like(Ty2); n2 = torch.empty((L2,), dtype=torch.float64, device=device)
+                x2 = torch.zeros((L2, b2.d), dtype=dt2, device=device)
+                for _ in range(3):
+                    x2.zero_(); b2.filter(Ty2, T=T2, x=x2, yhat=yh2, nll=n2)
+                b2.profile_enable(20)
+                for _ in range(20):
+                    x2.zero_(); b2.filter(Ty2, T=T2, x=x2, yhat=yh2, nll=n2)
+                ms2 = float(np.mean(b2.profile_read()))
+                es2 = 4 if dt2 == torch.float32 else 8
+                others[name] = {"workload": desc2, "kernel_ms": ms2, "steps_per_s_kernel_only": L2 * T2 / (ms2 * 1e-3),
+                                "achieved_GBps": 2 * es2 * L2 * T2 / (ms2 * 1e-3) / 1e9, "frac": 2 * es2 * L2 * T2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+                del b2, Ty2, yh2
+            out["other_configs"] = others
             sub = np.arange(0, L, max(1, L // 64))[:64]
             cb, nll_rel, mean_rel = cpu_baseline(prm, Ty[:, :T].cpu().numpy(), T, float(total.item()), yhat[sub][:, :T].double().cpu().numpy(), sub)
             out["cpu_baseline"] = cb
