@@ -118,6 +118,7 @@ struct moihgp_gp {
     double* dwork = nullptr;   // L*L + L, lazily (missing-output projection)
     double* dpolar = nullptr;  // M*L + 2*L*L + 8, lazily (device polar factor)
     int* dfallback = nullptr;  // [L] flags of latents redone by the sequential gradient kernel
+    bool U_host_stale = false; // the device holds a newer U than the host mirror (fetched on getParams)
     // window objective (moihgp_window_set / moihgp_window_eval)
     WindowBufs win{};
     double* dwin = nullptr;
@@ -142,7 +143,8 @@ static void gp_free(moihgp_gp* g) {
 
 static void upload_mixing(moihgp_gp* g) {
     if (g->latents_only) return;
-    MOIHGP_HIP_FATAL(hipMemcpyAsync(g->dU, g->U.data(), sizeof(double) * g->M * g->L, hipMemcpyHostToDevice, g->stream));
+    if (!g->U_host_stale)    // otherwise the device copy is the current one (device polar factor)
+        MOIHGP_HIP_FATAL(hipMemcpyAsync(g->dU, g->U.data(), sizeof(double) * g->M * g->L, hipMemcpyHostToDevice, g->stream));
     MOIHGP_HIP_FATAL(hipMemcpyAsync(g->dS, g->S.data(), sizeof(double) * g->L, hipMemcpyHostToDevice, g->stream));
     launch_scales(g->dS, g->L, g->dsqrtS, g->dinvsqrtS, g->stream);
     MOIHGP_HIP_FATAL(hipMemcpyAsync(g->dsigma, &g->sigma, sizeof(double), hipMemcpyHostToDevice, g->stream));
@@ -284,13 +286,12 @@ static bool compute_polar(moihgp_gp* g, const double* Uparam) {
     const size_t M = g->M, L = g->L;
     bool on_device = (double)M * (double)L * (double)L > 2.0e4;   // measured: 256x256 host Jacobi 384 ms vs 1024x1024 device 3.7 ms
     if (const char* e = std::getenv("MOIHGP_POLAR")) on_device = (e[0] == 'd');
-    if (!on_device) return polar_factor(M, L, Uparam, g->U.data());
+    if (!on_device) { g->U_host_stale = false; return polar_factor(M, L, Uparam, g->U.data()); }
     if (!g->dpolar) g->dpolar = dev_alloc<double>(M * L + 2 * L * L + 8 + 3 * L);
     MOIHGP_HIP_FATAL(hipMemcpyAsync(g->dU, Uparam, sizeof(double) * M * L, hipMemcpyHostToDevice, g->stream));
     const int its = polar_factor_device(g->dU, M, L, g->dpolar, g->stream);
     if (its < 0) return false;
-    MOIHGP_HIP_FATAL(hipMemcpyAsync(g->U.data(), g->dU, sizeof(double) * M * L, hipMemcpyDeviceToHost, g->stream));
-    MOIHGP_HIP_FATAL(hipStreamSynchronize(g->stream));
+    g->U_host_stale = true;                      // 8*M*L bytes over PCIe only when somebody asks (getParams)
     return true;
 }
 
@@ -300,6 +301,7 @@ static void do_update(moihgp_gp* g, const double* params) {          // moihgp.h
         set_last_error("update: mixing matrix is rank deficient");
         std::fprintf(stderr, "libmoihgp: %s\n", g_last_error);
         for (auto& u : g->U) u = std::nan("");
+        g->U_host_stale = false;
     }
     for (size_t l = 0; l < L; l++) g->S[l] = params[sizeU + l];          // moihgp.h:448
     g->sigma = params[sizeU + L];                                        // moihgp.h:449
@@ -310,6 +312,11 @@ static void do_update(moihgp_gp* g, const double* params) {          // moihgp.h
 
 static void do_get_params(moihgp_gp* g, double* params) {            // moihgp.h:721-738
     const size_t M = g->M, L = g->L, sizeU = M * L;
+    if (g->U_host_stale) {
+        MOIHGP_HIP_FATAL(hipMemcpyAsync(g->U.data(), g->dU, sizeof(double) * sizeU, hipMemcpyDeviceToHost, g->stream));
+        MOIHGP_HIP_FATAL(hipStreamSynchronize(g->stream));
+        g->U_host_stale = false;
+    }
     std::memcpy(params, g->U.data(), sizeof(double) * sizeU);
     std::memcpy(params + sizeU, g->S.data(), sizeof(double) * L);
     params[sizeU + L] = g->sigma;

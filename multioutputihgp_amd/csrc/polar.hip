@@ -40,6 +40,44 @@ __global__ void __launch_bounds__(256) gram_stats_kernel(const double* __restric
     if (tid == 0) { out[0] = r0[0]; out[1] = r1[0]; out[2] = r2[0]; }
 }
 
+// y = G v (one wave per row), used by the power iteration for lambda_max(G)
+__global__ void __launch_bounds__(256) symv_kernel(const double* __restrict__ G, size_t L, const double* __restrict__ v, double* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const size_t i = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= L) return;
+    double s = 0.0;
+    for (size_t j = lane; j < L; j += 64) s += G[i * L + j] * v[j];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) y[i] = s;
+}
+
+// v <- y / ||y||, stats[3] = ||y|| (the Rayleigh-type estimate of lambda_max when ||v|| = 1)      (one workgroup)
+__global__ void __launch_bounds__(256) normalize_kernel(const double* __restrict__ y, size_t L, double* __restrict__ v, double* __restrict__ stats) {
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    double s = 0.0;
+    for (size_t i = tid; i < L; i += 256) s += y[i] * y[i];
+    red[tid] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    const double nrm = sqrt(red[0]);
+    for (size_t i = tid; i < L; i += 256) v[i] = y[i] / nrm;
+    if (tid == 0) stats[3] = nrm;
+}
+
+__global__ void fill_kernel(double* __restrict__ v, size_t n, double val) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = val;
+}
+
+// X *= 1/sqrt(s2), G *= 1/s2 with s2 = stats[4]
+__global__ void scale2_kernel(double* __restrict__ X, size_t nX, double* __restrict__ G, size_t nG, const double* __restrict__ stats) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const double s2 = stats[4];
+    if (i < nX) X[i] *= 1.0 / sqrt(s2);
+    if (i < nG) G[i] *= 1.0 / s2;
+}
+
 __global__ void scale_kernel(double* __restrict__ X, size_t n, const double* __restrict__ stats) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -62,24 +100,40 @@ int polar_factor_device(double* X, size_t M, size_t L, double* work, hipStream_t
     double* W = G + L * L;            // L*L
     double* Xn = W + L * L;           // M*L
     double* stats = Xn + M * L;       // 8
-    double* rows = stats + 8;         // 3*L
-    double h[3];
-    const unsigned nbLL = (unsigned)((L * L + 255) / 256), nbML = (unsigned)((M * L + 255) / 256);
+    double* rows = stats + 8;         // 3*L  (also the two power-iteration vectors)
+    double h[5];
+    const unsigned nbLL = (unsigned)((L * L + 255) / 256), nbML = (unsigned)((M * L + 255) / 256), nbRow = (unsigned)((L + 3) / 4);
     if (launch_gram(X, M, L, G, s)) return -1;
-    hipLaunchKernelGGL(gram_row_stats_kernel, dim3((unsigned)((L + 3) / 4)), dim3(256), 0, s, G, L, rows);
+    // ---- scale: s^2 ~ lambda_max(G) = sigma_max(A)^2.  Newton-Schulz converges for sigma/s in (0, sqrt 3), so the
+    // estimate only has to be right within a factor 3 in lambda; it is cross-checked against the rigorous bounds
+    // ||G||_inf and trace(G) and the iteration falls back to them should the error ever grow.
+    hipLaunchKernelGGL(gram_row_stats_kernel, dim3(nbRow), dim3(256), 0, s, G, L, rows);
     hipLaunchKernelGGL(gram_stats_kernel, dim3(1), dim3(256), 0, s, rows, L, stats);
-    hipLaunchKernelGGL(scale_kernel, dim3(nbML), dim3(256), 0, s, X, M * L, stats);
-    MOIHGP_HIP_FATAL(hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, s));
+    double* v = rows;
+    double* y = rows + L;
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, s, v, L, 1.0 / sqrt((double)L));
+    for (int it = 0; it < 12; it++) {
+        hipLaunchKernelGGL(symv_kernel, dim3(nbRow), dim3(256), 0, s, (const double*)G, L, (const double*)v, y);
+        hipLaunchKernelGGL(normalize_kernel, dim3(1), dim3(256), 0, s, (const double*)y, L, v, stats);
+    }
+    MOIHGP_HIP_FATAL(hipMemcpyAsync(h, stats, sizeof(double) * 4, hipMemcpyDeviceToHost, s));
     MOIHGP_HIP_FATAL(hipStreamSynchronize(s));
-    if (!(fmin(h[0], h[1]) > 0.0) || h[0] != h[0]) return -1;
+    const double bound = fmin(h[0], h[1]);
+    if (!(bound > 0.0) || h[0] != h[0]) return -1;
+    double s2 = 1.05 * h[3];
+    if (!(s2 > 0.0) || s2 > bound) s2 = bound;
+    bool used_bound = (s2 == bound);
+    h[4] = s2;
+    MOIHGP_HIP_FATAL(hipMemcpyAsync(stats + 4, &h[4], sizeof(double), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(scale2_kernel, dim3(nbML > nbLL ? nbML : nbLL), dim3(256), 0, s, X, M * L, G, L * L, (const double*)stats);   // G is now X^T X
     double prev = 1e300;
     double* cur = X;
     double* nxt = Xn;
     for (int it = 1; it <= 200; it++) {
-        if (launch_gram(cur, M, L, G, s)) return -1;
-        hipLaunchKernelGGL(gram_row_stats_kernel, dim3((unsigned)((L + 3) / 4)), dim3(256), 0, s, G, L, rows);
+        if (it > 1 && launch_gram(cur, M, L, G, s)) return -1;
+        hipLaunchKernelGGL(gram_row_stats_kernel, dim3(nbRow), dim3(256), 0, s, G, L, rows);
         hipLaunchKernelGGL(gram_stats_kernel, dim3(1), dim3(256), 0, s, rows, L, stats);
-        MOIHGP_HIP_FATAL(hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, s));
+        MOIHGP_HIP_FATAL(hipMemcpyAsync(h, stats, sizeof(double) * 3, hipMemcpyDeviceToHost, s));
         MOIHGP_HIP_FATAL(hipStreamSynchronize(s));
         const double err = h[2];
         if (err != err) return -1;
@@ -88,7 +142,18 @@ int polar_factor_device(double* X, size_t M, size_t L, double* work, hipStream_t
             if (cur != X) MOIHGP_HIP_FATAL(hipMemcpyAsync(X, cur, sizeof(double) * M * L, hipMemcpyDeviceToDevice, s));
             return it - 1;
         }
-        if (it > 60 && err >= prev) break;       // stagnating far from orthonormal: rank deficient
+        if (it > 3 && err > 4.0 * prev && !used_bound) {
+            // the spectral estimate was too small after all (error growing): the current iterate still has the polar factor
+            // of A, so rescale it by the rigorous bound of ITS Gram matrix (h[0], h[1] above) and carry on
+            used_bound = true;
+            h[4] = fmin(h[0], h[1]);
+            MOIHGP_HIP_FATAL(hipMemcpyAsync(stats + 4, &h[4], sizeof(double), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(scale2_kernel, dim3(nbML > nbLL ? nbML : nbLL), dim3(256), 0, s, cur, M * L, G, L * L, (const double*)stats);
+            MOIHGP_HIP_FATAL(hipStreamSynchronize(s));
+            prev = 1e300;
+            continue;
+        }
+        if (it > 80 && err >= prev) break;       // stagnating far from orthonormal: rank deficient
         prev = err;
         hipLaunchKernelGGL(ns_weight_kernel, dim3(nbLL), dim3(256), 0, s, G, W, L);
         if (launch_matmul_nn(cur, M, L, W, nxt, s)) return -1;

@@ -30,7 +30,7 @@ struct FastConst {
     T a[D * D];        // A = expm(dt F): x <- A x + K v is the innovation form of ihgp.h:90 (v = y - HA x)
     T k[D];            // K
     T g[CK * D];       // g_k = AKHA^(CK-1-k) K
-    T sp[4 * D * D];   // M^(1,2,4,8), M = AKHA^CK
+    const T* sp;       // M^(1,2,4,8), M = AKHA^CK: 4*D*D scalars parked in LDS (wave-private), re-read at every scan level
     T pj[D * D];       // M^(lane%16 + 1)
 };
 
@@ -372,8 +372,13 @@ filter_scan_kernel(const T* __restrict__ Ty, size_t Ttot, size_t ld, size_t L, c
     for (int i = 0; i < D; i++) c.k[i] = cb[Lay::K + i];
 #pragma unroll
     for (int i = 0; i < CK * D; i++) c.g[i] = cb[Lay::G + i];
-#pragma unroll
-    for (int i = 0; i < 4 * D * D; i++) c.sp[i] = cb[Lay::SP + i];
+    {   // park the scan powers in LDS: as registers they would be 36-72 more uniform values than the SGPR file holds
+        T* spw = reinterpret_cast<T*>(smem + (size_t)(SPLIT ? nsplit : kWavesPerBlock) * NVP * sizeof(V) +
+                                      (SPLIT ? (size_t)nsplit * CR * sizeof(double) : 0)) + (size_t)wave * (4 * D * D);
+        if (lane < 4 * D * D) spw[lane] = cb[Lay::SP + lane];
+        c.sp = spw;
+        wave_lds_fence();
+    }
 #pragma unroll
     for (int i = 0; i < D * D; i++) c.pj[i] = cb[Lay::PJ + (lane & 15) * D * D + i];
 
@@ -471,7 +476,8 @@ int launch_filter_t(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* c
     dim3 block(SPLIT ? 64 * nsplit : 64 * kWavesPerBlock);
     dim3 grid(SPLIT ? (unsigned)L : (unsigned)((L + kWavesPerBlock - 1) / kWavesPerBlock));
     constexpr size_t tile = 64 * (CK / (16 / sizeof(T)) + 1) * 16;                    // padded LDS tile per wave
-    const size_t smem = SPLIT ? (size_t)nsplit * (tile + (D * D + D + 2) * sizeof(double)) : (size_t)kWavesPerBlock * tile;
+    const size_t smem = (SPLIT ? (size_t)nsplit * (tile + (D * D + D + 2) * sizeof(double)) : (size_t)kWavesPerBlock * tile) +
+                        (size_t)(SPLIT ? nsplit : kWavesPerBlock) * 4 * D * D * sizeof(T);
     const T* ty = static_cast<const T*>(Ty);
     T* xs = static_cast<T*>(x);
     T* yh = static_cast<T*>(yhat);
@@ -526,7 +532,7 @@ int launch_filter_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, 
     if (d == 2) MOIHGP_FILTER_CASE(float, 2, kChunk32, 4, cb32);
     if (variant == 2 || variant == 4 || variant == 6) {   // tuning probes: plain stores (2), nontemporal loads (4), both (6)
         dim3 block(64 * kWavesPerBlock), grid((unsigned)((L + kWavesPerBlock - 1) / kWavesPerBlock));
-        const size_t sm = (size_t)kWavesPerBlock * 64 * 5 * 16;
+        const size_t sm = (size_t)kWavesPerBlock * (64 * 5 * 16 + 36 * 4);
         if (variant == 2) hipExtLaunchKernelGGL((filter_scan_kernel<float, 3, kChunk32, true, true, 4, false, 2>), grid, block, sm, stream, ev0, ev1, 0, (const float*)Ty, T, ld, L, cb32, cb64, (float*)x, (float*)yhat, nll, 1, T);
         else if (variant == 4) hipExtLaunchKernelGGL((filter_scan_kernel<float, 3, kChunk32, true, true, 4, false, 4>), grid, block, sm, stream, ev0, ev1, 0, (const float*)Ty, T, ld, L, cb32, cb64, (float*)x, (float*)yhat, nll, 1, T);
         else hipExtLaunchKernelGGL((filter_scan_kernel<float, 3, kChunk32, true, true, 4, false, 6>), grid, block, sm, stream, ev0, ev1, 0, (const float*)Ty, T, ld, L, cb32, cb64, (float*)x, (float*)yhat, nll, 1, T);
@@ -534,7 +540,7 @@ int launch_filter_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, 
     }
     if (variant == 9) {   // tuning probe (staging only)
         dim3 block(64 * kWavesPerBlock), grid((unsigned)((L + kWavesPerBlock - 1) / kWavesPerBlock));
-        hipExtLaunchKernelGGL((filter_scan_kernel<float, 3, kChunk32, true, true, 1, false, 1>), grid, block, (size_t)kWavesPerBlock * 64 * 5 * 16, stream, ev0, ev1, 0,
+        hipExtLaunchKernelGGL((filter_scan_kernel<float, 3, kChunk32, true, true, 1, false, 1>), grid, block, (size_t)kWavesPerBlock * (64 * 5 * 16 + 36 * 4), stream, ev0, ev1, 0,
                               (const float*)Ty, T, ld, L, cb32, cb64, (float*)x, (float*)yhat, nll, 1, T);
         return 0;
     }

@@ -123,7 +123,8 @@ def row_window(a):
     for (M, L) in ((256, 256), (a.M, a.M)):
         gp = MOIHGP(0.1, M, L, kernel="Matern52ss")
         p = gp.params.copy()
-        p[:M * L] += 0.01 * rng.standard_normal(M * L)
+        dU = rng.standard_normal(M * L)
+        p[:M * L] += 0.1 * dU / np.linalg.norm(dU)          # ||dU||_F = 0.1 = the reference's L-BFGS-B max_step (moihgp_online.h:156)
         p[M * L + L + 1:] = synth_params(L, 0, rng).ravel()
         d = gp.igp_dim
         x = np.zeros((L, d)); dx = np.zeros((L, 3, d))
