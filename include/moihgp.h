@@ -173,6 +173,12 @@ int moihgp_window_eval(moihgp_gp* gp, const double* x, const double* dx, double*
 int moihgp_profile_enable(moihgp_gp* gp, int max_launches);
 int moihgp_profile_read(moihgp_gp* gp, float* ms, int n);
 
+/* Page-lock a caller-owned HOST buffer that is passed again and again to the reference ABI (the params / grad staging arrays
+ * of pywrapper.py:146-149 are 8*(M*L+..) bytes: 134 MB at M = L = 4096), so that the copies behind gpXX_update / gpXX_lik1 /
+ * moihgp_window_eval run at PCIe rate instead of the pageable rate.  The buffer must outlive the handle (it is unregistered
+ * in *_del).  Optional: everything works without it. */
+int moihgp_pin_host_buffer(moihgp_gp* gp, void* ptr, size_t bytes);
+
 /* Stream synchronisation helper for callers without a HIP runtime binding. */
 int moihgp_stream_sync(void* stream);
 

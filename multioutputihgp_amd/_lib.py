@@ -21,7 +21,7 @@ ADDITIVE_SYMBOLS = [
     "moihgp_num_output", "moihgp_num_latent", "moihgp_reseed_U", "moihgp_new_latents",
     "moihgp_update_latents", "moihgp_get_latent", "moihgp_filter_stream", "moihgp_grad_stream",
     "moihgp_project_stream", "moihgp_unproject_stream", "moihgp_stream_sync",
-    "moihgp_profile_enable", "moihgp_profile_read", "moihgp_window_set", "moihgp_window_eval",
+    "moihgp_profile_enable", "moihgp_profile_read", "moihgp_window_set", "moihgp_window_eval", "moihgp_pin_host_buffer",
 ]
 
 
@@ -94,6 +94,8 @@ def load_library():
     lib.moihgp_window_set.argtypes = [C.c_void_p, c_double_p, C.c_size_t]
     lib.moihgp_window_eval.restype = C.c_int
     lib.moihgp_window_eval.argtypes = [C.c_void_p] + [c_double_p] * 6
+    lib.moihgp_pin_host_buffer.restype = C.c_int
+    lib.moihgp_pin_host_buffer.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     lib.moihgp_stream_sync.restype = C.c_int
     lib.moihgp_stream_sync.argtypes = [C.c_void_p]
     _LIB = lib

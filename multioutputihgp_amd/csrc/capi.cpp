@@ -119,6 +119,7 @@ struct moihgp_gp {
     double* dpolar = nullptr;  // M*L + 2*L*L + 8, lazily (device polar factor)
     int* dfallback = nullptr;  // [L] flags of latents redone by the sequential gradient kernel
     bool U_host_stale = false; // the device holds a newer U than the host mirror (fetched on getParams)
+    std::vector<void*> pinned; // caller buffers page-locked through moihgp_pin_host_buffer
     // window objective (moihgp_window_set / moihgp_window_eval)
     WindowBufs win{};
     double* dwin = nullptr;
@@ -136,6 +137,7 @@ static void gp_free(moihgp_gp* g) {
                     g->ddxnew, g->dTy, g->dUty, g->dTyhat, g->dloss, g->dgrad, g->dscratch, g->dwork, g->dpolar, g->dfallback, g->dwin};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    for (void* p : g->pinned) (void)hipHostUnregister(p);
     for (hipEvent_t e : g->prof_ev) (void)hipEventDestroy(e);
     if (g->stream) (void)hipStreamDestroy(g->stream);
     delete g;
@@ -534,6 +536,14 @@ int moihgp_window_eval(moihgp_gp* gp, const double* x, const double* dx, double*
     if (xnew) MOIHGP_HIP_FATAL(hipMemcpyAsync(xnew, w.x, sizeof(double) * L * d, hipMemcpyDeviceToHost, gp->stream));
     if (dxnew) MOIHGP_HIP_FATAL(hipMemcpyAsync(dxnew, w.dx, sizeof(double) * L * P * d, hipMemcpyDeviceToHost, gp->stream));
     MOIHGP_HIP_FATAL(hipStreamSynchronize(gp->stream));
+    return 0;
+}
+
+int moihgp_pin_host_buffer(moihgp_gp* gp, void* ptr, size_t bytes) {
+    if (!gp || !ptr || bytes == 0) { set_last_error("pin_host_buffer: bad argument"); return 1; }
+    hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) { (void)hipGetLastError(); set_last_error("hipHostRegister: %s", hipGetErrorString(e)); return 2; }
+    gp->pinned.push_back(ptr);
     return 0;
 }
 

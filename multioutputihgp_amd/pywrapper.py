@@ -70,6 +70,12 @@ class MOIHGP(object):
         self.__yhat_p = self.__yhat.ctypes.data_as(c_double_p)
         self.__dxnew = np.zeros((self.num_latent, self.num_igp_param, self.igp_dim), dtype=np.float64)
         self.__dxnew_p = self.__dxnew.ctypes.data_as(c_double_p)
+        # large models: page-lock the two big persistent staging arrays (they live as long as this object) and keep a
+        # persistent gradient buffer for the window objective
+        self.__wgrad = np.zeros((self.num_param,), dtype=np.float64)
+        if self.num_param * 8 >= (1 << 20):
+            for buf in (self.__params, self.__grad, self.__wgrad):
+                lib.moihgp_pin_host_buffer(self.__obj, buf.ctypes.data, buf.nbytes)
 
     def __del__(self):
         try:
@@ -125,7 +131,8 @@ class MOIHGP(object):
     def window_objective(self, Y, x, dx, set_window=True):
         """The learners' windowed objective in ONE call (include/moihgp.h `moihgp_window_*`): equivalent to
         `for y in Y: (xn, _, dxn) = step(x, y, dx); l, g = negLogLikelihood(x, y, dx); loss += l; grad += g; x, dx = xn, dxn`
-        (online_learning.py:83-89).  Returns (loss, grad, xnew, dxnew).  Raises if Y holds NaN."""
+        (online_learning.py:83-89).  Returns (loss, grad, xnew, dxnew); `grad` is a persistent buffer that the next call
+        overwrites (copy it to keep it).  Raises if Y holds NaN."""
         lib = self.__lib
         if set_window:
             Yc = np.ascontiguousarray(Y, dtype=np.float64).reshape(-1, self.num_output)
@@ -134,12 +141,12 @@ class MOIHGP(object):
                 raise MoihgpError(last_error(lib) or "moihgp_window_set failed")
         xc = np.ascontiguousarray(x, dtype=np.float64).reshape(self.num_latent, self.igp_dim)
         dxc = np.ascontiguousarray(dx, dtype=np.float64).reshape(self.num_latent, self.num_igp_param, self.igp_dim)
-        loss = np.zeros(1); grad = np.zeros(self.num_param); xn = np.zeros_like(xc); dxn = np.zeros_like(dxc)
+        loss = np.zeros(1); xn = np.zeros_like(xc); dxn = np.zeros_like(dxc)
         rc = lib.moihgp_window_eval(self.__obj, xc.ctypes.data_as(c_double_p), dxc.ctypes.data_as(c_double_p), loss.ctypes.data_as(c_double_p),
-                                    grad.ctypes.data_as(c_double_p), xn.ctypes.data_as(c_double_p), dxn.ctypes.data_as(c_double_p))
+                                    self.__wgrad.ctypes.data_as(c_double_p), xn.ctypes.data_as(c_double_p), dxn.ctypes.data_as(c_double_p))
         if rc != 0:
             raise MoihgpError(last_error(lib) or "moihgp_window_eval failed")
-        return float(loss[0]), grad, xn, dxn
+        return float(loss[0]), self.__wgrad, xn, dxn      # persistent (page-locked) buffer: overwritten by the next call
 
     @property
     def num_output(self):
