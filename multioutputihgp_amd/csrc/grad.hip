@@ -19,6 +19,14 @@
 // the scan kernel flags such a latent and grad_seq_kernel (one lane per latent, sequential, loads prefetched in
 // 16-byte vectors) recomputes it.  The reference never feeds a NaN to IHGP through MOIHGP (SURVEY 8a notes).
 #include "kernels_common.h"
+#include <cstdlib>
+
+#ifndef MOIHGP_GRAD_SPREG
+#define MOIHGP_GRAD_SPREG 1
+#endif
+#ifndef MOIHGP_GRAD_MINW
+#define MOIHGP_GRAD_MINW 1
+#endif
 
 namespace moihgp {
 namespace {
@@ -71,7 +79,7 @@ __device__ inline T tick_mean(const GradConst<T, D>& c, T* xs, T y, T& hx_out) {
 // WRITE: 0 no stream output, 1 filtered means yhat_t = x_{t+1}[0] (ihgp.h:51), 2 predicted means hx_t = HA x_t (pre-step; what
 // MOIHGP::negLogLikelihood needs for `pv`, moihgp.h:505-512)
 template <typename T, int D, int CK, int WRITE>
-__global__ void __launch_bounds__(64 * kWavesPerBlock)
+__global__ void __launch_bounds__(64 * kWavesPerBlock, MOIHGP_GRAD_MINW)
 grad_scan_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, const T* __restrict__ cbT,
                  const double* __restrict__ cb64, T* __restrict__ x, T* __restrict__ dx, T* __restrict__ yhat,
                  double* __restrict__ nll, double* __restrict__ grad, int* __restrict__ fallback) {
@@ -184,9 +192,13 @@ grad_scan_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, con
         for (int k = 0; k < VPL; k++) unpack<T>(lds[lane * (VPL + 1) + k], &y[k * EPV]);
 
         // ---- (a) mean: chunk response + scan -------------------------------------------------------------
-        T sp[4 * D * D];
+#if MOIHGP_GRAD_SPREG
+        T sp[4 * D * D];                     // scan powers of this segment in registers
 #pragma unroll
         for (int i = 0; i < 4 * D * D; i++) sp[i] = tab[CK * D + i];
+#else
+        const T* sp = tab + CK * D;          // scan powers stay in LDS: broadcast reads at every use
+#endif
         T z[D];
 #pragma unroll
         for (int i = 0; i < D; i++) z[i] = T(0);
@@ -450,18 +462,21 @@ int launch_grad_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, si
                        hipStream_t stream, int out_mode) {
     if (L == 0) return 0;
     // short windows (the online learner's W <= 128 ticks, moihgp_online.h:61-70) use 16-byte chunks so that a
-    // window still spreads over the lanes of the wave; long streams use 64-byte chunks
+    // window still spreads over the lanes of the wave; long streams use 8-tick chunks (tuning hook: MOIHGP_GRAD_CK)
     const bool shortw = T <= (dtype == 0 ? 256 : 512);
+    static const int ck_override = [] { const char* e = std::getenv("MOIHGP_GRAD_CK"); return e ? std::atoi(e) : 0; }();
 #define MOIHGP_GRAD_CASE(TT, DD, CKK, CB) \
     return launch_grad_t<TT, DD, CKK>((const TT*)Ty, T, ld, L, CB, cb64, (TT*)x, (TT*)dx, (TT*)yhat, nll, grad, fallback, out_mode, stream)
     if (dtype == 0) {
         if (d == 2) { if (shortw) MOIHGP_GRAD_CASE(double, 2, 2, cb64); MOIHGP_GRAD_CASE(double, 2, 8, cb64); }
-        if (shortw) MOIHGP_GRAD_CASE(double, 3, 2, cb64);
+        if (shortw || ck_override == 2) MOIHGP_GRAD_CASE(double, 3, 2, cb64);
+        if (ck_override == 4) MOIHGP_GRAD_CASE(double, 3, 4, cb64);
         MOIHGP_GRAD_CASE(double, 3, 8, cb64);
     }
     if (d == 2) { if (shortw) MOIHGP_GRAD_CASE(float, 2, 4, cb32); MOIHGP_GRAD_CASE(float, 2, 16, cb32); }
-    if (shortw) MOIHGP_GRAD_CASE(float, 3, 4, cb32);
-    MOIHGP_GRAD_CASE(float, 3, 16, cb32);
+    if (shortw || ck_override == 4) MOIHGP_GRAD_CASE(float, 3, 4, cb32);
+    if (ck_override == 16) MOIHGP_GRAD_CASE(float, 3, 16, cb32);
+    MOIHGP_GRAD_CASE(float, 3, 8, cb32);            // measured: 8-tick chunks (165 VGPRs) beat 16-tick chunks (256 VGPRs) by 17 %
 #undef MOIHGP_GRAD_CASE
 }
 
