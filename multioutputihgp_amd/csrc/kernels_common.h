@@ -74,6 +74,18 @@ __device__ inline double dpp0(double v) {
     unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, ROW_MASK, 0xF, false);
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
+// same with an explicit fill value `old` for lanes the control leaves without a source
+template <int CTRL, int ROW_MASK>
+__device__ inline float dpp_fill(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ inline double dpp_fill(double old, double v) {
+    unsigned long long u = __builtin_bit_cast(unsigned long long, v), f = __builtin_bit_cast(unsigned long long, old);
+    unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)f, (int)(unsigned)u, CTRL, ROW_MASK, 0xF, false);
+    unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(f >> 32), (int)(unsigned)(u >> 32), CTRL, ROW_MASK, 0xF, false);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
 // wave_shr:1 with lane 0 keeping `first`
 __device__ inline float wave_shr1(float v, float first) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, first), __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, false));

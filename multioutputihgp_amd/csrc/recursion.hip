@@ -119,91 +119,133 @@ __device__ inline bool fast_segment(T* y, T* xin, const FastConst<T, D, CK>& c, 
     return true;
 }
 
-// Missing-data path (ihgp.h:83-87: a NaN observation advances x <- A x): chunk maps become
-// lane-dependent, so (M_j, z_j) pairs are scanned (Kogge-Stone over 64 lanes with shuffles).  Works on the
-// chunk parked in LDS (ch = this lane's CK elements) and leaves the filtered means there; rolled loops
-// and its own constant loads keep it out of the register budget of the fast path.
+// Missing-data path (ihgp.h:83-87: a NaN observation advances x <- A x, i.e. the innovation form with v = 0).  Chunk
+// maps become lane-dependent, so every lane accumulates the transition matrix M_j of its chunk next to its response
+// z_j, and the pairs are scanned: in-row Kogge-Stone with row_shr (lanes without a source compose with the identity),
+// then the three row_bcast:15 rounds, where a lane folds the finished prefix of the previous row through its own in-row
+// matrix.  Works on the chunk still parked in LDS (ch = this lane's CK elements) and leaves the filtered means there.
+// Ticks past the end of the stream are treated as missing (they only influence lanes whose results are discarded) and
+// frozen in the replay.  mseg (optional) receives the transition matrix of the whole segment (time split).
+template <int O, typename T, int D>
+__device__ inline void generic_scan_level(T* z, T* m) {
+    T zp[D], mp[D * D];
+#pragma unroll
+    for (int i = 0; i < D; i++) zp[i] = dpp0<DPP_ROW_SHR + O, 0xF>(z[i]);
+#pragma unroll
+    for (int i = 0; i < D * D; i++) mp[i] = dpp_fill<DPP_ROW_SHR + O, 0xF>((i % (D + 1) == 0) ? T(1) : T(0), m[i]);
+    matvec_acc<T, D>(m, zp, z);          // z = M zp + z
+    matmul<T, D>(m, mp, m);              // M = M Mp
+}
+
 template <typename T, int D, int CK, bool NLL>
 __device__ inline void generic_segment(T* ch, T* xin, const T* cb /* this latent's constant block */,
                                        int lane, size_t t0, size_t Tlen, double& acc, unsigned& nobs,
                                        T* mseg = nullptr /* out: transition matrix of the whole segment */) {
     using Lay = CB<D>;
-    T aa[D * D], akha[D * D], kk[D], ha[D], mj[D * D], z[D];
+    T a[D * D], kk[D], y[CK];
 #pragma unroll
-    for (int i = 0; i < D * D; i++) { aa[i] = cb[Lay::A + i]; akha[i] = cb[Lay::AKHA + i]; mj[i] = (i % (D + 1) == 0) ? T(1) : T(0); }
+    for (int i = 0; i < D * D; i++) a[i] = cb[Lay::A + i];
 #pragma unroll
-    for (int i = 0; i < D; i++) { kk[i] = cb[Lay::K + i]; ha[i] = cb[Lay::HA + i]; z[i] = (lane == 0) ? xin[i] : T(0); }
-#pragma unroll 1
+    for (int i = 0; i < D; i++) kk[i] = cb[Lay::K + i];
+#pragma unroll
+    for (int k = 0; k < CK; k++) y[k] = ch[k];
+    // one masked tick in innovation form: hx = A0.x ; v = miss ? 0 : y - hx ; x <- A x + K v
+    auto tick = [&](T* xs, T yk, bool miss, T& hx_out) -> T {
+        T hx = 0;
+#pragma unroll
+        for (int j = 0; j < D; j++) hx = fma(a[j], xs[j], hx);
+        const T v = miss ? T(0) : yk - hx;
+        T xn[D];
+        xn[0] = fma(kk[0], v, hx);
+#pragma unroll
+        for (int i = 1; i < D; i++) {
+            T s = kk[i] * v;
+#pragma unroll
+            for (int j = 0; j < D; j++) s = fma(a[i * D + j], xs[j], s);
+            xn[i] = s;
+        }
+#pragma unroll
+        for (int i = 0; i < D; i++) xs[i] = xn[i];
+        hx_out = hx;
+        return v;
+    };
+    // ---- pass 1: chunk response z (lane 0 from the carried-in state) and chunk matrix M ------------------------------
+    T z[D], m[D * D];
+#pragma unroll
+    for (int i = 0; i < D; i++) z[i] = (lane == 0) ? xin[i] : T(0);
+#pragma unroll
+    for (int i = 0; i < D * D; i++) m[i] = (i % (D + 1) == 0) ? T(1) : T(0);
+#pragma unroll
     for (int k = 0; k < CK; k++) {
-        const T yk = ch[k];
-        const bool miss = (yk != yk);
-        if ((t0 + k) < Tlen) {
-            T b[D * D], zn[D];
+        const bool miss = (y[k] != y[k]) || (t0 + k) >= Tlen;
+        T hx;
+        tick(z, y[k], miss, hx);
+        // M <- (A - w K HA) M with w = !miss; HA M is row 0 of A M
+        T am[D * D];
+        matmul<T, D>(a, m, am);
 #pragma unroll
-            for (int i = 0; i < D * D; i++) b[i] = miss ? aa[i] : akha[i];
+        for (int i = 0; i < D; i++) {
+            const T wk = miss ? T(0) : kk[i];
 #pragma unroll
-            for (int i = 0; i < D; i++) zn[i] = miss ? T(0) : kk[i] * yk;
-            matvec_acc<T, D>(b, z, zn);
-#pragma unroll
-            for (int i = 0; i < D; i++) z[i] = zn[i];
-            matmul<T, D>(b, mj, mj);
+            for (int j = 0; j < D; j++) m[i * D + j] = fma(-wk, am[j], am[i * D + j]);
         }
     }
-#pragma unroll 1
-    for (int s = 0; s < 6; s++) {
-        const int o = 1 << s;
-        T zp[D], mq[D * D];
+    // ---- scan of the (M_j, z_j) pairs ------------------------------------------------------------------------------------
+    generic_scan_level<1, T, D>(z, m);
+    generic_scan_level<2, T, D>(z, m);
+    generic_scan_level<4, T, D>(z, m);
+    generic_scan_level<8, T, D>(z, m);
+    if (mseg) {                          // segment matrix = row3 * row2 * row1 * row0 (in-row totals sit in lanes 15, 31, 47, 63)
+        T r[D * D];
 #pragma unroll
-        for (int i = 0; i < D; i++) zp[i] = __shfl_up(z[i], o);
+        for (int i = 0; i < D * D; i++) mseg[i] = read_lane(m[i], 15);
 #pragma unroll
-        for (int i = 0; i < D * D; i++) mq[i] = __shfl_up(mj[i], o);
-        if (lane >= o) {
-            matvec_acc<T, D>(mj, zp, z);
-            matmul<T, D>(mj, mq, mj);
+        for (int q = 1; q < 4; q++) {
+#pragma unroll
+            for (int i = 0; i < D * D; i++) r[i] = read_lane(m[i], 16 * q + 15);
+            matmul<T, D>(r, mseg, mseg);
         }
     }
-    if (mseg) {                                       // lanes past the end hold identity maps
+    {
+        T t[D];
 #pragma unroll
-        for (int i = 0; i < D * D; i++) mseg[i] = __shfl(mj[i], 63);
+        for (int i = 0; i < D; i++) t[i] = dpp0<DPP_ROW_BCAST15, 0x2>(z[i]);
+        matvec_acc<T, D>(m, t, z);
+#pragma unroll
+        for (int i = 0; i < D; i++) t[i] = dpp0<DPP_ROW_BCAST15, 0x4>(z[i]);
+        matvec_acc<T, D>(m, t, z);
+#pragma unroll
+        for (int i = 0; i < D; i++) t[i] = dpp0<DPP_ROW_BCAST15, 0x8>(z[i]);
+        matvec_acc<T, D>(m, t, z);
     }
     T xs[D];
 #pragma unroll
-    for (int i = 0; i < D; i++) {
-        T up = __shfl_up(z[i], 1);
-        xs[i] = (lane == 0) ? xin[i] : up;
-    }
-#pragma unroll 1
+    for (int i = 0; i < D; i++) xs[i] = wave_shr1(z[i], xin[i]);
+    // ---- pass 2: replay from the true start state -----------------------------------------------------------------------
+    T part = 0;
+#pragma unroll
     for (int k = 0; k < CK; k++) {
-        const T yk = ch[k];
-        const bool miss = (yk != yk);
-        if ((t0 + k) < Tlen) {
-            if (NLL && !miss) {
-                T hx = 0;
+        const bool valid = (t0 + k) < Tlen;
+        const bool miss = (y[k] != y[k]);
+        T xo[D], hx;
 #pragma unroll
-                for (int i = 0; i < D; i++) hx = fma(ha[i], xs[i], hx);
-                double v = (double)(yk - hx);
-                acc = fma(v, v, acc);
-                nobs++;
-            }
-            T b[D * D], xn[D];
-#pragma unroll
-            for (int i = 0; i < D * D; i++) b[i] = miss ? aa[i] : akha[i];
-#pragma unroll
-            for (int i = 0; i < D; i++) xn[i] = miss ? T(0) : kk[i] * yk;
-            matvec_acc<T, D>(b, xs, xn);
-#pragma unroll
-            for (int i = 0; i < D; i++) xs[i] = xn[i];
+        for (int i = 0; i < D; i++) xo[i] = xs[i];
+        const T v = tick(xs, y[k], miss || !valid, hx);
+        if (NLL) {
+            part = fma(v, v, part);              // v = 0 on missing / past-the-end ticks
+            nobs += (valid && !miss) ? 1u : 0u;
         }
+#pragma unroll
+        for (int i = 0; i < D; i++) xs[i] = valid ? xs[i] : xo[i];
         ch[k] = xs[0];
     }
-    size_t tb = t0 - (size_t)lane * CK;               // wave-uniform segment base
-    size_t last = Tlen - 1 - tb;
-    int jl = (last / CK) > 63 ? 63 : (int)(last / CK);
+    if (NLL) acc += (double)part;
+    const size_t last = Tlen - 1 - (t0 - (size_t)lane * CK);
+    const int jl = (last / CK) > 63 ? 63 : (int)(last / CK);
 #pragma unroll
-    for (int i = 0; i < D; i++) xin[i] = __shfl(xs[i], jl);
+    for (int i = 0; i < D; i++) xin[i] = read_lane(xs[i], jl);
 }
 
-// ---------------------------------------------------------------------------------------------
 // One sweep over `Tlen` ticks of one stream (`row`) by one wavefront, segment by segment.
 //   SLICEMAP = false: the real sweep (filtered means to `orow` if WRITE, sum of v^2 in acc/nobs if NLL)
 //   SLICEMAP = true : no replay and no outputs; xin ends as the state reached from the given start and msl as
