@@ -109,6 +109,12 @@ moihgp_gp*  moihgp_new_latents(int kernel, double dt, size_t num_latent_local, c
 /* Re-run IHGP::update (ihgp.h:117-201) for every owned latent from HOST params [nl][3]. */
 int         moihgp_update_latents(moihgp_gp* gp, const double* params_LP);
 
+/* Set the mixing of a full object directly, WITHOUT the polar-factor step of update() (moihgp.h:433-447): U [M][L] row-major,
+ * S [L], sigma, all HOST.  For latent shards of a bigger model: rank r builds an object with its L_r latents and hands it the
+ * columns [lo_r, hi_r) of the global orthonormal factor, so that moihgp_project_stream / moihgp_unproject_stream compute this
+ * rank's part of S^-1/2 U^T y and of U S^1/2 Ty (sharded.py).  Combine with moihgp_update_latents for the per-latent parameters. */
+int         moihgp_set_mixing(moihgp_gp* gp, const double* U, const double* S, double sigma);
+
 /* Copy the stationary matrices of latent l (ihgp.h:243-254) to HOST buffers (any may be NULL):
  * A[d*d] K[d] S[1] HA[d] AKHA[d*d] dA[P*d*d] dS[P] dK[P*d] dAKHA[P*d*d] HdA[P*d], row-major;
  * iters[1+P] = DARE iteration count followed by the P DLyap counts (utils/dare.h returns are ignored

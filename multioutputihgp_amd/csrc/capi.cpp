@@ -390,6 +390,17 @@ moihgp_gp* moihgp_new_latents(int kernel, double dt, size_t nl, const double* pa
     return gp_create(kernel, dt, 0, nl, true, params_LP);
 }
 
+int moihgp_set_mixing(moihgp_gp* gp, const double* U, const double* S, double sigma) {
+    if (!gp || gp->latents_only || !U || !S) { set_last_error("set_mixing: needs a full MOIHGP object and non-null U, S"); return 1; }
+    std::memcpy(gp->U.data(), U, sizeof(double) * gp->M * gp->L);
+    std::memcpy(gp->S.data(), S, sizeof(double) * gp->L);
+    gp->sigma = sigma;
+    gp->U_host_stale = false;
+    upload_mixing(gp);
+    MOIHGP_HIP_FATAL(hipStreamSynchronize(gp->stream));
+    return 0;
+}
+
 int moihgp_update_latents(moihgp_gp* gp, const double* params_LP) {
     if (!gp || !params_LP) { set_last_error("update_latents: null argument"); return 1; }
     for (size_t i = 0; i < gp->L * (size_t)gp->P; i++) gp->igp[i] = params_LP[i];

@@ -47,3 +47,85 @@ def gather_latent_grads(grad_local: torch.Tensor, L: int, group=None) -> torch.T
     out = [torch.empty_like(pad) for _ in range(ws)]
     dist.all_gather(out, pad, group=group)
     return torch.cat([o[:n] for o, n in zip(out, sizes)], dim=0)
+
+
+class ShardedMOIHGP:
+    """The whole-stream pipeline of one model sharded over the ranks of a process group, one process per GPU
+    (SURVEY 8e / 8f N1).
+
+    Every rank holds the full parameter vector.  `update(params)` computes the global orthonormal factor U (the polar
+    factor of moihgp.h:433-447; redundantly on every rank: deterministic, no broadcast of 8*M*L bytes) and hands this rank's
+    latent columns U[:, lo:hi], S[lo:hi] and per-latent triples to a shard object.  `filter(Y)` then runs, per rank,
+        Ty_r   = S_r^-1/2 U_r^T Y^T          local GEMM on the replicated observation stream Y [T, M]       (moihgp.h:181)
+        sweep  over its latents               no communication                                               (ihgp.h:81-93, :204-209)
+        Yhat_r = (U_r S_r^1/2 Tyhat_r)^T      local GEMM: this rank's PARTIAL prediction [T, M]              (moihgp.h:222-225)
+    and combines  Yhat = sum_r Yhat_r  with one all-reduce of T*M elements (bandwidth-relevant: per-link bound on xGMI rings)
+    and the NLL with the 8-byte all-reduce.  The three global NLL terms of moihgp.h:653 need U U^T y, i.e. another reduction
+    of the same shape; they are evaluated from the already reduced quantities on every rank.
+    """
+
+    def __init__(self, dt, num_output, num_latent, kernel="Matern52ss", group=None):
+        from .pywrapper import MOIHGP
+        self.group = group
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        self.M, self.L = num_output, num_latent
+        self.lo, self.hi = shard_bounds(num_latent, self.world, self.rank)
+        self._full = MOIHGP(dt, num_output, num_latent, kernel=kernel)          # polar factor + bookkeeping of all parameters
+        self._shard = MOIHGP(dt, num_output, self.hi - self.lo, kernel=kernel)  # this rank's latent columns
+        self._sync_shard()
+
+    def _sync_shard(self):
+        import ctypes as C
+        import numpy as np
+        from ._lib import c_double_p, load_library
+        lib = load_library()
+        p = self._full.params
+        M, L = self.M, self.L
+        U = p[:M * L].reshape(M, L)
+        Us = np.ascontiguousarray(U[:, self.lo:self.hi])
+        Ss = np.ascontiguousarray(p[M * L + self.lo:M * L + self.hi])
+        self.sigma = float(p[M * L + L])
+        self.S = p[M * L:M * L + L].copy()
+        igp = np.ascontiguousarray(p[M * L + L + 1:].reshape(L, 3)[self.lo:self.hi])
+        if lib.moihgp_set_mixing(self._shard.handle, Us.ctypes.data_as(c_double_p), Ss.ctypes.data_as(c_double_p), C.c_double(self.sigma)):
+            raise RuntimeError("moihgp_set_mixing failed")
+        if lib.moihgp_update_latents(self._shard.handle, igp.ctypes.data_as(c_double_p)):
+            raise RuntimeError("moihgp_update_latents failed")
+
+    def update(self, params):
+        self._full.update(params)
+        self._sync_shard()
+
+    @property
+    def params(self):
+        return self._full.params
+
+    def _allreduce(self, t):
+        if self.world == 1:
+            return t
+        if t.is_cuda and dist.get_backend(self.group) == "gloo":     # CPU rehearsal of the exchange
+            c = t.cpu()
+            dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group)
+            return c.to(t.device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def filter(self, Y: torch.Tensor):
+        """Y [T, M] (CUDA, fp32/fp64, replicated on every rank).  Returns (Yhat [T, M], nll_total) where nll_total is the sum
+        over ticks of MOIHGP::negLogLikelihood(x, y) (moihgp.h:614-688) along the filtered trajectory."""
+        from .streams import LatentBank, project_stream, unproject_stream
+        T = Y.shape[0]
+        Ty = project_stream(self._shard, Y)
+        bank = LatentBank.from_handle(self._shard)
+        yhat_lat, _, nll = bank.filter(Ty, T=T)
+        part = unproject_stream(self._shard, yhat_lat, T)                 # this rank's partial prediction
+        uuty = unproject_stream(self._shard, Ty, T)                       # this rank's part of U U^T y (same GEMM shape)
+        both = self._allreduce(torch.stack([part, uuty]))                 # one collective for both [T, M] slabs
+        Yhat, UUty = both[0], both[1]
+        nll_lat = allreduce_nll(nll, self.group)
+        resid = (Y - UUty).double().norm(dim=1)                           # ||(I - U U^T) y_t||, un-squared (moihgp.h:651)
+        m_n = max(float(self.M - self.L), 0.0)
+        import math
+        glob = T * (0.5 * math.log(float(self.S.sum())) + 0.5 * m_n * math.log(self.sigma)) + 0.5 * float(resid.sum()) / self.sigma
+        return Yhat, float(nll_lat.item()) + glob
