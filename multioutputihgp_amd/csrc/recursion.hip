@@ -1,23 +1,25 @@
 // recursion.hip -- the hot path: per-latent steady-state Kalman recursion + NLL over whole
-// time streams (reference include/moihgp/ihgp.h:81-100 step, :204-222 negLogLikelihood, driven
+// time streams (reference include/moihgp/ihgp.h:81-100 step, :204-209 negLogLikelihood, driven
 // tick by tick by moihgp.h:367-373 / moihgp_online.h:61-70 / moihgp_regression.h:42-50).
 //
 // Mapping (MI355X, wave64): ONE WAVEFRONT OWNS ONE LATENT.  The latent's stream is series-major
 // (contiguous in time), so the wave reads it with fully coalesced 16-byte-per-lane loads, 64*CK
 // ticks ("segment") at a time.  Inside a segment the 64 lanes are 64 consecutive time chunks of
-// CK ticks.  The recursion x <- AKHA x + K y is linear time-invariant, so the segment is solved
-// exactly (up to rounding) in three steps without any serial walk over 64*CK ticks:
-//   1. every lane runs its CK ticks from a zero state (lane 0 from the carried-in state) -> z_j
-//   2. a 6-step Kogge-Stone scan over lanes composes the chunk maps: s_j = M s_{j-1} + z_j with
-//      M = AKHA^CK and the uniform powers M^(2^k) (per-latent constants, computed once per wave)
-//   3. every lane re-runs its CK ticks from its true start state, emitting yhat / NLL terms.
-// The per-latent matrices are wave-uniform (scalar registers); the y chunk lives in VGPRs between
-// pass 1 and pass 3, so HBM sees each stream element exactly once in and once out.
-// The coalesced <-> chunk-per-lane re-layout goes through a wave-private, padded LDS tile
-// (no workgroup barrier: the four waves of a block never communicate).
+// CK ticks.  The recursion x <- AKHA x + K y is linear time-invariant, so a segment is solved
+// exactly (up to rounding) without any serial walk over its 64*CK ticks:
+//   1. chunk response from a zero state as a CK-tap dot product z_j = sum_k g_k y_k,
+//      g_k = AKHA^(CK-1-k) K (no dependency chain); lane 0 adds M x_in, M = AKHA^CK
+//   2. inclusive scan s_j = M s_{j-1} + z_j over the 64 lanes entirely in DPP (kernels_common.h dpp_scan)
+//   3. replay of the chunk from its true start state in innovation form, emitting yhat / v^2.
+// g, M^(1,2,4,8), M^(lane%16+1) are per-latent tables written by IHGP::update (stationary.hip); the y
+// chunk lives in VGPRs between steps 1 and 3, so HBM sees each stream element exactly once in and
+// once out (filtered means leave through streaming stores).  The coalesced <-> chunk-per-lane
+// re-layout goes through a wave-private, padded LDS tile (no workgroup barrier: the four waves of a
+// block never communicate).
 //
-// Missing data (NaN y, ihgp.h:83-87: x <- A x) and the ragged tail segment make chunk maps
-// lane-dependent; those segments take the generic path that scans (M_j, z_j) pairs.
+// Missing data (NaN y, ihgp.h:83-87: x <- A x) makes chunk maps lane-dependent: generic_segment()
+// scans (M_j, z_j) pairs.  Ragged tails run the fast path with a masked replay.  With few latents
+// (L < 1024) the slices of one latent are spread over the waves of a workgroup (time split, below).
 #include "kernels_common.h"
 #include <hip/hip_ext.h>
 
