@@ -113,12 +113,14 @@ struct moihgp_gp {
     double *dU = nullptr, *dS = nullptr, *dsqrtS = nullptr, *dinvsqrtS = nullptr, *dsigma = nullptr, *dparams = nullptr, *cb64 = nullptr;
     float* cb32 = nullptr;
     // per-tick staging
-    double *dx = nullptr, *dy = nullptr, *ddx = nullptr, *dxnew = nullptr, *dyhat = nullptr, *ddxnew = nullptr;
+    double *dx = nullptr, *dy = nullptr, *ddx = nullptr;       // one device block [x | y | dx]
+    double* dpart = nullptr;                                   // [32][L] chunk partials of the per-tick projection
     double *dTy = nullptr, *dUty = nullptr, *dTyhat = nullptr, *dloss = nullptr, *dgrad = nullptr, *dscratch = nullptr;
     double* dwork = nullptr;   // L*L + L, lazily (missing-output projection)
     double* dpolar = nullptr;  // M*L + 2*L*L + 8, lazily (device polar factor)
     int* dfallback = nullptr;  // [L] flags of latents redone by the sequential gradient kernel
     bool U_host_stale = false; // the device holds a newer U than the host mirror (fetched on getParams)
+    double *hin = nullptr, *hout = nullptr, *hgrad = nullptr;   // page-locked per-tick staging (hout / hgrad are device-mapped)
     std::vector<void*> pinned; // caller buffers page-locked through moihgp_pin_host_buffer
     // window objective (moihgp_window_set / moihgp_window_eval)
     WindowBufs win{};
@@ -133,11 +135,13 @@ struct moihgp_gp {
 
 static void gp_free(moihgp_gp* g) {
     if (!g) return;
-    void* ptrs[] = {g->dU, g->dS, g->dsqrtS, g->dinvsqrtS, g->dsigma, g->dparams, g->cb64, g->cb32, g->dx, g->dy, g->ddx, g->dxnew, g->dyhat,
-                    g->ddxnew, g->dTy, g->dUty, g->dTyhat, g->dloss, g->dgrad, g->dscratch, g->dwork, g->dpolar, g->dfallback, g->dwin};
+    void* ptrs[] = {g->dU, g->dS, g->dsqrtS, g->dinvsqrtS, g->dsigma, g->dparams, g->cb64, g->cb32, g->dx, g->dpart, g->dTy, g->dUty, g->dTyhat, g->dloss, g->dgrad, g->dscratch, g->dwork, g->dpolar, g->dfallback, g->dwin};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (void* p : g->pinned) (void)hipHostUnregister(p);
+    if (g->hin) (void)hipHostFree(g->hin);
+    if (g->hout) (void)hipHostFree(g->hout);
+    if (g->hgrad) (void)hipHostFree(g->hgrad);
     for (hipEvent_t e : g->prof_ev) (void)hipEventDestroy(e);
     if (g->stream) (void)hipStreamDestroy(g->stream);
     delete g;
@@ -213,13 +217,18 @@ static moihgp_gp* gp_create(int kernel, double dt, size_t M, size_t L, bool late
         g->dsqrtS = dev_alloc<double>(L);
         g->dinvsqrtS = dev_alloc<double>(L);
         g->dsigma = dev_alloc<double>(1);
-        g->dx = dev_alloc<double>(L * g->d);
-        g->dxnew = dev_alloc<double>(L * g->d);
-        g->ddx = dev_alloc<double>(L * g->P * g->d);
-        g->ddxnew = dev_alloc<double>(L * g->P * g->d);
-        g->dy = dev_alloc<double>(M);
-        g->dyhat = dev_alloc<double>(M);
+        {   // inputs of the per-tick ABI as ONE device block [x | y | dx] (a single packed copy per call)
+            const size_t nin = L * g->d + M + L * g->P * g->d;
+            g->dx = dev_alloc<double>(nin);
+            g->dy = g->dx + L * g->d;
+            g->ddx = g->dy + M;
+            MOIHGP_HIP_FATAL(hipHostMalloc((void**)&g->hin, sizeof(double) * nin, hipHostMallocDefault));
+            MOIHGP_HIP_FATAL(hipHostMalloc((void**)&g->hout, sizeof(double) * (nin + 8), hipHostMallocMapped));
+            if (g->num_param * sizeof(double) <= (size_t)1 << 20)
+                MOIHGP_HIP_FATAL(hipHostMalloc((void**)&g->hgrad, sizeof(double) * g->num_param, hipHostMallocMapped));
+        }
         g->dTy = dev_alloc<double>(L);
+        g->dpart = dev_alloc<double>(32 * L);
         g->dUty = dev_alloc<double>(L);
         g->dTyhat = dev_alloc<double>(L);
         g->dloss = dev_alloc<double>(1);
@@ -238,10 +247,22 @@ static bool has_nan(const double* y, size_t n) {                       // moihgp
     return false;
 }
 
+// ---- per-tick staging: ONE packed host->device copy from a page-locked block [x | y | dx]; the kernels write their
+// results (xnew, yhat, dxnew, loss, and the gradient when it is small) straight into a page-locked, device-mapped host
+// block, so a call costs one async copy + the kernel launches + one stream synchronisation.
+static void stage_inputs(moihgp_gp* g, const double* x, const double* y, const double* dx) {
+    const size_t L = g->L, d = g->d, P = g->P, M = g->M;
+    double* h = g->hin;
+    std::memcpy(h, x, sizeof(double) * L * d);
+    if (y) std::memcpy(h + L * d, y, sizeof(double) * M);
+    if (dx) std::memcpy(h + L * d + M, dx, sizeof(double) * L * P * d);
+    const size_t n = L * d + M + (dx ? L * P * d : 0);           // dx sits last: skipped when absent
+    MOIHGP_HIP_FATAL(hipMemcpyAsync(g->dx, h, sizeof(double) * n, hipMemcpyHostToDevice, g->stream));
+}
+
 static void do_project(moihgp_gp* g, const double* y_host) {
-    MOIHGP_HIP_FATAL(hipMemcpyAsync(g->dy, y_host, sizeof(double) * g->M, hipMemcpyHostToDevice, g->stream));
     TickArgs a = g->tick();
-    launch_project_tick(a, g->dy, g->dTy, g->dUty, nullptr, g->stream);   // moihgp.h:181
+    launch_project_tick(a, g->dy, g->dTy, g->dUty, g->dpart, g->stream);   // moihgp.h:181
     if (has_nan(y_host, g->M)) {                                         // moihgp.h:167-178
         if (!g->dwork) g->dwork = dev_alloc<double>(g->L * g->L + g->L);
         launch_project_tick_missing(a, g->dy, g->dTy, g->dwork, g->stream);
@@ -250,34 +271,34 @@ static void do_project(moihgp_gp* g, const double* y_host) {
 
 static void do_step(moihgp_gp* g, const double* x, const double* y, const double* dx, double* xnew, double* yhat, double* dxnew) {
     if (g->latents_only) { set_last_error("per-tick ABI needs a full MOIHGP object"); std::fprintf(stderr, "%s\n", g_last_error); std::abort(); }
-    const size_t L = g->L, d = g->d, P = g->P;
-    MOIHGP_HIP_FATAL(hipMemcpyAsync(g->dx, x, sizeof(double) * L * d, hipMemcpyHostToDevice, g->stream));
-    if (dx) MOIHGP_HIP_FATAL(hipMemcpyAsync(g->ddx, dx, sizeof(double) * L * P * d, hipMemcpyHostToDevice, g->stream));
+    const size_t L = g->L, d = g->d, P = g->P, M = g->M;
+    stage_inputs(g, x, y, dx);
     if (y) do_project(g, y);
     TickArgs a = g->tick();
-    launch_step_tick(a, g->dx, y ? g->dTy : nullptr, dx ? g->ddx : nullptr, g->dxnew, g->dTyhat, dx ? g->ddxnew : nullptr, g->stream);
-    if (yhat) {
-        launch_unproject_tick(a, g->dTyhat, g->dyhat, g->stream);
-        MOIHGP_HIP_FATAL(hipMemcpyAsync(yhat, g->dyhat, sizeof(double) * g->M, hipMemcpyDeviceToHost, g->stream));
-    }
-    MOIHGP_HIP_FATAL(hipMemcpyAsync(xnew, g->dxnew, sizeof(double) * L * d, hipMemcpyDeviceToHost, g->stream));
-    if (dx && dxnew) MOIHGP_HIP_FATAL(hipMemcpyAsync(dxnew, g->ddxnew, sizeof(double) * L * P * d, hipMemcpyDeviceToHost, g->stream));
+    double* o_x = g->hout;                       // mapped host block: [xnew | yhat | dxnew | loss]
+    double* o_y = o_x + L * d;
+    double* o_dx = o_y + M;
+    launch_step_tick(a, g->dx, y ? g->dTy : nullptr, dx ? g->ddx : nullptr, o_x, g->dTyhat, dx ? o_dx : nullptr, g->stream);
+    if (yhat) launch_unproject_tick(a, g->dTyhat, o_y, g->stream);
     MOIHGP_HIP_FATAL(hipStreamSynchronize(g->stream));
+    std::memcpy(xnew, o_x, sizeof(double) * L * d);
+    if (yhat) std::memcpy(yhat, o_y, sizeof(double) * M);
+    if (dx && dxnew) std::memcpy(dxnew, o_dx, sizeof(double) * L * P * d);
 }
 
 static double do_lik(moihgp_gp* g, const double* x, const double* y, const double* dx, double* grad) {
     if (g->latents_only) { set_last_error("per-tick ABI needs a full MOIHGP object"); std::fprintf(stderr, "%s\n", g_last_error); std::abort(); }
-    const size_t L = g->L, d = g->d, P = g->P;
-    MOIHGP_HIP_FATAL(hipMemcpyAsync(g->dx, x, sizeof(double) * L * d, hipMemcpyHostToDevice, g->stream));
-    if (dx) MOIHGP_HIP_FATAL(hipMemcpyAsync(g->ddx, dx, sizeof(double) * L * P * d, hipMemcpyHostToDevice, g->stream));
+    const size_t L = g->L, d = g->d, P = g->P, M = g->M;
+    stage_inputs(g, x, y, dx);
     do_project(g, y);
     TickArgs a = g->tick();
-    launch_nll_tick(a, g->dx, g->dy, g->dTy, g->dUty, dx ? g->ddx : nullptr, g->dloss, g->dgrad, g->dscratch, g->stream);
-    double loss = 0.0;
-    MOIHGP_HIP_FATAL(hipMemcpyAsync(&loss, g->dloss, sizeof(double), hipMemcpyDeviceToHost, g->stream));
-    if (dx && grad) MOIHGP_HIP_FATAL(hipMemcpyAsync(grad, g->dgrad, sizeof(double) * g->num_param, hipMemcpyDeviceToHost, g->stream));
+    double* o_loss = g->hout + L * d + M + L * P * d;
+    const bool small_grad = g->hgrad != nullptr;                         // gradient written straight to mapped host memory
+    launch_nll_tick(a, g->dx, g->dy, g->dTy, g->dUty, dx ? g->ddx : nullptr, o_loss, small_grad ? g->hgrad : g->dgrad, g->dscratch, g->stream);
+    if (dx && grad && !small_grad) MOIHGP_HIP_FATAL(hipMemcpyAsync(grad, g->dgrad, sizeof(double) * g->num_param, hipMemcpyDeviceToHost, g->stream));
     MOIHGP_HIP_FATAL(hipStreamSynchronize(g->stream));
-    return loss;
+    if (dx && grad && small_grad) std::memcpy(grad, g->hgrad, sizeof(double) * g->num_param);
+    return *o_loss;
 }
 
 // U = polar(Uparam) (moihgp.h:433-447).  Newton-Schulz on the device (polar.hip) except for tiny matrices (M L^2 <= 2e4,

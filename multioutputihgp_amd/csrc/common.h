@@ -81,7 +81,7 @@ struct TickArgs {
     const double* invsqrtS;  // [L] S^-1/2
     const double* sigma;     // [1]
 };
-void launch_project_tick(const TickArgs& a, const double* y, double* Ty, double* Uty, int* n_nan, hipStream_t s);
+void launch_project_tick(const TickArgs& a, const double* y, double* Ty, double* Uty, double* part /* [32][L] scratch or NULL */, hipStream_t s);
 void launch_project_tick_missing(const TickArgs& a, const double* y, double* Ty, double* work /*L*L+L*/, hipStream_t s);
 void launch_step_tick(const TickArgs& a, const double* x, const double* Ty /*NULL: predict only*/, const double* dx,
                       double* xnew, double* Tyhat, double* dxnew, hipStream_t s);

@@ -22,6 +22,33 @@ __global__ void project_tick_kernel(size_t M, size_t L, const double* __restrict
     if (Ty) Ty[l] = (1.0 / sqrt(S[l])) * s;
 }
 
+// Same projection for larger M: the rows are cut into chunks handled by different workgroups (4 waves each take a quarter of
+// the chunk; lanes run over 64 consecutive latents so that every load is a coalesced 512-byte row segment); a second tiny
+// kernel adds the chunk partials in a fixed order (deterministic, no atomics).
+__global__ void __launch_bounds__(256) project_partial_kernel(size_t M, size_t L, size_t rows_per_chunk, const double* __restrict__ U,
+                                                              const double* __restrict__ y, double* __restrict__ part) {
+    __shared__ double red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const size_t l = (size_t)blockIdx.x * 64 + lane, c = blockIdx.y;
+    const size_t m0 = c * rows_per_chunk, m1 = (m0 + rows_per_chunk < M) ? m0 + rows_per_chunk : M;
+    double s = 0.0;
+    if (l < L)
+        for (size_t m = m0 + w; m < m1; m += 4) s += U[m * L + l] * y[m];
+    red[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && l < L) part[c * L + l] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+__global__ void project_finish_kernel(size_t L, size_t nchunk, const double* __restrict__ part, const double* __restrict__ S,
+                                      double* __restrict__ Ty, double* __restrict__ Uty) {
+    size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= L) return;
+    double s = 0.0;
+    for (size_t c = 0; c < nchunk; c++) s += part[c * L + l];
+    if (Uty) Uty[l] = s;
+    if (Ty) Ty[l] = (1.0 / sqrt(S[l])) * s;
+}
+
 // Normal equations over observed rows (moihgp.h:167-177): N = U0^T U0, r = U0^T y0.
 __global__ void normal_eq_kernel(size_t M, size_t L, const double* __restrict__ U, const double* __restrict__ y,
                                  double* __restrict__ N, double* __restrict__ r) {
@@ -221,8 +248,17 @@ __global__ void ugrad_kernel(size_t M, size_t L, const double* __restrict__ S, c
 
 static inline unsigned nblk(size_t n, unsigned b) { return (unsigned)((n + b - 1) / b); }
 
-void launch_project_tick(const TickArgs& a, const double* y, double* Ty, double* Uty, int* /*n_nan*/, hipStream_t s) {
-    hipLaunchKernelGGL(project_tick_kernel, dim3(nblk(a.L, 128)), dim3(128), 0, s, a.M, a.L, a.U, a.S, y, Ty, Uty);
+void launch_project_tick(const TickArgs& a, const double* y, double* Ty, double* Uty, double* part /* [32][L] scratch */, hipStream_t s) {
+    if (a.M <= 128 || !part) {
+        hipLaunchKernelGGL(project_tick_kernel, dim3(nblk(a.L, 128)), dim3(128), 0, s, a.M, a.L, a.U, a.S, y, Ty, Uty);
+    } else {
+        size_t nchunk = (a.M + 63) / 64;
+        if (nchunk > 32) nchunk = 32;
+        const size_t rpc = (a.M + nchunk - 1) / nchunk;
+        nchunk = (a.M + rpc - 1) / rpc;
+        hipLaunchKernelGGL(project_partial_kernel, dim3(nblk(a.L, 64), (unsigned)nchunk), dim3(256), 0, s, a.M, a.L, rpc, a.U, y, part);
+        hipLaunchKernelGGL(project_finish_kernel, dim3(nblk(a.L, 256)), dim3(256), 0, s, a.L, nchunk, part, a.S, Ty, Uty);
+    }
     MOIHGP_HIP_FATAL(hipGetLastError());
 }
 
