@@ -114,6 +114,8 @@ struct moihgp_gp {
     float* cb32 = nullptr;
     // per-tick staging
     double *dx = nullptr, *dy = nullptr, *ddx = nullptr;       // one device block [x | y | dx]
+    int* dunstable = nullptr;                                  // device int[2]: latents flagged unstable (fp64, fp32 blocks)
+    int n_unstable[2] = {0, 0};
     double* dpart = nullptr;                                   // [32][L] chunk partials of the per-tick projection
     double *dTy = nullptr, *dUty = nullptr, *dTyhat = nullptr, *dloss = nullptr, *dgrad = nullptr, *dscratch = nullptr;
     double* dwork = nullptr;   // L*L + L, lazily (missing-output projection)
@@ -135,7 +137,7 @@ struct moihgp_gp {
 
 static void gp_free(moihgp_gp* g) {
     if (!g) return;
-    void* ptrs[] = {g->dU, g->dS, g->dsqrtS, g->dinvsqrtS, g->dsigma, g->dparams, g->cb64, g->cb32, g->dx, g->dpart, g->dTy, g->dUty, g->dTyhat, g->dloss, g->dgrad, g->dscratch, g->dwork, g->dpolar, g->dfallback, g->dwin};
+    void* ptrs[] = {g->dU, g->dS, g->dsqrtS, g->dinvsqrtS, g->dsigma, g->dparams, g->cb64, g->cb32, g->dx, g->dpart, g->dTy, g->dUty, g->dTyhat, g->dloss, g->dgrad, g->dscratch, g->dwork, g->dpolar, g->dfallback, g->dwin, g->dunstable};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (void* p : g->pinned) (void)hipHostUnregister(p);
@@ -158,7 +160,8 @@ static void upload_mixing(moihgp_gp* g) {
 
 static void run_ihgp_update(moihgp_gp* g) {
     MOIHGP_HIP_FATAL(hipMemcpyAsync(g->dparams, g->igp.data(), sizeof(double) * g->L * g->P, hipMemcpyHostToDevice, g->stream));
-    launch_ihgp_update(g->kernel, g->d, g->dt, g->dparams, g->L, g->cb64, g->cb32, g->stream);
+    launch_ihgp_update(g->kernel, g->d, g->dt, g->dparams, g->L, g->cb64, g->cb32, g->dunstable, g->stream);
+    MOIHGP_HIP_FATAL(hipMemcpyAsync(g->n_unstable, g->dunstable, 2 * sizeof(int), hipMemcpyDeviceToHost, g->stream));
     MOIHGP_HIP_FATAL(hipStreamSynchronize(g->stream));
 }
 
@@ -202,6 +205,7 @@ static moihgp_gp* gp_create(int kernel, double dt, size_t M, size_t L, bool late
     g->cb64 = dev_alloc<double>(L * cbs);
     g->cb32 = dev_alloc<float>(L * cbs);
     g->dfallback = dev_alloc<int>(L);
+    g->dunstable = dev_alloc<int>(2);
     g->igp.resize(L * g->P);
     for (size_t l = 0; l < L; l++) {
         if (params_LP) for (int p = 0; p < g->P; p++) g->igp[l * g->P + p] = params_LP[l * g->P + p];
@@ -485,7 +489,7 @@ int moihgp_filter_stream(moihgp_gp* gp, int dtype, const void* Ty, size_t T, siz
         }
     }
     return launch_filter_stream(gp->d, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cb32, x, yhat, nll, (hipStream_t)stream, variant, e0, e1,
-                                nsplit, Tslice);
+                                nsplit, Tslice, gp->n_unstable[dtype == MOIHGP_F64 ? 0 : 1]);
 }
 
 int moihgp_profile_enable(moihgp_gp* gp, int max_launches) {

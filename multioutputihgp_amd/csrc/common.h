@@ -34,7 +34,10 @@ struct CB {
     static constexpr int G     = ITERS + 1 + P;     // [16][D]   g_k = AKHA^(CK-1-k) K, chunk response z = sum_k g_k y_k
     static constexpr int SP    = G + 16 * D;        // [4][D*D]  M^(1,2,4,8), M = AKHA^CK (in-row scan levels)
     static constexpr int PJ    = SP + 4 * D * D;    // [16][D*D] M^(r+1), r = lane % 16 (cross-row fix-up)
-    static constexpr int RAW   = PJ + 16 * D * D;
+    static constexpr int SCANOK = PJ + 16 * D * D;  // [1]  1 if every table entry is finite and tame in this block's precision, else 0:
+                                                    //      an unstable latent (rho(AKHA) > 1, possible with the reference's literal DARE) is
+                                                    //      then filtered by the exact sequential path instead of the scan
+    static constexpr int RAW   = SCANOK + 1;
     static constexpr int SIZE  = (RAW + 3) / 4 * 4; // padded to 16/32 bytes
 };
 
@@ -57,13 +60,13 @@ void set_last_error(const char* fmt, ...);
 // stationary.hip: IHGP::update for n latents.  params_dev [n][3] fp64 (device).  Writes the fp64
 // constant blocks and their fp32 copies.
 void launch_ihgp_update(int kernel, int d, double dt, const double* params_dev, size_t n,
-                        double* cb64, float* cb32, hipStream_t stream);
+                        double* cb64, float* cb32, int* n_unstable /* device int[2]: fp64 count, fp32 count */, hipStream_t stream);
 
 // recursion.hip: batched sweeps over series-major streams.
 int launch_filter_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, size_t L,
                          const double* cb64, const float* cb32, void* x, void* yhat, double* nll,
                          hipStream_t stream, int variant = 0, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
-                         int nsplit = 1, size_t Tslice = 0);
+                         int nsplit = 1, size_t Tslice = 0, int n_unstable = 0 /* latents with SCANOK == 0 in this dtype's blocks */);
 // Time split for small L (slices of one latent = wavefronts of one workgroup): nsplit == 1 means none.
 void filter_split_plan(int dtype, size_t T, size_t L, int* nsplit, size_t* Tslice);
 int launch_grad_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, size_t L,

@@ -147,6 +147,16 @@ grad_scan_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, con
 #pragma unroll
         for (int i = 0; i < D * D; i++) pj[i] = (T)acc[i];
         wave_lds_fence();
+        // unstable latent (rho(AKHA) > 1): the largest power (lane 15: M^16) has left the range where the scan is trustworthy
+        // in this precision -> leave the latent to the sequential kernel
+        const double lim = sizeof(T) == 4 ? 1e18 : 1e150;
+        bool bad = false;
+#pragma unroll
+        for (int i = 0; i < D * D; i++) bad |= !(fabs(acc[i]) < lim);
+        if (__any(bad)) {
+            if (lane == 0) fallback[l] = 1;
+            return;
+        }
     }
     static_assert((CK & (CK - 1)) == 0, "CK must be a power of two");
 

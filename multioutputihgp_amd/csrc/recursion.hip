@@ -426,6 +426,9 @@ filter_scan_kernel(const T* __restrict__ Ty, size_t Ttot, size_t ld, size_t L, c
 #pragma unroll
     for (int i = 0; i < D * D; i++) c.pj[i] = cb[Lay::PJ + (lane & 15) * D * D + i];
 
+    // An unstable latent (rho(AKHA) > 1: scan tables overflowed, flagged by IHGP::update) is left to filter_seq_kernel.
+    // Uniform over the wave, and over the workgroup in split mode (one latent per workgroup), and ahead of any barrier.
+    if (cb[Lay::SCANOK] == T(0)) return;
     const T* row = Ty + l * ld + toff;
     T* orow = WRITE ? yhat + l * ld + toff : nullptr;
     T xin[D];
@@ -514,9 +517,53 @@ filter_scan_kernel(const T* __restrict__ Ty, size_t Ttot, size_t ld, size_t L, c
     }
 }
 
+// Exact sequential filter for the latents flagged unstable (SCANOK == 0): one lane per latent, tick by tick in innovation
+// form (identical in meaning to ihgp.h:81-93 / :204-209, missing ticks included), stream fetched in 16-byte vectors.
+// Launched only when IHGP::update reported such latents; every other lane exits at once.
+template <typename T, int D>
+__global__ void __launch_bounds__(64)
+filter_seq_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, const T* __restrict__ cbT, const double* __restrict__ cb64,
+                  T* __restrict__ x, T* __restrict__ yhat, double* __restrict__ nll) {
+    using V = typename VecOf<T>::type;
+    using Lay = CB<D>;
+    constexpr int EPV = 16 / sizeof(T);
+    const size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= L) return;
+    const T* cb = cbT + l * Lay::SIZE;
+    if (cb[Lay::SCANOK] != T(0)) return;
+    T a[D * D], kk[D], xs[D];
+    for (int i = 0; i < D * D; i++) a[i] = cb[Lay::A + i];
+    for (int i = 0; i < D; i++) { kk[i] = cb[Lay::K + i]; xs[i] = x[l * D + i]; }
+    double acc = 0.0, n = 0.0;
+    const T* row = Ty + l * ld;
+    for (size_t tb = 0; tb < Tlen; tb += EPV) {
+        T yv[EPV];
+        unpack<T>(*reinterpret_cast<const V*>(row + tb), yv);
+        for (int e = 0; e < EPV && tb + e < Tlen; e++) {
+            const T yk = yv[e];
+            const bool miss = (yk != yk);
+            T hx = 0;
+            for (int q = 0; q < D; q++) hx = fma(a[q], xs[q], hx);
+            const T v = miss ? T(0) : yk - hx;
+            if (!miss) { acc = fma((double)v, (double)v, acc); n += 1.0; }
+            T xn[D];
+            xn[0] = fma(kk[0], v, hx);
+            for (int i = 1; i < D; i++) {
+                T s = kk[i] * v;
+                for (int q = 0; q < D; q++) s = fma(a[i * D + q], xs[q], s);
+                xn[i] = s;
+            }
+            for (int i = 0; i < D; i++) xs[i] = xn[i];
+            if (yhat) yhat[l * ld + tb + e] = xs[0];
+        }
+    }
+    for (int i = 0; i < D; i++) x[l * D + i] = xs[i];
+    if (nll) { const double* c64 = cb64 + l * Lay::SIZE; nll[l] = 0.5 * (acc / c64[Lay::S] + n * c64[Lay::LOGS]); }
+}
+
 template <typename T, int D, int CK, int MINW, bool SPLIT>
 int launch_filter_t(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, const double* cb64, void* x,
-                    void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, int nsplit, size_t Tslice) {
+                    void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, int nsplit, size_t Tslice, int n_unstable) {
     dim3 block(SPLIT ? 64 * nsplit : 64 * kWavesPerBlock);
     dim3 grid(SPLIT ? (unsigned)L : (unsigned)((L + kWavesPerBlock - 1) / kWavesPerBlock));
     constexpr size_t tile = 64 * (CK / (16 / sizeof(T)) + 1) * 16;                    // padded LDS tile per wave
@@ -534,6 +581,8 @@ int launch_filter_t(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* c
         hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, false, true, MINW, SPLIT>), grid, block, smem, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xs, yh, nll, nsplit, Tslice);
     else
         hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, false, false, MINW, SPLIT>), grid, block, smem, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xs, yh, nll, nsplit, Tslice);
+    if (n_unstable > 0)
+        hipLaunchKernelGGL((filter_seq_kernel<T, D>), dim3((unsigned)((L + 63) / 64)), dim3(64), 0, stream, ty, Tlen, ld, L, cbT, cb64, xs, yh, nll);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_last_error("filter_scan_kernel launch: %s", hipGetErrorString(e)); return 2; }
     return 0;
@@ -558,13 +607,13 @@ void filter_split_plan(int dtype, size_t T, size_t L, int* nsplit, size_t* Tslic
 
 int launch_filter_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* cb64,
                          const float* cb32, void* x, void* yhat, double* nll, hipStream_t stream, int variant,
-                         hipEvent_t ev0, hipEvent_t ev1, int nsplit, size_t Tslice) {
+                         hipEvent_t ev0, hipEvent_t ev1, int nsplit, size_t Tslice, int n_unstable) {
     if (L == 0) return 0;
     if (nsplit > kMaxSplit) { set_last_error("nsplit > %d", kMaxSplit); return 1; }
 #define MOIHGP_FILTER_CASE(TT, DD, CKK, MW, CB)                                                                                   \
     do {                                                                                                                          \
-        if (nsplit > 1) return launch_filter_t<TT, DD, CKK, 1, true>(Ty, T, ld, L, CB, cb64, x, yhat, nll, stream, ev0, ev1, nsplit, Tslice); \
-        return launch_filter_t<TT, DD, CKK, MW, false>(Ty, T, ld, L, CB, cb64, x, yhat, nll, stream, ev0, ev1, 1, T);             \
+        if (nsplit > 1) return launch_filter_t<TT, DD, CKK, 1, true>(Ty, T, ld, L, CB, cb64, x, yhat, nll, stream, ev0, ev1, nsplit, Tslice, n_unstable); \
+        return launch_filter_t<TT, DD, CKK, MW, false>(Ty, T, ld, L, CB, cb64, x, yhat, nll, stream, ev0, ev1, 1, T, n_unstable);             \
     } while (0)
     // register caps: fp32 <= 128 VGPRs (4 waves/SIMD: all 4096 wavefronts of a 4096-latent shard resident),
     // fp64 uncapped (188 VGPRs, 2 waves/SIMD: capping it to 168 spills and is 35 % slower)

@@ -260,7 +260,8 @@ __device__ int dlyap(const double* Ad, const double* Q, double* P) {
 
 template <int D>
 __global__ void __launch_bounds__(64) ihgp_update_kernel(int kernel, double dt, const double* __restrict__ params,
-                                                         size_t n, double* __restrict__ cb64, float* __restrict__ cb32) {
+                                                         size_t n, double* __restrict__ cb64, float* __restrict__ cb32,
+                                                         int* __restrict__ n_unstable) {
     using L = CB<D>;
     constexpr int P = kNumIgpParam, NN = D * D;
     size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -410,6 +411,12 @@ __global__ void __launch_bounds__(64) ihgp_update_kernel(int kernel, double dt, 
             for (int i = 0; i < NN; i++) PJ[r * NN + i] = Pw[i];
             mm<D>(Pw, M, Pw);
         }
+        // scan usable?  every entry finite and far from the overflow threshold of the block's precision
+        const double lim = pass == 0 ? 1e150 : 1e18;
+        bool ok = true;
+        for (int i = 0; i < L::SCANOK - L::G; i++) ok = ok && (fabs(tab[i]) < lim);      // false for NaN too
+        tab[L::SCANOK - L::G] = ok ? 1.0 : 0.0;
+        if (!ok) atomicAdd(&n_unstable[pass], 1);
         if (pass == 0) for (int i = 0; i < L::SIZE - L::G; i++) o64[L::G + i] = tab[i];
         else for (int i = 0; i < L::SIZE - L::G; i++) o32[L::G + i] = (float)tab[i];
     }
@@ -418,13 +425,14 @@ __global__ void __launch_bounds__(64) ihgp_update_kernel(int kernel, double dt, 
 }  // namespace
 
 void launch_ihgp_update(int kernel, int d, double dt, const double* params_dev, size_t n, double* cb64, float* cb32,
-                        hipStream_t stream) {
+                        int* n_unstable, hipStream_t stream) {
     if (n == 0) return;
+    MOIHGP_HIP_FATAL(hipMemsetAsync(n_unstable, 0, 2 * sizeof(int), stream));
     dim3 block(64), grid((unsigned)((n + 63) / 64));
     if (d == 2)
-        hipLaunchKernelGGL(ihgp_update_kernel<2>, grid, block, 0, stream, kernel, dt, params_dev, n, cb64, cb32);
+        hipLaunchKernelGGL(ihgp_update_kernel<2>, grid, block, 0, stream, kernel, dt, params_dev, n, cb64, cb32, n_unstable);
     else
-        hipLaunchKernelGGL(ihgp_update_kernel<3>, grid, block, 0, stream, kernel, dt, params_dev, n, cb64, cb32);
+        hipLaunchKernelGGL(ihgp_update_kernel<3>, grid, block, 0, stream, kernel, dt, params_dev, n, cb64, cb32, n_unstable);
     MOIHGP_HIP_FATAL(hipGetLastError());
 }
 

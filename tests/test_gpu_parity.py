@@ -470,3 +470,43 @@ def test_sharded_pipeline_two_ranks_vs_oracle(env, M, L, T):
         nll += ref.negLogLikelihood(x, Y[t])
         x, yh[t] = ref.step(x, Y[t])
     assert rel_err(Yhat0, yh) < 1e-9 and abs(nll0 - nll) < 1e-9 * abs(nll)
+
+
+# ------------------------------------------------------------------------------------------ unstable latents (literal DARE quirk)
+@pytest.mark.parametrize("dtype,T", [(torch.float64, 1500), (torch.float32, 150)])
+@pytest.mark.parametrize("split", ["1", "0"])
+def test_unstable_latents_take_the_sequential_path(env, dtype, T, split, monkeypatch):
+    """With the reference's literal DARE (utils/dare.h:23, A un-transposed) parts of the learner's own parameter box give
+    rho(AKHA) > 1.  The recursion then grows like rho^t; the scan tables would overflow, so such latents are flagged at
+    update() and filtered sequentially.  Results must still equal the oracle's tick loop while they are finite."""
+    if split == "1":
+        monkeypatch.setenv("MOIHGP_FILTER_SPLIT", "1")
+    else:
+        monkeypatch.delenv("MOIHGP_FILTER_SPLIT", raising=False)
+    prm = np.array([[99.2440457, 4.06889466, 2.55306111e-03],      # rho(AKHA) = 1.47 (Matern-3/2, dt = 0.1)
+                    [1.0, 1.0, 0.1],                                 # stable
+                    [0.927049235, 1.63239037, 4.34082530e-04],      # rho = 1.17
+                    [66.2316497, 5.1761023, 1.51666229e-03]])       # rho = 1.37
+    L = prm.shape[0]
+    igps = env["cref"].ihgp_array("Matern32", 0.1, prm)
+    assert max(abs(np.linalg.eigvals(igps[0].mat("AKHA")))) > 1.4
+    rng = np.random.default_rng(3)
+    Ty = synth(L, T, rng, 0.02)
+    bank = env["streams"].LatentBank(0.1, prm, kernel="Matern32")
+    o = env["cref"].filter_stream(igps, Ty)
+    yhat, xT, nll = bank.filter(to_dev(Ty, dtype), T=T)
+    torch.cuda.synchronize()
+    yh = yhat[:, :T].cpu().numpy().astype(np.float64)
+    assert np.all(np.isfinite(yh)) and np.all(np.isfinite(o["yhat"]))
+    tol = 1e-9 if dtype == torch.float64 else 2e-3
+    for l in range(L):          # per latent: magnitudes differ by hundreds of orders
+        assert rel_err(yh[l], o["yhat"][l]) < tol, l
+        a, b = nll[l].item(), o["nll_per_latent"][l]
+        assert (np.isinf(a) and np.isinf(b)) or abs(a - b) < tol * abs(b), l      # v^2 overflows for rho^t ~ 1e250: inf on both sides
+    # gradient sweep: unstable latents go to the sequential kernel
+    og = env["cref"].grad_stream(igps, Ty[:, :120])
+    r = bank.grad(to_dev(Ty[:, :120], dtype), T=120)
+    torch.cuda.synchronize()
+    g = r["grad"].cpu().numpy()
+    for l in range(L):
+        assert rel_err(g[l], og["grad"][l]) < (1e-8 if dtype == torch.float64 else 5e-3), l
