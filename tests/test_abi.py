@@ -71,3 +71,13 @@ def test_reference_pywrapper_binds_only_symbols_we_export(hip_built):
     assert len(names) == 26
     lib = C.CDLL(hip_built)
     assert all(hasattr(lib, n) for n in names)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """No HIP library -> no product: the loader raises instead of falling back to anything."""
+    from multioutputihgp_amd import _lib
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(_lib, "_HERE", str(tmp_path))
+    with pytest.raises(_lib.MoihgpError) as ei:
+        _lib.load_library()
+    assert "no CPU fallback" in str(ei.value)
