@@ -23,7 +23,11 @@
 namespace moihgp {
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 16, LDT = BM + 16;
+constexpr int BM = 128, BN = 128, LDT = BM + 16;
+#ifndef MOIHGP_GEMM_BK
+#define MOIHGP_GEMM_BK 32
+#endif
+constexpr int BK = MOIHGP_GEMM_BK, KH = BK / 16;   // k-depth of a tile; staged as KH slabs of 16
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef float float4_t __attribute__((ext_vector_type(4)));
@@ -60,7 +64,9 @@ template <> __device__ inline void load8<float, float>(const float* p, float* o)
     for (int v = 0; v < 2; v++) { float4 t = q[v]; o[4 * v] = t.x; o[4 * v + 1] = t.y; o[4 * v + 2] = t.z; o[4 * v + 3] = t.w; }
 }
 
-template <typename TC, typename TA, typename TB, bool A_ICONTIG, bool B_KCONTIG>
+// SYM: the product is symmetric (Gram matrix X^T X): only tiles on or above the diagonal are computed; mirror_upper_kernel
+// fills the lower triangle afterwards with coalesced reads and writes.
+template <typename TC, typename TA, typename TB, bool A_ICONTIG, bool B_KCONTIG, bool SYM = false>
 __global__ void __launch_bounds__(256)
 gemm_mfma_kernel(size_t Mi, size_t Nj, size_t Kk, const TA* __restrict__ A, size_t lda, const TB* __restrict__ B, size_t ldb,
                  TC* __restrict__ C, size_t ldc, const double* __restrict__ rs, int rs_mode, const double* __restrict__ ks, int ks_mode,
@@ -68,18 +74,28 @@ gemm_mfma_kernel(size_t Mi, size_t Nj, size_t Kk, const TA* __restrict__ A, size
     __shared__ TC As[BK][LDT];
     __shared__ TC Bs[BK][LDT];
     // ---- XCD-aware tile order: workgroups b, b+8, b+16.. share an XCD; give each XCD a contiguous run of tiles ----
-    const unsigned nwg = tiles_m * tiles_n;
+    const unsigned nwg = SYM ? tiles_m * (tiles_m + 1) / 2 : tiles_m * tiles_n;
     unsigned bid = blockIdx.x;
     {
         const unsigned q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    // column-panel order with groups of 8 row tiles (keeps a B panel and 8 A panels hot in L2)
-    constexpr unsigned GROUP = 8;
-    const unsigned per_group = GROUP * tiles_n;
-    const unsigned g = bid / per_group, first_m = g * GROUP;
-    const unsigned gsz = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
-    const unsigned tm = first_m + (bid % per_group) % gsz, tn = (bid % per_group) / gsz;
+    unsigned tm, tn;
+    if (SYM) {
+        // only tiles on or above the diagonal exist: row tm holds tiles_m - tm of them
+        tm = 0;
+        unsigned rem = bid;
+        while (rem >= tiles_m - tm) { rem -= tiles_m - tm; tm++; }
+        tn = tm + rem;
+    } else {
+        // column-panel order with groups of 8 row tiles (keeps a B panel and 8 A panels hot in L2)
+        constexpr unsigned GROUP = 8;
+        const unsigned per_group = GROUP * tiles_n;
+        const unsigned g = bid / per_group, first_m = g * GROUP;
+        const unsigned gsz = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+        tm = first_m + (bid % per_group) % gsz;
+        tn = (bid % per_group) / gsz;
+    }
     const size_t i0 = (size_t)tm * BM, j0 = (size_t)tn * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -93,88 +109,95 @@ gemm_mfma_kernel(size_t Mi, size_t Nj, size_t Kk, const TA* __restrict__ A, size
 #pragma unroll
             for (int r = 0; r < 4; r++) acc[a][b][r] = 0;
 
-    // register staging of one 128 x 16 tile of each operand: 8 elements per thread each, contiguous in memory
-    // (along i / j for the *-contiguous layouts, along k otherwise).  Interior tiles take 16-byte vector loads.
-    TC ra[8], rb[8];
+    // register staging of one 128 x BK tile of each operand as KH slabs of 16 in k: 8 elements per thread and slab, contiguous
+    // in memory (along i / j for the *-contiguous layouts, along k otherwise).  Interior tiles take 16-byte vector loads.
+    TC ra[KH][8], rb[KH][8];
     const bool a_vec = ((uintptr_t)A % 16 == 0) && (lda % (16 / sizeof(TA)) == 0);
     const bool b_vec = ((uintptr_t)B % 16 == 0) && (ldb % (16 / sizeof(TB)) == 0);
     const bool i_full = i0 + BM <= Mi, j_full = j0 + BN <= Nj;
-    auto fetch = [&](size_t k0) {
-        const bool k_full = k0 + BK <= Kk;
-        if (A_ICONTIG) {      // rows of As are contiguous in memory: thread -> (k = tid / 16, 8 consecutive i)
-            const int kk = tid >> 4, ii = (tid & 15) * 8;
-            const size_t gk = k0 + kk;
-            if (a_vec && i_full && k_full) load8<TA, TC>(A + gk * lda + i0 + ii, ra);
-            else {
+    auto fetch = [&](size_t kt) {
+        const bool k_full = kt + BK <= Kk;
 #pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    const size_t gi = i0 + ii + e;
-                    ra[e] = (gk < Kk && gi < Mi) ? (TC)A[gk * lda + gi] : TC(0);
+        for (int h = 0; h < KH; h++) {
+            const size_t k0 = kt + 16 * h;
+            if (A_ICONTIG) {      // rows of As are contiguous in memory: thread -> (k = tid / 16, 8 consecutive i)
+                const int kk = tid >> 4, ii = (tid & 15) * 8;
+                const size_t gk = k0 + kk;
+                if (a_vec && i_full && k_full) load8<TA, TC>(A + gk * lda + i0 + ii, ra[h]);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const size_t gi = i0 + ii + e;
+                        ra[h][e] = (gk < Kk && gi < Mi) ? (TC)A[gk * lda + gi] : TC(0);
+                    }
+                }
+            } else {              // A(i,k) = A[i*lda + k]: thread -> (i = tid / 2, 8 consecutive k)
+                const int ii = tid >> 1, kk = (tid & 1) * 8;
+                const size_t gi = i0 + ii;
+                if (a_vec && i_full && k_full) load8<TA, TC>(A + gi * lda + k0 + kk, ra[h]);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const size_t gk = k0 + kk + e;
+                        ra[h][e] = (gk < Kk && gi < Mi) ? (TC)A[gi * lda + gk] : TC(0);
+                    }
                 }
             }
-        } else {              // A(i,k) = A[i*lda + k]: thread -> (i = tid / 2, 8 consecutive k)
-            const int ii = tid >> 1, kk = (tid & 1) * 8;
-            const size_t gi = i0 + ii;
-            if (a_vec && i_full && k_full) load8<TA, TC>(A + gi * lda + k0 + kk, ra);
-            else {
+            if (B_KCONTIG) {      // B(k,j) = B[j*ldb + k]: thread -> (j = tid / 2, 8 consecutive k)
+                const int jj = tid >> 1, kk = (tid & 1) * 8;
+                const size_t gj = j0 + jj;
+                if (b_vec && j_full && k_full) load8<TB, TC>(B + gj * ldb + k0 + kk, rb[h]);
+                else {
 #pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    const size_t gk = k0 + kk + e;
-                    ra[e] = (gk < Kk && gi < Mi) ? (TC)A[gi * lda + gk] : TC(0);
+                    for (int e = 0; e < 8; e++) {
+                        const size_t gk = k0 + kk + e;
+                        rb[h][e] = (gk < Kk && gj < Nj) ? (TC)B[gj * ldb + gk] : TC(0);
+                    }
                 }
-            }
-        }
-        if (B_KCONTIG) {      // B(k,j) = B[j*ldb + k]: thread -> (j = tid / 2, 8 consecutive k)
-            const int jj = tid >> 1, kk = (tid & 1) * 8;
-            const size_t gj = j0 + jj;
-            if (b_vec && j_full && k_full) load8<TB, TC>(B + gj * ldb + k0 + kk, rb);
-            else {
+                if (ks_mode == 1) {
 #pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    const size_t gk = k0 + kk + e;
-                    rb[e] = (gk < Kk && gj < Nj) ? (TC)B[gj * ldb + gk] : TC(0);
+                    for (int e = 0; e < 8; e++) { const size_t gk = k0 + kk + e; if (gk < Kk) rb[h][e] *= (TC)ks[gk]; }
                 }
-            }
-            if (ks_mode == 1) {
+            } else {              // B(k,j) = B[k*ldb + j]: thread -> (k = tid / 16, 8 consecutive j)
+                const int kk = tid >> 4, jj = (tid & 15) * 8;
+                const size_t gk = k0 + kk;
+                if (b_vec && j_full && k_full) load8<TB, TC>(B + gk * ldb + j0 + jj, rb[h]);
+                else {
 #pragma unroll
-                for (int e = 0; e < 8; e++) { const size_t gk = k0 + kk + e; if (gk < Kk) rb[e] *= (TC)ks[gk]; }
-            }
-        } else {              // B(k,j) = B[k*ldb + j]: thread -> (k = tid / 16, 8 consecutive j)
-            const int kk = tid >> 4, jj = (tid & 15) * 8;
-            const size_t gk = k0 + kk;
-            if (b_vec && j_full && k_full) load8<TB, TC>(B + gk * ldb + j0 + jj, rb);
-            else {
-#pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    const size_t gj = j0 + jj + e;
-                    rb[e] = (gk < Kk && gj < Nj) ? (TC)B[gk * ldb + gj] : TC(0);
+                    for (int e = 0; e < 8; e++) {
+                        const size_t gj = j0 + jj + e;
+                        rb[h][e] = (gk < Kk && gj < Nj) ? (TC)B[gk * ldb + gj] : TC(0);
+                    }
                 }
-            }
-            if (ks_mode == 1 && gk < Kk) {
-                const TC sc = (TC)ks[gk];
+                if (ks_mode == 1 && gk < Kk) {
+                    const TC sc = (TC)ks[gk];
 #pragma unroll
-                for (int e = 0; e < 8; e++) rb[e] *= sc;
+                    for (int e = 0; e < 8; e++) rb[h][e] *= sc;
+                }
             }
         }
     };
     auto stash = [&]() {
-        if (A_ICONTIG) {
-            const int kk = tid >> 4, ii = (tid & 15) * 8;
 #pragma unroll
-            for (int e = 0; e < 8; e++) As[kk][ii + e] = ra[e];
-        } else {
-            const int ii = tid >> 1, kk = (tid & 1) * 8;
+        for (int h = 0; h < KH; h++) {
+            if (A_ICONTIG) {
+                const int kk = 16 * h + (tid >> 4), ii = (tid & 15) * 8;
 #pragma unroll
-            for (int e = 0; e < 8; e++) As[kk + e][ii] = ra[e];
-        }
-        if (B_KCONTIG) {
-            const int jj = tid >> 1, kk = (tid & 1) * 8;
+                for (int e = 0; e < 8; e++) As[kk][ii + e] = ra[h][e];
+            } else {
+                const int ii = tid >> 1, kk = 16 * h + (tid & 1) * 8;
 #pragma unroll
-            for (int e = 0; e < 8; e++) Bs[kk + e][jj] = rb[e];
-        } else {
-            const int kk = tid >> 4, jj = (tid & 15) * 8;
+                for (int e = 0; e < 8; e++) As[kk + e][ii] = ra[h][e];
+            }
+            if (B_KCONTIG) {
+                const int jj = tid >> 1, kk = 16 * h + (tid & 1) * 8;
 #pragma unroll
-            for (int e = 0; e < 8; e++) Bs[kk][jj + e] = rb[e];
+                for (int e = 0; e < 8; e++) Bs[kk + e][jj] = rb[h][e];
+            } else {
+                const int kk = 16 * h + (tid >> 4), jj = (tid & 15) * 8;
+#pragma unroll
+                for (int e = 0; e < 8; e++) Bs[kk][jj + e] = rb[h][e];
+            }
         }
     };
 
@@ -211,17 +234,41 @@ gemm_mfma_kernel(size_t Mi, size_t Nj, size_t Kk, const TA* __restrict__ A, size
 #pragma unroll
             for (int b = 0; b < 4; b++) {
                 const size_t gj = j0 + wn * 64 + b * 16 + (lane & 15);
-                if (gj < Nj) C[gi * ldc + gj] = scale * acc[a][b][r];
+                if (gj < Nj) {
+                    C[gi * ldc + gj] = scale * acc[a][b][r];
+                }
             }
         }
 }
 
-template <typename TC, typename TA, typename TB, bool AI, bool BK_>
+// G[j][i] = G[i][j] for the 128 x 128 tiles strictly above the diagonal: 32 x 32 sub-tiles transposed through LDS.
+__global__ void __launch_bounds__(256) mirror_upper_kernel(double* __restrict__ G, size_t L, unsigned tiles) {
+    __shared__ double t[32][33];
+    const unsigned tm = blockIdx.y, tn = blockIdx.x;
+    if (tn <= tm) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8 threads
+    for (int si = 0; si < 4; si++)
+        for (int sj = 0; sj < 4; sj++) {
+            const size_t i0 = (size_t)tm * BM + si * 32, j0 = (size_t)tn * BN + sj * 32;
+            for (int r = ty; r < 32; r += 8) {
+                const size_t i = i0 + r, j = j0 + tx;
+                t[r][tx] = (i < L && j < L) ? G[i * L + j] : 0.0;
+            }
+            __syncthreads();
+            for (int r = ty; r < 32; r += 8) {
+                const size_t j = j0 + r, i = i0 + tx;
+                if (i < L && j < L) G[j * L + i] = t[tx][r];
+            }
+            __syncthreads();
+        }
+}
+
+template <typename TC, typename TA, typename TB, bool AI, bool BK_, bool SYM = false>
 int launch(size_t Mi, size_t Nj, size_t Kk, const TA* A, size_t lda, const TB* B, size_t ldb, TC* C, size_t ldc, const double* rs,
            int rs_mode, const double* ks, int ks_mode, hipStream_t s) {
     const unsigned tm = (unsigned)((Mi + BM - 1) / BM), tn = (unsigned)((Nj + BN - 1) / BN);
     if (tm == 0 || tn == 0) return 0;
-    hipLaunchKernelGGL((gemm_mfma_kernel<TC, TA, TB, AI, BK_>), dim3(tm * tn), dim3(256), 0, s, Mi, Nj, Kk, A, lda, B, ldb, C, ldc, rs,
+    hipLaunchKernelGGL((gemm_mfma_kernel<TC, TA, TB, AI, BK_, SYM>), dim3(SYM ? tm * (tm + 1) / 2 : tm * tn), dim3(256), 0, s, Mi, Nj, Kk, A, lda, B, ldb, C, ldc, rs,
                        rs_mode, ks, ks_mode, tm, tn);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_last_error("gemm_mfma launch: %s", hipGetErrorString(e)); return 2; }
@@ -261,7 +308,10 @@ int launch_ugrad_gemm(const double* Y, size_t W, size_t M, const double* Z, size
 
 // G[a][b] = sum_m X[m][a] X[m][b]  (X is M x L row-major):  A i-contiguous (lda = L), B j-contiguous (ldb = L)
 int launch_gram(const double* X, size_t M, size_t L, double* G, hipStream_t s) {
-    return launch<double, double, double, true, false>(L, L, M, X, L, X, L, G, L, nullptr, 0, nullptr, 0, s);
+    if (int rc = launch<double, double, double, true, false, true>(L, L, M, X, L, X, L, G, L, nullptr, 0, nullptr, 0, s)) return rc;   // upper tiles only
+    const unsigned tiles = (unsigned)((L + BM - 1) / BM);
+    if (tiles > 1) hipLaunchKernelGGL(mirror_upper_kernel, dim3(tiles, tiles), dim3(256), 0, s, G, L, tiles);
+    return 0;
 }
 
 // C[m][b] = sum_a X[m][a] W[a][b]  (X M x L, W L x L, row-major):  A k-contiguous (lda = L), B j-contiguous (ldb = L)
