@@ -83,6 +83,13 @@ size_t gp52_num_igp_param(moihgp_gp* gp);
 /* ------------------------------------------------------------------ Part 2: additive ABI */
 enum { MOIHGP_MATERN32 = 0, MOIHGP_MATERN52 = 1 };
 enum { MOIHGP_F64 = 0, MOIHGP_F32 = 1 };
+/* Stacked state: the sum of J Matern components observed through one output (state dim J*2 or J*3 up to 12; BASELINE.json's
+ * d = 6 / d = 12 shapes).  The reference ships no such model; it is what its IHGP<StateSpace> template (ihgp.h:17-35)
+ * computes for a StateSpace with F, Pinf block-diagonal in the reference's component models and H = [H_1 .. H_J].
+ * J in {2, 3, 4}.  Hyper-parameters per latent: [magnitude_1, lengthscale_1, .., magnitude_J, lengthscale_J, noise]
+ * (P = 2J + 1).  Accepted by moihgp_new_latents / moihgp_update_latents / moihgp_filter_stream / moihgp_get_latent
+ * (filter mode: no sensitivities, so moihgp_grad_stream and the full-object entries refuse it). */
+#define MOIHGP_STACK(base, J) ((base) | ((J) << 4))
 
 /* Thread-local message of the last failure ("" if none). */
 const char* moihgp_last_error(void);
@@ -104,9 +111,9 @@ void        moihgp_reseed_U(moihgp_gp* gp, unsigned long long seed);
 
 /* Latent-sharded construction: the object owns latents [l0, l0+nl) only and takes only
  * their (magnitude, lengthscale, noise) triples; no mixing matrix.  Used by one rank per GPU.
- * params_LP is a HOST array [nl][3]. */
+ * params_LP is a HOST array [nl][P], P = 3 (2J + 1 for a stacked kernel). */
 moihgp_gp*  moihgp_new_latents(int kernel, double dt, size_t num_latent_local, const double* params_LP);
-/* Re-run IHGP::update (ihgp.h:117-201) for every owned latent from HOST params [nl][3]. */
+/* Re-run IHGP::update (ihgp.h:117-201) for every owned latent from HOST params [nl][P]. */
 int         moihgp_update_latents(moihgp_gp* gp, const double* params_LP);
 
 /* Set the mixing of a full object directly, WITHOUT the polar-factor step of update() (moihgp.h:433-447): U [M][L] row-major,

@@ -160,7 +160,8 @@ static void upload_mixing(moihgp_gp* g) {
 
 static void run_ihgp_update(moihgp_gp* g) {
     MOIHGP_HIP_FATAL(hipMemcpyAsync(g->dparams, g->igp.data(), sizeof(double) * g->L * g->P, hipMemcpyHostToDevice, g->stream));
-    launch_ihgp_update(g->kernel, g->d, g->dt, g->dparams, g->L, g->cb64, g->cb32, g->dunstable, g->stream);
+    if (kernel_stack(g->kernel)) launch_stack_update(g->kernel, g->dt, g->dparams, g->L, g->cb64, g->cb32, g->dunstable, g->stream);
+    else launch_ihgp_update(g->kernel, g->d, g->dt, g->dparams, g->L, g->cb64, g->cb32, g->dunstable, g->stream);
     MOIHGP_HIP_FATAL(hipMemcpyAsync(g->n_unstable, g->dunstable, 2 * sizeof(int), hipMemcpyDeviceToHost, g->stream));
     MOIHGP_HIP_FATAL(hipStreamSynchronize(g->stream));
 }
@@ -188,7 +189,12 @@ static moihgp_gp* gp_create(int kernel, double dt, size_t M, size_t L, bool late
         std::fprintf(stderr, "%s\n", g_last_error);
         return nullptr;
     }
-    if (kernel != MOIHGP_MATERN32 && kernel != MOIHGP_MATERN52) { set_last_error("unknown kernel id %d", kernel); return nullptr; }
+    const int kbase = kernel_base(kernel), kstack = kernel_stack(kernel);
+    if ((kbase != MOIHGP_MATERN32 && kbase != MOIHGP_MATERN52) || kstack == 1 || kstack > 4) { set_last_error("unknown kernel id %d", kernel); return nullptr; }
+    if (kstack && !latents_only) {
+        set_last_error("stacked kernels are filter-mode latent banks (moihgp_new_latents); the mixing of a full object does not depend on the kernel");
+        return nullptr;
+    }
     if (L == 0) { set_last_error("num_latent must be >= 1"); return nullptr; }
     if (!latents_only && M < L) {
         // moihgp.h:510 indexes y(idx) for idx < num_latent and the thin SVD needs full column rank
@@ -197,10 +203,11 @@ static moihgp_gp* gp_create(int kernel, double dt, size_t M, size_t L, bool late
     }
     moihgp_gp* g = new moihgp_gp();
     g->kernel = kernel; g->dt = dt; g->M = M; g->L = L; g->latents_only = latents_only;
-    g->d = (kernel == MOIHGP_MATERN32) ? 2 : 3;                          // matern32ss.h:95, matern52ss.h:106
+    g->d = (kbase == MOIHGP_MATERN32) ? 2 : 3;                           // matern32ss.h:95, matern52ss.h:106
+    if (kstack) { g->d *= kstack; g->P = 2 * kstack + 1; }               // (magnitude_j, lengthscale_j) x J, noise
     g->num_param = M * L + L + 1 + L * g->P;                             // moihgp.h:93
     MOIHGP_HIP_FATAL(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
-    const size_t cbs = (size_t)cb_size(g->d);
+    const size_t cbs = kstack ? (size_t)xc_size(g->d) : (size_t)cb_size(g->d);
     g->dparams = dev_alloc<double>(L * g->P);
     g->cb64 = dev_alloc<double>(L * cbs);
     g->cb32 = dev_alloc<float>(L * cbs);
@@ -209,6 +216,7 @@ static moihgp_gp* gp_create(int kernel, double dt, size_t M, size_t L, bool late
     g->igp.resize(L * g->P);
     for (size_t l = 0; l < L; l++) {
         if (params_LP) for (int p = 0; p < g->P; p++) g->igp[l * g->P + p] = params_LP[l * g->P + p];
+        else if (kstack) { for (int j = 0; j < kstack; j++) { g->igp[l * g->P + 2 * j] = 1.0; g->igp[l * g->P + 2 * j + 1] = (double)(j + 1); } g->igp[l * g->P + 2 * kstack] = 0.1; }
         else { g->igp[l * g->P + 0] = 1.0; g->igp[l * g->P + 1] = 1.0; g->igp[l * g->P + 2] = 0.1; }   // matern32ss.h:34-36
     }
     if (!latents_only) {
@@ -436,7 +444,20 @@ int moihgp_update_latents(moihgp_gp* gp, const double* params_LP) {
 int moihgp_get_latent(moihgp_gp* gp, size_t l, double* A, double* K, double* S, double* HA, double* AKHA, double* dA,
                       double* dS, double* dK, double* dAKHA, double* HdA, int* iters) {
     if (!gp || l >= gp->L) { set_last_error("get_latent: bad latent index"); return 1; }
-    const int d = gp->d, P = gp->P, cbs = cb_size(d);
+    const int d = gp->d, P = gp->P;
+    if (kernel_stack(gp->kernel)) {
+        if (dA || dS || dK || dAKHA || HdA) { set_last_error("get_latent: stacked kernels carry no hyper-parameter sensitivities"); return 1; }
+        const int xs = xc_size(d);
+        std::vector<double> bx(xs);
+        MOIHGP_HIP_FATAL(hipMemcpy(bx.data(), gp->cb64 + l * xs, sizeof(double) * xs, hipMemcpyDeviceToHost));
+        // the offsets of XC<D> depend on D only through d: AKHA, K, A, HA, S, LOGS, ITERS in this order
+        const int oK = d * d, oA = oK + d, oHA = oA + d * d, oS = oHA + d, oIT = oS + 2;
+        auto cp = [&](double* dst, int off, int n) { if (dst) std::memcpy(dst, bx.data() + off, sizeof(double) * n); };
+        cp(AKHA, 0, d * d); cp(K, oK, d); cp(A, oA, d * d); cp(HA, oHA, d); cp(S, oS, 1);
+        if (iters) iters[0] = (int)bx[oIT];
+        return 0;
+    }
+    const int cbs = cb_size(d);
     std::vector<double> b(cbs);
     MOIHGP_HIP_FATAL(hipMemcpy(b.data(), gp->cb64 + l * cbs, sizeof(double) * cbs, hipMemcpyDeviceToHost));
     auto copy = [&](double* dst, int off, int n) { if (dst) std::memcpy(dst, b.data() + off, sizeof(double) * n); };
@@ -475,6 +496,8 @@ int moihgp_filter_stream(moihgp_gp* gp, int dtype, const void* Ty, size_t T, siz
         e1 = gp->prof_ev[2 * gp->prof_n + 1];
         gp->prof_n++;
     }
+    if (kernel_stack(gp->kernel))
+        return launch_filter_stream_x(gp->d, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cb32, x, yhat, nll, (hipStream_t)stream, e0, e1);
     // time split across the wavefronts of a workgroup when there are too few latents to fill the chip
     int nsplit = 1; size_t Tslice = T;
     filter_split_plan(dtype, T, gp->L, &nsplit, &Tslice);
@@ -520,6 +543,7 @@ int moihgp_grad_stream(moihgp_gp* gp, int dtype, const void* Ty, size_t T, size_
                        double* grad, void* stream) {
     if (int rc = check_stream_args(gp, dtype, Ty, T, ld, x)) return rc;
     if (!dx || !grad) { set_last_error("grad_stream: dx and grad are required"); return 1; }
+    if (kernel_stack(gp->kernel)) { set_last_error("grad_stream: stacked kernels are filter-mode only"); return 1; }
     return launch_grad_stream(gp->d, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cb32, x, dx, yhat, nll, grad, gp->dfallback, (hipStream_t)stream);
 }
 

@@ -46,6 +46,32 @@ constexpr int kChunk64 = 8;    // fp64:  8 ticks = 64 B per lane per segment (51
 
 constexpr int cb_size(int d) { return d == 2 ? CB<2>::SIZE : CB<3>::SIZE; }
 
+// ---- stacked models (sum of J Matern components, state dim D = J * d_base up to 12; include/moihgp.h MOIHGP_STACK) ----------
+// Filter-mode block (no hyper-parameter sensitivities yet): the matrices of ihgp.h:120-130 plus the tables of the
+// time-parallel segment solve of recursion_x.hip.  Both the fp64 and the fp32 copy use kChunkX ticks per lane.
+constexpr int kChunkX = 16;
+constexpr int kMaxStackDim = 12;
+template <int D>
+struct XC {
+    static constexpr int AKHA   = 0;                // [D*D]
+    static constexpr int K      = AKHA + D * D;     // [D]
+    static constexpr int A      = K + D;            // [D*D]
+    static constexpr int HA     = A + D * D;        // [D]
+    static constexpr int S      = HA + D;           // [1]
+    static constexpr int LOGS   = S + 1;            // [1]
+    static constexpr int ITERS  = LOGS + 1;         // [1]  DARE iteration count
+    static constexpr int SCANOK = ITERS + 1;        // [1]  as CB::SCANOK
+    static constexpr int G      = (SCANOK + 1 + 3) / 4 * 4;   // [kChunkX][D]  g_k = AKHA^(CK-1-k) K
+    static constexpr int SP     = G + kChunkX * D;  // [6][D*D]  M^(1,2,4,8,16,32), M = AKHA^CK: levels of a 64-lane Kogge-Stone scan
+    static constexpr int SIZE   = (SP + 6 * D * D + 3) / 4 * 4;
+};
+constexpr int xc_size(int d) {
+    return d == 4 ? XC<4>::SIZE : d == 6 ? XC<6>::SIZE : d == 8 ? XC<8>::SIZE : d == 9 ? XC<9>::SIZE : d == 12 ? XC<12>::SIZE : 0;
+}
+// kernel id = base | (J << 4) (include/moihgp.h); J == 0 for the reference's two models
+inline int kernel_base(int kernel) { return kernel & 15; }
+inline int kernel_stack(int kernel) { return kernel >> 4; }
+
 // ---- error handling -------------------------------------------------------------------------
 void set_last_error(const char* fmt, ...);
 [[noreturn]] void fatal_hip(hipError_t e, const char* what, const char* file, int line);
@@ -61,6 +87,13 @@ void set_last_error(const char* fmt, ...);
 // constant blocks and their fp32 copies.
 void launch_ihgp_update(int kernel, int d, double dt, const double* params_dev, size_t n,
                         double* cb64, float* cb32, int* n_unstable /* device int[2]: fp64 count, fp32 count */, hipStream_t stream);
+
+// stationary_x.hip / recursion_x.hip: the same two stages for stacked models (state dim d in {4, 6, 8, 9, 12}).
+// params_dev [n][2J+1] = (magnitude_j, lengthscale_j) x J, noise.
+void launch_stack_update(int kernel, double dt, const double* params_dev, size_t n, double* cb64, float* cb32,
+                         int* n_unstable, hipStream_t stream);
+int launch_filter_stream_x(int d, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* cb64, const float* cb32,
+                           void* x, void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 
 // recursion.hip: batched sweeps over series-major streams.
 int launch_filter_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, size_t L,

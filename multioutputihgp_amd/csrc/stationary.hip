@@ -15,144 +15,10 @@
 #include "common.h"
 
 #pragma clang fp contract(off)
+#include "stationary_common.h"
 
 namespace moihgp {
 namespace {
-
-template <int N>
-__device__ inline void mm(const double* A, const double* B, double* C) {
-    double T[N * N];
-    for (int i = 0; i < N; i++)
-        for (int j = 0; j < N; j++) {
-            double s = 0.0;
-            for (int k = 0; k < N; k++) s += A[i * N + k] * B[k * N + j];
-            T[i * N + j] = s;
-        }
-    for (int i = 0; i < N * N; i++) C[i] = T[i];
-}
-template <int N>
-__device__ inline void mt(const double* A, double* At) {
-    double T[N * N];
-    for (int i = 0; i < N; i++)
-        for (int j = 0; j < N; j++) T[j * N + i] = A[i * N + j];
-    for (int i = 0; i < N * N; i++) At[i] = T[i];
-}
-template <int N>
-__device__ inline void mv(const double* A, const double* x, double* y) {
-    double T[N];
-    for (int i = 0; i < N; i++) {
-        double s = 0.0;
-        for (int k = 0; k < N; k++) s += A[i * N + k] * x[k];
-        T[i] = s;
-    }
-    for (int i = 0; i < N; i++) y[i] = T[i];
-}
-template <int N>
-__device__ inline bool all_zero(const double* A) {
-    for (int i = 0; i < N * N; i++)
-        if (A[i] != 0.0) return false;
-    return true;
-}
-
-// X = Den^-1 Num, partial pivoting (Eigen partialPivLu().solve)
-template <int N>
-__device__ void lu_solve(const double* Ain, const double* Bin, double* X) {
-    double A[N * N], B[N * N];
-    for (int i = 0; i < N * N; i++) { A[i] = Ain[i]; B[i] = Bin[i]; }
-    for (int k = 0; k < N; k++) {
-        int p = k;
-        double best = fabs(A[k * N + k]);
-        for (int i = k + 1; i < N; i++)
-            if (fabs(A[i * N + k]) > best) { best = fabs(A[i * N + k]); p = i; }
-        if (p != k)
-            for (int j = 0; j < N; j++) {
-                double t = A[k * N + j]; A[k * N + j] = A[p * N + j]; A[p * N + j] = t;
-                t = B[k * N + j]; B[k * N + j] = B[p * N + j]; B[p * N + j] = t;
-            }
-        for (int i = k + 1; i < N; i++) {
-            double f = A[i * N + k] / A[k * N + k];
-            for (int j = k; j < N; j++) A[i * N + j] -= f * A[k * N + j];
-            for (int j = 0; j < N; j++) B[i * N + j] -= f * B[k * N + j];
-        }
-    }
-    for (int j = 0; j < N; j++)
-        for (int i = N - 1; i >= 0; i--) {
-            double s = B[i * N + j];
-            for (int k = i + 1; k < N; k++) s -= A[i * N + k] * X[k * N + j];
-            X[i * N + j] = s / A[i * N + i];
-        }
-}
-
-// E = exp(Ain): Pade approximant of degree 3/5/7/9/13 by 1-norm, scaling & squaring for the last.
-template <int N>
-__device__ void expm(const double* Ain, double* E) {
-    constexpr int NN = N * N;
-    double A[NN], A2[NN], A4[NN], A6[NN], U[NN], V[NN], T[NN];
-    double l1 = 0.0;
-    for (int j = 0; j < N; j++) {
-        double s = 0.0;
-        for (int i = 0; i < N; i++) s += fabs(Ain[i * N + j]);
-        if (s > l1) l1 = s;
-    }
-    for (int i = 0; i < NN; i++) A[i] = Ain[i];
-    int squarings = 0;
-    if (l1 < 1.495585217958292e-002) {
-        const double b[] = {120., 60., 12., 1.};
-        mm<N>(A, A, A2);
-        for (int i = 0; i < NN; i++) T[i] = b[3] * A2[i];
-        for (int i = 0; i < N; i++) T[i * N + i] += b[1];
-        mm<N>(A, T, U);
-        for (int i = 0; i < NN; i++) V[i] = b[2] * A2[i];
-        for (int i = 0; i < N; i++) V[i * N + i] += b[0];
-    } else if (l1 < 2.539398330063230e-001) {
-        const double b[] = {30240., 15120., 3360., 420., 30., 1.};
-        mm<N>(A, A, A2); mm<N>(A2, A2, A4);
-        for (int i = 0; i < NN; i++) T[i] = b[5] * A4[i] + b[3] * A2[i];
-        for (int i = 0; i < N; i++) T[i * N + i] += b[1];
-        mm<N>(A, T, U);
-        for (int i = 0; i < NN; i++) V[i] = b[4] * A4[i] + b[2] * A2[i];
-        for (int i = 0; i < N; i++) V[i * N + i] += b[0];
-    } else if (l1 < 9.504178996162932e-001) {
-        const double b[] = {17297280., 8648640., 1995840., 277200., 25200., 1512., 56., 1.};
-        mm<N>(A, A, A2); mm<N>(A2, A2, A4); mm<N>(A4, A2, A6);
-        for (int i = 0; i < NN; i++) T[i] = b[7] * A6[i] + b[5] * A4[i] + b[3] * A2[i];
-        for (int i = 0; i < N; i++) T[i * N + i] += b[1];
-        mm<N>(A, T, U);
-        for (int i = 0; i < NN; i++) V[i] = b[6] * A6[i] + b[4] * A4[i] + b[2] * A2[i];
-        for (int i = 0; i < N; i++) V[i * N + i] += b[0];
-    } else if (l1 < 2.097847961257068e+000) {
-        const double b[] = {17643225600., 8821612800., 2075673600., 302702400., 30270240., 2162160., 110880., 3960., 90., 1.};
-        double A8[NN];
-        mm<N>(A, A, A2); mm<N>(A2, A2, A4); mm<N>(A4, A2, A6); mm<N>(A6, A2, A8);
-        for (int i = 0; i < NN; i++) T[i] = b[9] * A8[i] + b[7] * A6[i] + b[5] * A4[i] + b[3] * A2[i];
-        for (int i = 0; i < N; i++) T[i * N + i] += b[1];
-        mm<N>(A, T, U);
-        for (int i = 0; i < NN; i++) V[i] = b[8] * A8[i] + b[6] * A6[i] + b[4] * A4[i] + b[2] * A2[i];
-        for (int i = 0; i < N; i++) V[i * N + i] += b[0];
-    } else {
-        const double b[] = {64764752532480000., 32382376266240000., 7771770303897600., 1187353796428800.,
-                            129060195264000., 10559470521600., 670442572800., 33522128640., 1323241920.,
-                            40840800., 960960., 16380., 182., 1.};
-        const double maxnorm = 5.371920351148152;
-        frexp(l1 / maxnorm, &squarings);
-        if (squarings < 0) squarings = 0;
-        double sc = ldexp(1.0, -squarings);
-        for (int i = 0; i < NN; i++) A[i] *= sc;
-        mm<N>(A, A, A2); mm<N>(A2, A2, A4); mm<N>(A4, A2, A6);
-        for (int i = 0; i < NN; i++) V[i] = b[13] * A6[i] + b[11] * A4[i] + b[9] * A2[i];
-        mm<N>(A6, V, T);
-        for (int i = 0; i < NN; i++) T[i] += b[7] * A6[i] + b[5] * A4[i] + b[3] * A2[i];
-        for (int i = 0; i < N; i++) T[i * N + i] += b[1];
-        mm<N>(A, T, U);
-        for (int i = 0; i < NN; i++) T[i] = b[12] * A6[i] + b[10] * A4[i] + b[8] * A2[i];
-        mm<N>(A6, T, V);
-        for (int i = 0; i < NN; i++) V[i] += b[6] * A6[i] + b[4] * A4[i] + b[2] * A2[i];
-        for (int i = 0; i < N; i++) V[i * N + i] += b[0];
-    }
-    for (int i = 0; i < NN; i++) { double u = U[i], v = V[i]; A2[i] = u + v; A4[i] = -u + v; }
-    lu_solve<N>(A4, A2, E);
-    for (int s = 0; s < squarings; s++) mm<N>(E, E, E);
-}
 
 template <int D>
 struct SS {
@@ -199,63 +65,6 @@ __device__ void ss_build(int kernel, const double* params, SS<D>& s) {
         s.dPinf[1][8] = -100.0 * magnitude / len2 / len3;
     }
     (void)kernel;
-}
-
-constexpr double kDareTol = 1e-8;   // utils/dare.h:7
-constexpr int kDareMaxIter = 100;   // utils/dare.h:8
-
-// utils/dare.h:10-33, Bd = H^T
-template <int D>
-__device__ int dare(const double* Ad, const double* Bd, const double* Q, double R, double* P) {
-    double AdT[D * D], Pn[D * D], T1[D * D], PB[D], APB[D], BtP[D], BPA[D];
-    mt<D>(Ad, AdT);
-    for (int i = 0; i < D * D; i++) P[i] = Q[i];
-    for (int it = 0; it < kDareMaxIter; it++) {
-        mm<D>(AdT, P, T1); mm<D>(T1, Ad, Pn);
-        mv<D>(P, Bd, PB);
-        double g = R;
-        for (int i = 0; i < D; i++) g += Bd[i] * PB[i];
-        mv<D>(AdT, PB, APB);
-        for (int j = 0; j < D; j++) { double s = 0.0; for (int i = 0; i < D; i++) s += Bd[i] * P[i * D + j]; BtP[j] = s; }
-        for (int j = 0; j < D; j++) { double s = 0.0; for (int k = 0; k < D; k++) s += BtP[k] * Ad[k * D + j]; BPA[j] = s; }
-        double ginv = 1.0 / g;
-        double diff = -INFINITY;
-        for (int i = 0; i < D; i++)
-            for (int j = 0; j < D; j++) {
-                double v = Pn[i * D + j] - APB[i] * ginv * BPA[j] + Q[i * D + j];   // dare.h:23
-                Pn[i * D + j] = v;
-                double dlt = v - P[i * D + j];
-                if (dlt > diff) diff = dlt;                                       // maxCoeff, dare.h:25
-            }
-        diff = fabs(diff);
-        for (int i = 0; i < D; i++)
-            for (int j = 0; j < D; j++) P[i * D + j] = (Pn[i * D + j] + Pn[j * D + i]) / 2.0;   // dare.h:26
-        if (diff < kDareTol) return it + 1;
-    }
-    return kDareMaxIter;
-}
-
-// utils/dare.h:36-58 (literal `AdT P Ad - P + Q`)
-template <int D>
-__device__ int dlyap(const double* Ad, const double* Q, double* P) {
-    double AdT[D * D], Pn[D * D], T1[D * D];
-    mt<D>(Ad, AdT);
-    for (int i = 0; i < D * D; i++) P[i] = Q[i];
-    for (int it = 0; it < kDareMaxIter; it++) {
-        mm<D>(AdT, P, T1); mm<D>(T1, Ad, Pn);
-        double diff = -INFINITY;
-        for (int i = 0; i < D * D; i++) {
-            double v = Pn[i] - P[i] + Q[i];
-            Pn[i] = v;
-            double dlt = v - P[i];
-            if (dlt > diff) diff = dlt;
-        }
-        diff = fabs(diff);
-        for (int i = 0; i < D; i++)
-            for (int j = 0; j < D; j++) P[i * D + j] = (Pn[i * D + j] + Pn[j * D + i]) / 2.0;
-        if (diff < kDareTol) return it + 1;
-    }
-    return kDareMaxIter;
 }
 
 template <int D>

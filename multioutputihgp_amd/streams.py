@@ -17,6 +17,9 @@ import torch
 from ._lib import MoihgpError, c_double_p, last_error, load_library
 
 KERNEL_ID = {"Matern32": 0, "Matern52": 1, "Matern52ss": 1}
+for _J in (2, 3, 4):          # stacked kernels (include/moihgp.h MOIHGP_STACK): "<base>x<J>", filter mode only
+    KERNEL_ID["Matern32x%d" % _J] = 0 | (_J << 4)
+    KERNEL_ID["Matern52x%d" % _J] = 1 | (_J << 4)
 _DT = {torch.float64: 0, torch.float32: 1}
 
 
@@ -50,11 +53,14 @@ class LatentBank:
 
     def __init__(self, dt: float, params_LP, kernel: str = "Matern52ss"):
         self._lib = load_library()
-        p = np.ascontiguousarray(np.asarray(params_LP, dtype=np.float64).reshape(-1, 3))
+        kid = KERNEL_ID[kernel]
+        J = kid >> 4
+        self.stacked = J > 0
+        self.P = 2 * J + 1 if J else 3
+        self.d = (2 if (kid & 15) == 0 else 3) * max(J, 1)
+        p = np.ascontiguousarray(np.asarray(params_LP, dtype=np.float64).reshape(-1, self.P))
         self.L = p.shape[0]
         self.kernel = kernel
-        self.d = 2 if KERNEL_ID[kernel] == 0 else 3
-        self.P = 3
         self._h = self._lib.moihgp_new_latents(KERNEL_ID[kernel], float(dt), self.L, p.ctypes.data_as(c_double_p))
         if not self._h:
             raise MoihgpError(last_error(self._lib) or "moihgp_new_latents failed")
@@ -71,6 +77,7 @@ class LatentBank:
         self.d = gp.igp_dim
         self.P = gp.num_igp_param
         self.kernel = None
+        self.stacked = False
         self.device = torch.device("cuda", torch.cuda.current_device())
         return self
 
@@ -83,15 +90,16 @@ class LatentBank:
             pass
 
     def update(self, params_LP):
-        p = np.ascontiguousarray(np.asarray(params_LP, dtype=np.float64).reshape(self.L, 3))
+        p = np.ascontiguousarray(np.asarray(params_LP, dtype=np.float64).reshape(self.L, self.P))
         _check(self._lib.moihgp_update_latents(self._h, p.ctypes.data_as(c_double_p)), self._lib)
 
     def latent(self, l: int) -> dict:
         d, P = self.d, self.P
-        out = dict(A=np.zeros((d, d)), K=np.zeros(d), S=np.zeros(1), HA=np.zeros(d), AKHA=np.zeros((d, d)),
-                   dA=np.zeros((P, d, d)), dS=np.zeros(P), dK=np.zeros((P, d)), dAKHA=np.zeros((P, d, d)), HdA=np.zeros((P, d)))
+        out = dict(A=np.zeros((d, d)), K=np.zeros(d), S=np.zeros(1), HA=np.zeros(d), AKHA=np.zeros((d, d)))
+        if not self.stacked:
+            out.update(dA=np.zeros((P, d, d)), dS=np.zeros(P), dK=np.zeros((P, d)), dAKHA=np.zeros((P, d, d)), HdA=np.zeros((P, d)))
         iters = (C.c_int * (1 + P))()
-        ptrs = [out[k].ctypes.data_as(c_double_p) for k in ("A", "K", "S", "HA", "AKHA", "dA", "dS", "dK", "dAKHA", "HdA")]
+        ptrs = [out[k].ctypes.data_as(c_double_p) if k in out else None for k in ("A", "K", "S", "HA", "AKHA", "dA", "dS", "dK", "dAKHA", "HdA")]
         _check(self._lib.moihgp_get_latent(self._h, l, *ptrs, iters), self._lib)
         out["S"] = float(out["S"][0])
         out["iters"] = list(iters)

@@ -9,32 +9,38 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DMAX, PMAX = 3, 3
+DMAX_X, PMAX_X = 12, 9            # the wide build (`make wide`), for the stacked models
 MATERN32, MATERN52 = 0, 1
 KERNEL_ID = {"Matern32": MATERN32, "Matern52": MATERN52}
+for _J in (2, 3, 4):              # stacked models: base | (J << 4), see moihgp_oracle.h
+    KERNEL_ID["Matern32x%d" % _J] = MATERN32 | (_J << 4)
+    KERNEL_ID["Matern52x%d" % _J] = MATERN52 | (_J << 4)
 
 
-class OrcIHGP(C.Structure):
-    _fields_ = [
+def _fields(dmax, pmax):
+    return [
         ("kernel", C.c_int), ("d", C.c_int), ("P", C.c_int),
         ("dt", C.c_double),
-        ("params", C.c_double * PMAX),
-        ("A", C.c_double * (DMAX * DMAX)),
-        ("Q", C.c_double * (DMAX * DMAX)),
-        ("PP", C.c_double * (DMAX * DMAX)),
-        ("PF", C.c_double * (DMAX * DMAX)),
-        ("K", C.c_double * DMAX),
+        ("params", C.c_double * pmax),
+        ("A", C.c_double * (dmax * dmax)),
+        ("Q", C.c_double * (dmax * dmax)),
+        ("PP", C.c_double * (dmax * dmax)),
+        ("PF", C.c_double * (dmax * dmax)),
+        ("K", C.c_double * dmax),
         ("S", C.c_double),
-        ("HA", C.c_double * DMAX),
-        ("AKHA", C.c_double * (DMAX * DMAX)),
-        ("dA", (C.c_double * (DMAX * DMAX)) * PMAX),
-        ("dS", C.c_double * PMAX),
-        ("dK", (C.c_double * DMAX) * PMAX),
-        ("dAKHA", (C.c_double * (DMAX * DMAX)) * PMAX),
-        ("HdA", (C.c_double * DMAX) * PMAX),
+        ("HA", C.c_double * dmax),
+        ("AKHA", C.c_double * (dmax * dmax)),
+        ("dA", (C.c_double * (dmax * dmax)) * pmax),
+        ("dS", C.c_double * pmax),
+        ("dK", (C.c_double * dmax) * pmax),
+        ("dAKHA", (C.c_double * (dmax * dmax)) * pmax),
+        ("HdA", (C.c_double * dmax) * pmax),
         ("dare_iters", C.c_int),
-        ("dlyap_iters", C.c_int * PMAX),
+        ("dlyap_iters", C.c_int * pmax),
     ]
 
+
+class _IHGPMixin:
     def mat(self, name):
         """Return field as numpy array trimmed to (d,d)/(d,)/(P,...)."""
         d, P = self.d, self.P
@@ -52,6 +58,14 @@ class OrcIHGP(C.Structure):
         return a
 
 
+class OrcIHGP(_IHGPMixin, C.Structure):
+    _fields_ = _fields(DMAX, PMAX)
+
+
+class OrcIHGPX(_IHGPMixin, C.Structure):          # layout of the wide build
+    _fields_ = _fields(DMAX_X, PMAX_X)
+
+
 _dp = C.POINTER(C.c_double)
 _fp = C.POINTER(C.c_float)
 
@@ -60,21 +74,34 @@ def _ptr(a, typ=_dp):
     return None if a is None else a.ctypes.data_as(typ)
 
 
-def build(native: bool = False) -> str:
-    target = "native" if native else "all"
+def _libname(native, wide):
+    return "libmoihgp_oracle_x.so" if wide else ("libmoihgp_oracle_native.so" if native else "libmoihgp_oracle.so")
+
+
+def build(native: bool = False, wide: bool = False) -> str:
+    target = "wide" if wide else ("native" if native else "all")
     subprocess.run(["make", "-s", "-C", _HERE, target], check=True)
-    return os.path.join(_HERE, "_build", "libmoihgp_oracle_native.so" if native else "libmoihgp_oracle.so")
+    return os.path.join(_HERE, "_build", _libname(native, wide))
 
 
 _LIBS = {}
 
 
-def lib(native: bool = False):
-    if native in _LIBS:
-        return _LIBS[native]
-    path = os.path.join(_HERE, "_build", "libmoihgp_oracle_native.so" if native else "libmoihgp_oracle.so")
+def is_wide(kernel) -> bool:
+    k = KERNEL_ID[kernel] if isinstance(kernel, str) else int(kernel)
+    return (k >> 4) != 0
+
+
+def lib(native: bool = False, wide: bool = False):
+    """native: -O3 -march=native build (CPU baseline); wide: capacity for the stacked models (OrcIHGPX structs)."""
+    key = (native and not wide, wide)
+    if key in _LIBS:
+        return _LIBS[key]
+    native = key[0]
+    path = os.path.join(_HERE, "_build", _libname(native, wide))
     if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(os.path.join(_HERE, "moihgp_oracle.c")):
-        build(native)
+        build(native, wide)
+    OrcIHGP = OrcIHGPX if wide else globals()["OrcIHGP"]
     L = C.CDLL(path)
     L.orc_expm.argtypes = [C.c_int, _dp, _dp]
     L.orc_ihgp_update.argtypes = [C.POINTER(OrcIHGP), C.c_int, C.c_double, _dp]
@@ -114,7 +141,10 @@ def lib(native: bool = False):
     L.orc_filter_stream_refshaped.argtypes = [C.POINTER(OrcIHGP), C.c_size_t, C.c_size_t, _dp, C.c_size_t, C.c_int, _dp, _dp]
     L.orc_filter_stream_refshaped.restype = C.c_double
     L.orc_max_threads.restype = C.c_int
-    _LIBS[native] = L
+    L.orc_dmax.restype = C.c_int
+    L.orc_pmax.restype = C.c_int
+    assert (L.orc_dmax(), L.orc_pmax()) == ((DMAX_X, PMAX_X) if wide else (DMAX, PMAX))
+    _LIBS[key] = L
     return L
 
 
@@ -126,10 +156,12 @@ def expm(A):
     return E
 
 
-def ihgp_update(kernel, dt, params) -> OrcIHGP:
-    g = OrcIHGP()
+def ihgp_update(kernel, dt, params):
+    w = is_wide(kernel)
+    g = OrcIHGPX() if w else OrcIHGP()
     p = np.ascontiguousarray(params, dtype=np.float64)
-    lib().orc_ihgp_update(C.byref(g), KERNEL_ID[kernel] if isinstance(kernel, str) else kernel, float(dt), _ptr(p))
+    rc = lib(wide=w).orc_ihgp_update(C.byref(g), KERNEL_ID[kernel] if isinstance(kernel, str) else kernel, float(dt), _ptr(p))
+    assert rc >= 0
     return g
 
 
@@ -137,9 +169,10 @@ def ihgp_array(kernel, dt, params_LP, native=False):
     """Array of L OrcIHGP from params [L][P]."""
     params_LP = np.ascontiguousarray(params_LP, dtype=np.float64)
     L = params_LP.shape[0]
-    arr = (OrcIHGP * L)()
+    w = is_wide(kernel)
+    arr = ((OrcIHGPX if w else OrcIHGP) * L)()
     k = KERNEL_ID[kernel] if isinstance(kernel, str) else kernel
-    Lb = lib(native)
+    Lb = lib(native, w)
     for l in range(L):
         Lb.orc_ihgp_update(C.byref(arr[l]), k, float(dt), _ptr(params_LP[l]))
     return arr
@@ -240,7 +273,7 @@ class GP:
 
 def filter_stream(igps, Ty, ld=None, layout=0, x0=None, want_yhat=True, nthreads=1, native=False):
     """Ty: [L][T] (layout 0) or [T][L] (layout 1) float64 or float32."""
-    Lb = lib(native)
+    Lb = lib(native, isinstance(igps[0], OrcIHGPX))
     f32 = Ty.dtype == np.float32
     Ty = np.ascontiguousarray(Ty)
     if layout == 0:
@@ -261,7 +294,7 @@ def filter_stream(igps, Ty, ld=None, layout=0, x0=None, want_yhat=True, nthreads
 
 
 def grad_stream(igps, Ty, layout=0, x0=None, dx0=None, want_yhat=True, nthreads=1):
-    Lb = lib()
+    Lb = lib(wide=isinstance(igps[0], OrcIHGPX))
     Ty = np.ascontiguousarray(Ty, dtype=np.float64)
     if layout == 0:
         L, T = Ty.shape

@@ -126,11 +126,56 @@ def gen_streams():
         np.savez(os.path.join(OUT, f"gradstream_{kern}.npz"), dt=0.1, params=params, Ty=Ty, x0=x0, dx0=dx0, yhat=yhat, xT=xT, dxT=dxT, nll=nll, grad=grad)
 
 
+STACKED = ("Matern32x2", "Matern52x2", "Matern52x3", "Matern52x4")
+
+
+def synth_params_stacked(L, J, rng):
+    cols = []
+    for _ in range(J):
+        cols += [rng.uniform(0.5, 2, L), rng.uniform(0.5, 2, L)]
+    return np.column_stack(cols + [rng.uniform(0.05, 0.2, L)])
+
+
+def gen_stacked():
+    """Stacked (sum-of-Matern) latents: stationary matrices incl. sensitivities, and filter streams (dense / 5 % missing)."""
+    rng = np.random.default_rng(SEED + 3)
+    for kern in STACKED:
+        J = int(kern[-1])
+        L, T = 5, 2600
+        params = synth_params_stacked(L, J, rng)
+        g = onp.IHGP(0.1, kern)
+        d = g.dim
+        st = {k: [] for k in ("A", "K", "S", "HA", "AKHA", "dare_iters")}
+        for l in range(L):
+            g.update(params[l])
+            c = cref.ihgp_update(kern, 0.1, params[l])
+            for k, v in (("A", g.A), ("K", g.K[:, 0]), ("HA", g.HA[0]), ("AKHA", g.AKHA), ("dA", np.array(g.dA)), ("dAKHA", np.array(g.dAKHA))):
+                assert rel(c.mat(k), v) < 1e-11, (kern, k, rel(c.mat(k), v))
+            assert abs(c.S - g.S[0, 0]) < 1e-11 * g.S[0, 0] and c.dare_iters == g.dare_iters
+            for k, v in (("A", g.A), ("K", g.K[:, 0]), ("S", g.S[0, 0]), ("HA", g.HA[0]), ("AKHA", g.AKHA), ("dare_iters", g.dare_iters)):
+                st[k].append(v)
+        out = dict(dt=0.1, params=params, **{k: np.array(v) for k, v in st.items()})
+        for tag, nan_frac in (("dense", 0.0), ("nan5", 0.05)):
+            Ty = synth_stream(L, T, rng, nan_frac)
+            x0 = 0.1 * rng.standard_normal((L, d))
+            yhat = np.zeros((L, T)); xT = np.zeros_like(x0); nll = np.zeros(L)
+            for l in range(L):
+                g.update(params[l])
+                r = onp.filter_stream(g, Ty[l], x0=x0[l])
+                yhat[l], xT[l], nll[l] = r["yhat"], r["x"], r["nll"]
+            cres = cref.filter_stream(cref.ihgp_array(kern, 0.1, params), Ty, x0=x0)
+            assert rel(cres["yhat"], yhat) < 1e-10 and rel(cres["x"], xT) < 1e-10 and rel(cres["nll_per_latent"], nll) < 1e-10
+            out.update({f"{tag}_Ty": Ty, f"{tag}_x0": x0, f"{tag}_yhat": yhat, f"{tag}_xT": xT, f"{tag}_nll": nll})
+        np.savez(os.path.join(OUT, f"stacked_{kern}.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    gen_stationary()
-    gen_moihgp()
-    gen_streams()
+    if "--stacked-only" not in sys.argv:
+        gen_stationary()
+        gen_moihgp()
+        gen_streams()
+    gen_stacked()
     print("golden fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):
         print(f"  {f:40s} {os.path.getsize(os.path.join(OUT, f)):8d} B")

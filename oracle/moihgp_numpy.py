@@ -123,7 +123,57 @@ class Matern52StateSpace:
         self.params = np.array(params, dtype=np.float64).copy()
 
 
+class StackedStateSpace:
+    """Sum of J independent Matern components observed through one output: the "stacked state" model of BASELINE.json's
+    d=6 / d=12 configs.  NOT a class of the reference (its only models are matern32ss.h / matern52ss.h); it is the plain
+    composition the reference's `IHGP<StateSpace>` template (ihgp.h:17-35) admits: any class exposing F, H, Pinf, R and
+    their derivatives plugs into IHGP::update unchanged.  Built from the reference's own component classes:
+        F = blockdiag(F_j), Pinf = blockdiag(Pinf_j), H = [H_1 .. H_J], R = noise,
+        params = [magnitude_1, lengthscale_1, .., magnitude_J, lengthscale_J, noise]  (P = 2J + 1),
+    derivative w.r.t. a component parameter = that component's derivative placed in its block, zero elsewhere."""
+
+    base = None
+    J = 1
+
+    def __init__(self):
+        self.parts = [self.base() for _ in range(self.J)]
+        db = self.base.dim
+        self.dim = d = db * self.J
+        self.num_param = P = 2 * self.J + 1
+        self.F = np.zeros((d, d)); self.Pinf = np.zeros((d, d)); self.H = np.zeros((1, d)); self.R = np.zeros((1, 1))
+        self.dF = [np.zeros((d, d)) for _ in range(P)]
+        self.dPinf = [np.zeros((d, d)) for _ in range(P)]
+        self.dR = [np.zeros((1, 1)) for _ in range(P)]
+        self.dR[P - 1][0, 0] = 1.0
+        default = []
+        for j in range(self.J):
+            default += [1.0, float(j + 1)]
+        self.update(np.array(default + [0.1]))
+
+    def update(self, params):
+        db, J = self.base.dim, self.J
+        params = np.asarray(params, dtype=np.float64)
+        self.R[0, 0] = params[2 * J]
+        for j, part in enumerate(self.parts):
+            part.update(np.array([params[2 * j], params[2 * j + 1], params[2 * J]]))
+            sl = slice(j * db, (j + 1) * db)
+            self.F[sl, sl] = part.F
+            self.Pinf[sl, sl] = part.Pinf
+            self.H[0, sl] = part.H[0]
+            for q in range(2):
+                self.dF[2 * j + q][sl, sl] = part.dF[q]
+                self.dPinf[2 * j + q][sl, sl] = part.dPinf[q]
+        self.params = params.copy()
+
+
+def _stacked(base_cls, J):
+    return type("%sx%d" % (base_cls.__name__, J), (StackedStateSpace,), {"base": base_cls, "J": J})
+
+
 KERNELS = {"Matern32": Matern32StateSpace, "Matern52": Matern52StateSpace}
+for _J in (2, 3, 4):
+    KERNELS["Matern32x%d" % _J] = _stacked(Matern32StateSpace, _J)
+    KERNELS["Matern52x%d" % _J] = _stacked(Matern52StateSpace, _J)
 
 
 # ----------------------------------------------------------------------------

@@ -143,7 +143,13 @@ typedef struct {
     double dF[NP][D * D], dPinf[NP][D * D], dR[NP];
 } ss_t;
 
+static void ss_build_stacked(int kernel, const double* params, ss_t* s);
+
+int orc_dmax(void) { return ORC_DMAX; }
+int orc_pmax(void) { return ORC_PMAX; }
+
 static void ss_build(int kernel, const double* params, ss_t* s) {
+    if (kernel >> 4) { ss_build_stacked(kernel, params, s); return; }
     memset(s, 0, sizeof(*s));
     double magnitude = params[0], lengthscale = params[1];
     s->P = 3;
@@ -177,6 +183,32 @@ static void ss_build(int kernel, const double* params, ss_t* s) {
         for (int i = 0; i < d * d; i++) s->dPinf[0][i] = s->Pinf[i] / magnitude;     /* :66 */
         s->dPinf[1][1 * d + 1] = kappa2; s->dPinf[1][2 * d + 0] = -kappa2; s->dPinf[1][0 * d + 2] = -kappa2;
         s->dPinf[1][2 * d + 2] = -100.0 * magnitude / len2 / len3;
+    }
+}
+
+/* Stacked state (header note): each component is built by the reference's own model code above and placed in its block. */
+static void ss_build_stacked(int kernel, const double* params, ss_t* s) {
+    int base = kernel & 15, J = kernel >> 4;
+    int db = base == ORC_MATERN32 ? 2 : 3, d = db * J, P = 2 * J + 1;
+    memset(s, 0, sizeof(*s));
+    if (d > D || P > NP) { s->d = 0; s->P = 0; return; }               /* needs the wide build; orc_ihgp_update reports it */
+    s->d = d; s->P = P;
+    s->R = params[2 * J];
+    s->dR[P - 1] = 1.0;
+    for (int j = 0; j < J; j++) {
+        ss_t* c = (ss_t*)malloc(sizeof(ss_t));
+        double cp[3] = {params[2 * j], params[2 * j + 1], params[2 * J]};
+        ss_build(base, cp, c);
+        for (int a = 0; a < db; a++) {
+            s->H[j * db + a] = c->H[a];
+            for (int b = 0; b < db; b++) {
+                int dst = (j * db + a) * d + (j * db + b), src = a * db + b;
+                s->F[dst] = c->F[src];
+                s->Pinf[dst] = c->Pinf[src];
+                for (int q = 0; q < 2; q++) { s->dF[2 * j + q][dst] = c->dF[q][src]; s->dPinf[2 * j + q][dst] = c->dPinf[q][src]; }
+            }
+        }
+        free(c);
     }
 }
 
@@ -242,6 +274,7 @@ int orc_ihgp_update(orc_ihgp* g, int kernel, double dt, const double* params) {
     ss_build(kernel, params, &s);
     int n = s.d, nn = n * n;
     memset(g, 0, sizeof(*g));
+    if (n == 0) return -1;                                            /* stacked model beyond this build's capacity */
     g->kernel = kernel; g->d = n; g->P = s.P; g->dt = dt;
     for (int p = 0; p < s.P; p++) g->params[p] = params[p];
     double T1[D * D], T2[D * D], AT[D * D];

@@ -17,10 +17,23 @@
 extern "C" {
 #endif
 
+/* Capacity of the fixed-size arrays below.  The default build (libmoihgp_oracle.so) covers the reference's two models;
+ * `make wide` builds the same source with -DORC_DMAX=12 -DORC_PMAX=9 (libmoihgp_oracle_x.so) for the stacked models. */
+#ifndef ORC_DMAX
 #define ORC_DMAX 3          /* max per-latent state dim (Matern-5/2) */
+#endif
+#ifndef ORC_PMAX
 #define ORC_PMAX 3          /* per-latent hyper-parameters (magnitude, lengthscale, noise) */
+#endif
 
 enum { ORC_MATERN32 = 0, ORC_MATERN52 = 1 };
+/* Stacked state ("sum of J Matern components observed through one output", BASELINE.json's d=6 / d=12 configs): NOT a model
+ * of the reference, but the plain composition its IHGP<StateSpace> template (ihgp.h:17-35) admits -- F, Pinf block-diagonal
+ * from the reference's own component models, H = [H_1 .. H_J], params = [mag_1, len_1, .., mag_J, len_J, noise], P = 2J+1.
+ * Kernel id = base | (J << 4), J >= 2; needs the wide build. */
+#define ORC_STACK(base, J) ((base) | ((J) << 4))
+int orc_dmax(void);
+int orc_pmax(void);
 
 /* Stationary matrices of one latent IHGP (moihgp/ihgp.h:243-254), row-major. */
 typedef struct {

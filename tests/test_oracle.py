@@ -170,3 +170,50 @@ def test_filter_is_linear_and_slab_consistent():
     b = cref.filter_stream(igps, np.ascontiguousarray(y1[:, 123:]), x0=a["x"])
     assert rel_err(np.hstack([a["yhat"], b["yhat"]]), whole["yhat"]) < 1e-15
     assert abs(a["nll"] + b["nll"] - whole["nll"]) < 1e-12 * abs(whole["nll"])
+
+
+# ------------------------------------------------------------------------------------------ stacked (sum-of-Matern) latents
+STACKED = ["Matern32x2", "Matern52x2", "Matern52x3", "Matern52x4"]
+
+
+@pytest.mark.parametrize("kern", STACKED)
+def test_stacked_golden_and_structure(kern):
+    """The wide C build reproduces the NumPy goldens; a stacked model with J identical-role components is what the
+    reference's IHGP<StateSpace> computes for block-diagonal F / Pinf and H = [H_1 .. H_J]."""
+    from oracle import moihgp_numpy as onp
+    g = load_golden(f"stacked_{kern}.npz")
+    igps = cref.ihgp_array(kern, float(g["dt"]), g["params"])
+    J = int(kern[-1]); db = 2 if kern.startswith("Matern32") else 3
+    for l in range(len(igps)):
+        assert igps[l].d == db * J and igps[l].P == 2 * J + 1
+        for k in ("A", "K", "HA", "AKHA"):
+            assert rel_err(igps[l].mat(k), g[k][l]) < 1e-11
+        assert abs(igps[l].S - g["S"][l]) < 1e-11 * g["S"][l] and igps[l].dare_iters == int(g["dare_iters"][l])
+        # A is block-diagonal with the single-component transition matrices on the diagonal (expm of a block-diagonal F)
+        A = igps[l].mat("A")
+        for j in range(J):
+            single = onp.IHGP(float(g["dt"]), kern[:-2]); single.update([g["params"][l][2 * j], g["params"][l][2 * j + 1], g["params"][l][-1]])
+            assert rel_err(A[j * db:(j + 1) * db, j * db:(j + 1) * db], single.A) < 1e-13
+            A[j * db:(j + 1) * db, j * db:(j + 1) * db] = 0
+        assert np.abs(A).max() < 1e-16
+    for tag in ("dense", "nan5"):
+        r = cref.filter_stream(igps, g[f"{tag}_Ty"], x0=g[f"{tag}_x0"], nthreads=2)
+        assert rel_err(r["yhat"], g[f"{tag}_yhat"]) < 1e-10 and rel_err(r["x"], g[f"{tag}_xT"]) < 1e-10
+        assert rel_err(r["nll_per_latent"], g[f"{tag}_nll"]) < 1e-10
+
+
+def test_stacked_one_component_equals_reference_model():
+    """J = 1 stacking is the reference model itself (same update, same step)."""
+    from oracle import moihgp_numpy as onp
+    one = type("M52x1", (onp.StackedStateSpace,), {"base": onp.Matern52StateSpace, "J": 1})
+    onp.KERNELS["_M52x1"] = one
+    try:
+        a, b = onp.IHGP(0.1, "_M52x1"), onp.IHGP(0.1, "Matern52")
+        p = np.array([1.3, 0.8, 0.07])
+        a.update(p); b.update(p)
+        for k in ("A", "AKHA", "K", "S", "HA"):
+            assert np.array_equal(getattr(a, k), getattr(b, k))
+        for q in range(3):
+            assert np.array_equal(a.dAKHA[q], b.dAKHA[q]) and np.array_equal(a.dK[q], b.dK[q])
+    finally:
+        del onp.KERNELS["_M52x1"]
