@@ -9,9 +9,9 @@ unit) = one latent x one tick.  value = N * L * T / seconds_per_pass, whole job.
 Default workload (N=1): BASELINE.json's target configuration "M=4096 outputs, T=10000, Matern-5/2, fp32,
 1xMI355X" (configs[2] without its L-BFGS outer loop, which stays on the host).  N>1: every rank owns 4096
 latents of a 4096*N-output model (weak scaling, configs[3] at N=8); the only collective is the RCCL
-all-reduce of the scalar NLL.  Other configs: --config c2 | c3f64.
+all-reduce of the scalar NLL.  Other configs: --config c2 | c3f64 | c2d6 | c5.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c2|c3f64] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c2|c3f64|c2d6|c5] [--no-cpu]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 """
@@ -36,15 +36,23 @@ CONFIGS = {
     "c3": (4096, 10000, torch.float32, "Matern52ss", "C3-filter: M=L=4096/GPU, T=10000, Matern-5/2 (matern52ss.h, d=3), fp32, filter+NLL"),
     "c3f64": (4096, 10000, torch.float64, "Matern52ss", "C3 shape in fp64: M=L=4096/GPU, T=10000, Matern-5/2 (d=3), fp64, filter+NLL"),
     "c2": (256, 10000, torch.float64, "Matern52ss", "C2: M=L=256, T=10000, Matern-5/2 (d=3), fp64, fixed hyper-parameters, filter+NLL"),
+    # stacked state (sum of J Matern-5/2 components): BASELINE.json's d=6 / d=12 shapes; not models of the reference
+    "c2d6": (256, 10000, torch.float64, "Matern52x2", "C2 as BASELINE.json words it: M=L=256, T=10000, 2 stacked Matern-5/2 (d=6), fp64, filter+NLL"),
+    "c5": (4096, 10000, torch.float64, "Matern52x4", "C5: M=L=4096, T=10000, 4 stacked Matern-5/2 (d=12), fp64, filter+NLL (VALU-bound)"),
 }
+ORACLE_KERNEL = {"Matern52ss": "Matern52", "Matern32": "Matern32"}      # product kernel name -> oracle kernel name
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 HBM_COPY_GBPS = 6290.0
 SEED = 20260101
 
 
-def synth_params(L, lo, rng):
+def synth_params(L, lo, rng, kernel="Matern52ss"):
     # mag~U(0.5,2), l~U(0.5,2), noise~U(0.05,0.2); drawn for the GLOBAL latent index range
-    return np.column_stack([rng.uniform(0.5, 2, L), rng.uniform(0.5, 2, L), rng.uniform(0.05, 0.2, L)])
+    J = int(kernel[-1]) if "x" in kernel else 1
+    cols = []
+    for _ in range(J):
+        cols += [rng.uniform(0.5, 2, L), rng.uniform(0.5, 2, L)]
+    return np.column_stack(cols + [rng.uniform(0.05, 0.2, L)])
 
 
 def synth_stream(L, lo, T, dtype, device, seed):
@@ -60,20 +68,22 @@ def synth_stream(L, lo, T, dtype, device, seed):
     return Ty
 
 
-def cpu_baseline(prm, Ty_host, T, nll_gpu_sum, yhat_gpu_sub, sub):
+def cpu_baseline(prm, Ty_host, T, nll_gpu_sum, yhat_gpu_sub, sub, kernel="Matern52ss"):
     """Time the CPU restatement (oracle/, kind 'port': the reference itself cannot be built here) on this
     box's host cores, on the same workload; also returns the parity figures of the metric."""
     from oracle import cref
+    okern = ORACLE_KERNEL.get(kernel, kernel)
+    wide = cref.is_wide(okern)
     native = True
     try:
-        cref.build(native=True)
+        cref.build(native=True, wide=wide)
     except Exception:
         native = False
-    Lb = cref.lib(native)
+    Lb = cref.lib(native, wide)
     cores = os.cpu_count() or 1
     nthreads = min(cores, int(Lb.orc_max_threads()))
     L = prm.shape[0]
-    igps = cref.ihgp_array("Matern52", 0.1, prm, native=native)
+    igps = cref.ihgp_array(okern, 0.1, prm, native=native)
     f32 = Ty_host.dtype == np.float32
     # (ii) fair-optimised: fixed-size arrays, -O3 -march=native, OpenMP over latents on all cores
     reps, t_best = 0, 1e30
@@ -88,7 +98,7 @@ def cpu_baseline(prm, Ty_host, T, nll_gpu_sum, yhat_gpu_sub, sub):
     import ctypes as C
     Ls = min(L, 512)
     Ty64 = np.ascontiguousarray(Ty_host[:Ls].astype(np.float64))
-    x = np.zeros((Ls, 3)); yh = np.zeros_like(Ty64)
+    x = np.zeros((Ls, int(igps[0].d))); yh = np.zeros_like(Ty64)
     dp = C.POINTER(C.c_double)
     t0 = time.perf_counter()
     Lb.orc_filter_stream_refshaped(igps, Ls, T, Ty64.ctypes.data_as(dp), Ty64.shape[1], 0, x.ctypes.data_as(dp), yh.ctypes.data_as(dp))
@@ -142,7 +152,7 @@ def main():
     Lglobal = Lg_per * world
     lo, hi = shard_bounds(Lglobal, world, rank)
     L = hi - lo
-    prm_all = synth_params(Lglobal, 0, np.random.default_rng(SEED))
+    prm_all = synth_params(Lglobal, 0, np.random.default_rng(SEED), kernel)
     prm = prm_all[lo:hi]
     bank = LatentBank(0.1, prm, kernel=kernel)
     Ty = synth_stream(L, lo, T, dtype, device, SEED + 1 + rank)
@@ -201,7 +211,7 @@ def main():
             "config": {"workload": desc, "latents_per_gpu": Lg_per, "latents_total": Lglobal, "ticks": T, "state_dim": bank.d,
                        "layout": "series-major [L][ld], HBM-resident", "sharding": f"latents x{world}, NLL scalar all-reduce"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic, "kernel": "filter_scan_kernel", "kernel_ms": kern_ms,
+                         "traffic": traffic, "kernel": "filter_x_kernel" if bank.stacked else "filter_scan_kernel", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": alg_bytes, "frac_of_measured_copy_peak": achieved / HBM_COPY_GBPS},
             "nll_total": float(total.item()),
         }
@@ -214,7 +224,7 @@ def main():
                 if name == args.config:
                     continue
                 L2, T2, dt2, k2, desc2 = CONFIGS[name]
-                b2 = LatentBank(0.1, synth_params(L2, 0, np.random.default_rng(SEED)), kernel=k2)
+                b2 = LatentBank(0.1, synth_params(L2, 0, np.random.default_rng(SEED), k2), kernel=k2)
                 Ty2 = synth_stream(L2, 0, T2, dt2, device, SEED + 1)
                 yh2 = torch.empty_like(Ty2); n2 = torch.empty((L2,), dtype=torch.float64, device=device)
                 x2 = torch.zeros((L2, b2.d), dtype=dt2, device=device)
@@ -225,12 +235,12 @@ def main():
                     x2.zero_(); b2.filter(Ty2, T=T2, x=x2, yhat=yh2, nll=n2)
                 ms2 = float(np.mean(b2.profile_read()))
                 es2 = 4 if dt2 == torch.float32 else 8
-                others[name] = {"workload": desc2, "kernel_ms": ms2, "steps_per_s_kernel_only": L2 * T2 / (ms2 * 1e-3),
+                others[name] = {"workload": desc2, "state_dim": b2.d, "kernel_ms": ms2, "steps_per_s_kernel_only": L2 * T2 / (ms2 * 1e-3),
                                 "achieved_GBps": 2 * es2 * L2 * T2 / (ms2 * 1e-3) / 1e9, "frac": 2 * es2 * L2 * T2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBPS}
                 del b2, Ty2, yh2
             out["other_configs"] = others
             sub = np.arange(0, L, max(1, L // 64))[:64]
-            cb, nll_rel, mean_rel = cpu_baseline(prm, Ty[:, :T].cpu().numpy(), T, float(total.item()), yhat[sub][:, :T].double().cpu().numpy(), sub)
+            cb, nll_rel, mean_rel = cpu_baseline(prm, Ty[:, :T].cpu().numpy(), T, float(total.item()), yhat[sub][:, :T].double().cpu().numpy(), sub, kernel)
             out["cpu_baseline"] = cb
             out["nll_rel_err"] = nll_rel
             out["filtered_mean_rel_err"] = mean_rel

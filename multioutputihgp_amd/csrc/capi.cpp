@@ -497,7 +497,7 @@ int moihgp_filter_stream(moihgp_gp* gp, int dtype, const void* Ty, size_t T, siz
         gp->prof_n++;
     }
     if (kernel_stack(gp->kernel))
-        return launch_filter_stream_x(gp->d, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cb32, x, yhat, nll, (hipStream_t)stream, e0, e1);
+        return launch_filter_stream_x(gp->kernel, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cb32, x, yhat, nll, (hipStream_t)stream, e0, e1);
     // time split across the wavefronts of a workgroup when there are too few latents to fill the chip
     int nsplit = 1; size_t Tslice = T;
     filter_split_plan(dtype, T, gp->L, &nsplit, &Tslice);

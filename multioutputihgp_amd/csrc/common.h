@@ -49,7 +49,7 @@ constexpr int cb_size(int d) { return d == 2 ? CB<2>::SIZE : CB<3>::SIZE; }
 // ---- stacked models (sum of J Matern components, state dim D = J * d_base up to 12; include/moihgp.h MOIHGP_STACK) ----------
 // Filter-mode block (no hyper-parameter sensitivities yet): the matrices of ihgp.h:120-130 plus the tables of the
 // time-parallel segment solve of recursion_x.hip.  Both the fp64 and the fp32 copy use kChunkX ticks per lane.
-constexpr int kChunkX = 16;
+constexpr int kChunkX = 32;          // ticks per lane per segment (2048-tick segments)
 constexpr int kMaxStackDim = 12;
 template <int D>
 struct XC {
@@ -61,7 +61,8 @@ struct XC {
     static constexpr int LOGS   = S + 1;            // [1]
     static constexpr int ITERS  = LOGS + 1;         // [1]  DARE iteration count
     static constexpr int SCANOK = ITERS + 1;        // [1]  as CB::SCANOK
-    static constexpr int G      = (SCANOK + 1 + 3) / 4 * 4;   // [kChunkX][D]  g_k = AKHA^(CK-1-k) K
+    static constexpr int AB     = (SCANOK + 1 + 3) / 4 * 4;   // [J][DB*DB] the diagonal blocks of A, packed (<= 3*D scalars)
+    static constexpr int G      = AB + 3 * D;       // [kChunkX][D]  g_k = AKHA^(CK-1-k) K
     static constexpr int SP     = G + kChunkX * D;  // [6][D*D]  M^(1,2,4,8,16,32), M = AKHA^CK: levels of a 64-lane Kogge-Stone scan
     static constexpr int SIZE   = (SP + 6 * D * D + 3) / 4 * 4;
 };
@@ -92,7 +93,7 @@ void launch_ihgp_update(int kernel, int d, double dt, const double* params_dev, 
 // params_dev [n][2J+1] = (magnitude_j, lengthscale_j) x J, noise.
 void launch_stack_update(int kernel, double dt, const double* params_dev, size_t n, double* cb64, float* cb32,
                          int* n_unstable, hipStream_t stream);
-int launch_filter_stream_x(int d, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* cb64, const float* cb32,
+int launch_filter_stream_x(int kernel, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* cb64, const float* cb32,
                            void* x, void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 
 // recursion.hip: batched sweeps over series-major streams.

@@ -6,14 +6,16 @@
 //   * the per-latent matrices are WAVE-UNIFORM, so they are never held per lane: every product reads its matrix
 //     through scalar loads (s_load from the latent's constant block, K$-resident) and feeds the FMAs as SGPR operands;
 //     the vector registers hold only state-sized vectors;
-//   * a segment is 64 lanes x 16 ticks.  z_j = sum_k g_k y_k (chunk response), then a 6-level Kogge-Stone scan
+//   * a segment is 64 lanes x 32 ticks.  z_j = sum_k g_k y_k (chunk response), then a 6-level Kogge-Stone scan
 //     x_j = M x_{j-1} + z_j with the uniform powers M^(1,2,4,8,16,32) (lane shifts by ds_bpermute), then every lane
-//     replays its 16 ticks from its start state with the literal step  v = y - HA x;  x <- AKHA x + K y;
+//     replays its 32 ticks from its start state in innovation form,  v = y - HA x;  x <- A x + K v  (== AKHA x + K y,
+//     ihgp.h:90), which only touches the J diagonal blocks of A: those stay in SGPRs for the whole replay, HA and K in
+//     VGPRs, so the replay loop has no memory access besides one LDS read and write per tick;
 //   * a segment that holds a NaN (or a latent whose scan tables overflowed, rho(AKHA) > 1) is run tick by tick with the
 //     rows of AKHA spread over the lanes (lane i owns row i, lane D owns HA; the state is gathered by v_readlane).
 //
-// Roofline: VALU-bound for D >= 9 in fp64 (per tick 2D^2+2D flop replay + 7 D^2 / 16 scan + D response against
-// 16 B of traffic), near the HBM / VALU balance point for D = 6.  DESIGN.md 3.7.
+// Roofline: VALU-bound for D >= 9 in fp64 (per tick about D*DB + 3D FMA replay + 7 D^2 / 32 scan + D response
+// against 16 B of traffic), near the HBM / VALU balance point for D = 6.  DESIGN.md 3.7.
 #include "kernels_common.h"
 #include <hip/hip_ext.h>
 
@@ -64,36 +66,41 @@ __device__ inline void matvec_u(const T* __restrict__ m0, const T (&v)[D], T (&o
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <typename T, int D, bool WRITE, bool NLL, bool TAIL>
-__device__ inline void replay(const T* __restrict__ c, T* tile_lane, int first_tick, int n, T (&xs)[D], double& acc, unsigned& nobs) {
+template <typename T, int DB, int J, bool WRITE, bool NLL, bool TAIL>
+__device__ inline void replay(const T* __restrict__ c, T* tile_lane, int first_tick, int n, const T (&hav)[DB * J], const T (&kv)[DB * J],
+                              T (&xs)[DB * J], double& acc, unsigned& nobs) {
+    constexpr int D = DB * J;
     using Lay = XC<D>;
+    const uptr<T> ab = launder(c + Lay::AB);       // once per segment: J*DB*DB uniform scalars, SGPR-resident across the loop
+    T a[J * DB * DB];
+#pragma unroll
+    for (int i = 0; i < J * DB * DB; i++) a[i] = ab[i];
 #pragma unroll 1
     for (int k = 0; k < kChunkX; k++) {
         const T y = tile_lane[k];
         T hx = 0;
-        {
-            const uptr<T> ha = launder(c + Lay::HA);
 #pragma unroll
-            for (int i = 0; i < D; i++) hx = fma(ha[i], xs[i], hx);
-        }
+        for (int i = 0; i < D; i++) hx = fma(hav[i], xs[i], hx);
+        const T v = y - hx;
         const bool valid = !TAIL || (first_tick + k < n);
         if (NLL && valid) {
-            const double v = (double)(y - hx);
-            acc = fma(v, v, acc);                                   // ihgp.h:206-207, pre-step state
+            const double vd = (double)v;
+            acc = fma(vd, vd, acc);                                 // ihgp.h:206-207, pre-step state
             nobs++;
         }
         T xn[D];
 #pragma unroll
-        for (int i = 0; i < D; i++) xn[i] = T(0);
-        matvec_u<T, D>(c + Lay::AKHA, xs, xn);
-        {
-            const uptr<T> kk = launder(c + Lay::K);
+        for (int j = 0; j < J; j++)
 #pragma unroll
-            for (int i = 0; i < D; i++) xn[i] = fma(kk[i], y, xn[i]);          // ihgp.h:90
-        }
+            for (int r = 0; r < DB; r++) {
+                T sum = kv[j * DB + r] * v;
+#pragma unroll
+                for (int q = 0; q < DB; q++) sum = fma(a[j * DB * DB + r * DB + q], xs[j * DB + q], sum);
+                xn[j * DB + r] = sum;                               // ihgp.h:90 as A x + K (y - HA x)
+            }
 #pragma unroll
         for (int i = 0; i < D; i++) xs[i] = valid ? xn[i] : xs[i];
-        if (WRITE) tile_lane[k] = xn[0];                            // ihgp.h:91
+        if (WRITE) tile_lane[k] = xn[0];                            // ihgp.h:91 `yhat = xnew(0, 0)`, literally
     }
 }
 
@@ -136,10 +143,11 @@ __device__ inline void sequential(const T* __restrict__ c, T* tile, int stride, 
     for (int i = 0; i < D; i++) xc[i] = read_lane(xv, i);
 }
 
-template <typename T, int D, bool WRITE, bool NLL, int WPB>
+template <typename T, int DB, int J, bool WRITE, bool NLL, int WPB>
 __global__ void __launch_bounds__(64 * WPB)
 filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, const T* __restrict__ cbT, const double* __restrict__ cb64,
                 T* __restrict__ x, T* __restrict__ yhat, double* __restrict__ nll) {
+    constexpr int D = DB * J;
     using V = typename VecOf<T>::type;
     using Lay = XC<D>;
     constexpr int CK = kChunkX, EPV = 16 / sizeof(T), STRIDE = CK + EPV, SEG = 64 * CK;
@@ -159,6 +167,15 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
     double acc = 0.0;
     unsigned nobs = 0;
     const bool scan_ok = c[Lay::SCANOK] != T(0);
+    // HA and K of this latent, replicated in vector registers for the replay loop (the asm pins them there: as uniform
+    // values the compiler would otherwise park them in scalar registers and run out)
+    T hav[D], kv[D];
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+        hav[i] = c[Lay::HA + i];
+        kv[i] = c[Lay::K + i];
+        asm volatile("" : "+v"(hav[i]), "+v"(kv[i]));
+    }
 
     for (size_t t0 = 0; t0 < Tlen; t0 += SEG) {
         const int n = (int)(Tlen - t0 < (size_t)SEG ? Tlen - t0 : (size_t)SEG);
@@ -214,8 +231,8 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
 #pragma unroll
                 for (int i = 0; i < D; i++) { const T m = bperm<T>(addr, z[i]); xs[i] = lane >= 1 ? m : xc[i]; }
             }
-            if (n == SEG) replay<T, D, WRITE, NLL, false>(c, tile_lane, lane * CK, n, xs, acc, nobs);
-            else replay<T, D, WRITE, NLL, true>(c, tile_lane, lane * CK, n, xs, acc, nobs);
+            if (n == SEG) replay<T, DB, J, WRITE, NLL, false>(c, tile_lane, lane * CK, n, hav, kv, xs, acc, nobs);
+            else replay<T, DB, J, WRITE, NLL, true>(c, tile_lane, lane * CK, n, hav, kv, xs, acc, nobs);
             const int jl = (n - 1) / CK;                             // the lane that holds the last tick
 #pragma unroll
             for (int i = 0; i < D; i++) xc[i] = read_lane(xs[i], jl);
@@ -245,48 +262,44 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
     }
 }
 
-template <typename T, int D, int WPB>
+template <typename T, int DB, int J, int WPB>
 int launch_x(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, const double* cb64, void* x, void* yhat, double* nll,
              hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     dim3 block(64 * WPB), grid((unsigned)((L + WPB - 1) / WPB));
     const T* ty = static_cast<const T*>(Ty);
     T* xs = static_cast<T*>(x);
     T* yh = static_cast<T*>(yhat);
-    if (yhat && nll) hipExtLaunchKernelGGL((filter_x_kernel<T, D, true, true, WPB>), grid, block, 0, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xs, yh, nll);
-    else if (yhat) hipExtLaunchKernelGGL((filter_x_kernel<T, D, true, false, WPB>), grid, block, 0, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xs, yh, nll);
-    else if (nll) hipExtLaunchKernelGGL((filter_x_kernel<T, D, false, true, WPB>), grid, block, 0, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xs, yh, nll);
-    else hipExtLaunchKernelGGL((filter_x_kernel<T, D, false, false, WPB>), grid, block, 0, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xs, yh, nll);
+    if (yhat && nll) hipExtLaunchKernelGGL((filter_x_kernel<T, DB, J, true, true, WPB>), grid, block, 0, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xs, yh, nll);
+    else if (yhat) hipExtLaunchKernelGGL((filter_x_kernel<T, DB, J, true, false, WPB>), grid, block, 0, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xs, yh, nll);
+    else if (nll) hipExtLaunchKernelGGL((filter_x_kernel<T, DB, J, false, true, WPB>), grid, block, 0, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xs, yh, nll);
+    else hipExtLaunchKernelGGL((filter_x_kernel<T, DB, J, false, false, WPB>), grid, block, 0, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xs, yh, nll);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_last_error("filter_x_kernel launch: %s", hipGetErrorString(e)); return 2; }
     return 0;
 }
 
-template <typename T, int D>
+template <typename T, int DB, int J>
 int launch_xd(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, const double* cb64, void* x, void* yhat, double* nll,
               hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     // few latents: one wavefront per workgroup, so that they spread over the compute units
-    if (L < 1024) return launch_x<T, D, 1>(Ty, Tlen, ld, L, cbT, cb64, x, yhat, nll, stream, ev0, ev1);
-    return launch_x<T, D, 4>(Ty, Tlen, ld, L, cbT, cb64, x, yhat, nll, stream, ev0, ev1);
+    if (L < 1024) return launch_x<T, DB, J, 1>(Ty, Tlen, ld, L, cbT, cb64, x, yhat, nll, stream, ev0, ev1);
+    return launch_x<T, DB, J, 4>(Ty, Tlen, ld, L, cbT, cb64, x, yhat, nll, stream, ev0, ev1);
 }
 
 }  // namespace
 
-int launch_filter_stream_x(int d, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* cb64, const float* cb32,
+int launch_filter_stream_x(int kernel, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* cb64, const float* cb32,
                            void* x, void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     if (L == 0) return 0;
-#define MOIHGP_X_CASE(DD)                                                                                          \
-    case DD:                                                                                                       \
-        return dtype == 0 ? launch_xd<double, DD>(Ty, T, ld, L, cb64, cb64, x, yhat, nll, stream, ev0, ev1)        \
-                          : launch_xd<float, DD>(Ty, T, ld, L, cb32, cb64, x, yhat, nll, stream, ev0, ev1)
-    switch (d) {
-        MOIHGP_X_CASE(4);
-        MOIHGP_X_CASE(6);
-        MOIHGP_X_CASE(8);
-        MOIHGP_X_CASE(9);
-        MOIHGP_X_CASE(12);
-    }
+    const int base = kernel_base(kernel), J = kernel_stack(kernel);
+#define MOIHGP_X_CASE(DBB, JJ)                                                                                        \
+    if (base == (DBB == 2 ? 0 : 1) && J == JJ)                                                                        \
+        return dtype == 0 ? launch_xd<double, DBB, JJ>(Ty, T, ld, L, cb64, cb64, x, yhat, nll, stream, ev0, ev1)      \
+                          : launch_xd<float, DBB, JJ>(Ty, T, ld, L, cb32, cb64, x, yhat, nll, stream, ev0, ev1)
+    MOIHGP_X_CASE(2, 2); MOIHGP_X_CASE(2, 3); MOIHGP_X_CASE(2, 4);
+    MOIHGP_X_CASE(3, 2); MOIHGP_X_CASE(3, 3); MOIHGP_X_CASE(3, 4);
 #undef MOIHGP_X_CASE
-    set_last_error("stacked state dim %d is not built (4, 6, 8, 9, 12)", d);
+    set_last_error("stacked kernel id %d is not built", kernel);
     return 1;
 }
 

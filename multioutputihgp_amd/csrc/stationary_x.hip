@@ -78,6 +78,9 @@ __global__ void __launch_bounds__(64) stack_update_kernel(double dt, const doubl
     for (int i = 0; i < NN; i++) { put(L::AKHA + i, AKHA[i]); put(L::A + i, A[i]); }
     for (int i = 0; i < D; i++) { put(L::K + i, K[i]); put(L::HA + i, HA[i]); }
     put(L::S, S); put(L::LOGS, log(S)); put(L::ITERS, (double)dare_iters);
+    for (int j = 0; j < J; j++)
+        for (int a = 0; a < DB; a++)
+            for (int b = 0; b < DB; b++) put(L::AB + j * DB * DB + a * DB + b, A[(j * DB + a) * D + j * DB + b]);
 
     // tables of the segment solve (recursion_x.hip): g_k = AKHA^(CK-1-k) K, and M^(2^lv) with M = AKHA^CK
     bool ok = true;
@@ -88,7 +91,7 @@ __global__ void __launch_bounds__(64) stack_update_kernel(double dt, const doubl
         mv<D>(AKHA, g, g);
     }
     for (int i = 0; i < NN; i++) T1[i] = AKHA[i];
-    for (int q = 1; q < kChunkX; q <<= 1) mm<D>(T1, T1, T1);            // M = AKHA^16
+    for (int q = 1; q < kChunkX; q <<= 1) mm<D>(T1, T1, T1);            // M = AKHA^CK
     for (int lv = 0; lv < 6; lv++) {
         for (int i = 0; i < NN; i++) { put(L::SP + lv * NN + i, T1[i]); ok = ok && (fabs(T1[i]) < 1e18); }   // false for NaN too
         mm<D>(T1, T1, T1);

@@ -75,11 +75,11 @@ def _ptr(a, typ=_dp):
 
 
 def _libname(native, wide):
-    return "libmoihgp_oracle_x.so" if wide else ("libmoihgp_oracle_native.so" if native else "libmoihgp_oracle.so")
+    return "libmoihgp_oracle%s%s.so" % ("_x" if wide else "", "_native" if native else "")
 
 
 def build(native: bool = False, wide: bool = False) -> str:
-    target = "wide" if wide else ("native" if native else "all")
+    target = ("wide-native" if native else "wide") if wide else ("native" if native else "all")
     subprocess.run(["make", "-s", "-C", _HERE, target], check=True)
     return os.path.join(_HERE, "_build", _libname(native, wide))
 
@@ -94,10 +94,9 @@ def is_wide(kernel) -> bool:
 
 def lib(native: bool = False, wide: bool = False):
     """native: -O3 -march=native build (CPU baseline); wide: capacity for the stacked models (OrcIHGPX structs)."""
-    key = (native and not wide, wide)
+    key = (native, wide)
     if key in _LIBS:
         return _LIBS[key]
-    native = key[0]
     path = os.path.join(_HERE, "_build", _libname(native, wide))
     if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(os.path.join(_HERE, "moihgp_oracle.c")):
         build(native, wide)
