@@ -61,10 +61,18 @@ struct XC {
     static constexpr int LOGS   = S + 1;            // [1]
     static constexpr int ITERS  = LOGS + 1;         // [1]  DARE iteration count
     static constexpr int SCANOK = ITERS + 1;        // [1]  as CB::SCANOK
-    static constexpr int AB     = (SCANOK + 1 + 3) / 4 * 4;   // [J][DB*DB] the diagonal blocks of A, packed (<= 3*D scalars)
-    static constexpr int G      = AB + 3 * D;       // [kChunkX][D]  g_k = AKHA^(CK-1-k) K
-    static constexpr int SP     = G + kChunkX * D;  // [6][D*D]  M^(1,2,4,8,16,32), M = AKHA^CK: levels of a 64-lane Kogge-Stone scan
-    static constexpr int SIZE   = (SP + 6 * D * D + 3) / 4 * 4;
+    static constexpr int NLEV   = SCANOK + 1;       // [1]  scan levels that matter in this block's precision: M^(2^k) for k >= NLEV is
+                                                    //      below D * |entry| < 1e-20 (fp64 block) / 1e-10 (fp32 block) and is skipped
+    static constexpr int AB     = (NLEV + 1 + 3) / 4 * 4;     // [J][DB*DB] the diagonal blocks of A, packed (<= 3*D scalars)
+    // ---- "slab" tables of recursion_x.hip: 16-element groups, each fetched as one register whose 16-lane rows all hold the
+    // same 16 scalars, and consumed by v_fmac_*_dpp row_newbcast (a broadcast operand at no instruction cost).  16-aligned.
+    static constexpr int LS     = (D * D + 15) / 16 * 16;      // one matrix, padded
+    static constexpr int GN     = (kChunkX * D + 15) / 16 * 16;
+    static constexpr int HA16   = (AB + 3 * D + 15) / 16 * 16; // [16]  HA, zero padded
+    static constexpr int K16    = HA16 + 16;                   // [16]  K, zero padded
+    static constexpr int G      = K16 + 16;         // [GN]  g_k = AKHA^(CK-1-k) K, row-major [k][i]
+    static constexpr int SP     = G + GN;           // [6][LS]  M^(1,2,4,8,16,32), M = AKHA^CK: levels of a 64-lane Kogge-Stone scan
+    static constexpr int SIZE   = SP + 6 * LS;      // a multiple of 16: every latent's tables stay 16-aligned
 };
 constexpr int xc_size(int d) {
     return d == 4 ? XC<4>::SIZE : d == 6 ? XC<6>::SIZE : d == 8 ? XC<8>::SIZE : d == 9 ? XC<9>::SIZE : d == 12 ? XC<12>::SIZE : 0;

@@ -3,14 +3,16 @@
 // Same contract as recursion.hip (one wavefront owns one latent; series-major stream; NaN = missing), different
 // machine mapping, because a D x D matrix no longer fits the register file next to the state:
 //
-//   * the per-latent matrices are WAVE-UNIFORM, so they are never held per lane: every product reads its matrix
-//     through scalar loads (s_load from the latent's constant block, K$-resident) and feeds the FMAs as SGPR operands;
-//     the vector registers hold only state-sized vectors;
-//   * a segment is 64 lanes x 32 ticks.  z_j = sum_k g_k y_k (chunk response), then a 6-level Kogge-Stone scan
-//     x_j = M x_{j-1} + z_j with the uniform powers M^(1,2,4,8,16,32) (lane shifts by ds_bpermute), then every lane
-//     replays its 32 ticks from its start state in innovation form,  v = y - HA x;  x <- A x + K v  (== AKHA x + K y,
-//     ihgp.h:90), which only touches the J diagonal blocks of A: those stay in SGPRs for the whole replay, HA and K in
-//     VGPRs, so the replay loop has no memory access besides one LDS read and write per tick;
+//   * the per-latent matrices are WAVE-UNIFORM, so they are never held one scalar per lane.  The scan and response tables
+//     live in "slabs": one register holds 16 table entries, the same 16 in each of the wave's four 16-lane rows, and the
+//     FMA reads entry e as a DPP broadcast operand (v_fmac_f64_dpp / v_fmac_f32_dpp row_newbcast:e) -- a uniform operand
+//     at no instruction cost, without going through the scalar register file.  A 12 x 12 matrix is 9 such registers, so the
+//     six scan powers of a latent stay resident for the whole kernel (54 slabs) and the scan phase issues no load at all;
+//   * a segment is 64 lanes x 32 ticks.  z_j = sum_k g_k y_k (chunk response, g streamed in per segment), then a 6-level
+//     Kogge-Stone scan x_j = M x_{j-1} + z_j with the uniform powers M^(1,2,4,8,16,32) (lane shifts by ds_bpermute), then
+//     every lane replays its 32 ticks from its start state in innovation form,  v = y - HA x;  x <- A x + K v
+//     (== AKHA x + K y, ihgp.h:90), which only touches the J diagonal blocks of A: those sit in SGPRs for the whole replay,
+//     HA and K in two slabs, so the replay loop has no memory access besides one LDS read and write per tick;
 //   * a segment that holds a NaN (or a latent whose scan tables overflowed, rho(AKHA) > 1) is run tick by tick with the
 //     rows of AKHA spread over the lanes (lane i owns row i, lane D owns HA; the state is gathered by v_readlane).
 //
@@ -18,6 +20,8 @@
 // against 16 B of traffic), near the HBM / VALU balance point for D = 6.  DESIGN.md 3.7.
 #include "kernels_common.h"
 #include <hip/hip_ext.h>
+#include <type_traits>
+#include <utility>
 
 namespace moihgp {
 namespace {
@@ -37,9 +41,9 @@ template <> __device__ inline double bperm<double>(int addr, double v) {
 // rows are fetched in batches of about 72 dwords; the scheduling barrier keeps the compiler from hoisting every s_load of a
 // 12 x 12 product to the top (288 dwords: it would spill SGPRs into VGPR lanes).
 // A wave-uniform view of a constant block for use INSIDE loops: the asm hides the pointer's provenance, so the loads cannot
-// be hoisted out of the enclosing loop (the blocks are loop-invariant, and LICM would otherwise pull thousands of scalar
-// loads in front of the segment loop and spill them); readfirstlane + the constant address space make every access through
-// the result a scalar load (s_load, SGPR operand of the FMA).  The blocks are written by the update kernel only.
+// be hoisted out of the enclosing loop (the blocks are loop-invariant, and LICM would otherwise pull them all in front of the
+// segment loop and run out of registers); readfirstlane + the constant address space make uniform accesses through the
+// result scalar loads.  The blocks are written by the update kernel only.
 template <typename T> using uptr = const __attribute__((address_space(4))) T*;
 template <typename T>
 __device__ inline uptr<T> launder(const T* p) {
@@ -51,37 +55,52 @@ __device__ inline uptr<T> launder(const T* p) {
     return (uptr<T>)(((unsigned long long)hi << 32) | lo);
 }
 
-template <typename T, int D>
-__device__ inline void matvec_u(const T* __restrict__ m0, const T (&v)[D], T (&out)[D]) {
-    const uptr<T> m = launder(m0);
-    constexpr int DW = D * (int)(sizeof(T) / 4), RB = 72 / DW < 1 ? 1 : 72 / DW;
+// compile-time loop: f(std::integral_constant<int, 0>) .. f(std::integral_constant<int, N-1>)
+template <typename F, int... I>
+__device__ inline void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ inline void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// acc += slab[E] * x, slab[E] = entry E (0..15) of a slab register, read as a DPP row broadcast.  Every lane of the wave must
+// be active (the kernel runs whole waves), and `slab` is only ever written by loads (no VALU-write -> DPP-read hazard).
+template <int E> __device__ inline void fmac_bc(double& acc, const double& slab, const double& x) {
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(slab), "v"(x), "n"(E));
+}
+template <int E> __device__ inline void fmac_bc(float& acc, const float& slab, const float& x) {
+    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(slab), "v"(x), "n"(E));
+}
+
+// slabs of a 16-aligned table: register s holds entries [16 s, 16 s + 16), replicated over the four rows of the wave
+template <typename T, int NS, typename P>
+__device__ inline void load_slabs(P tab, int lane, T (&slab)[NS]) {
 #pragma unroll
-    for (int i = 0; i < D; i++) {
-        T s = out[i];
-#pragma unroll
-        for (int j = 0; j < D; j++) s = fma(m[i * D + j], v[j], s);
-        out[i] = s;
-        if ((i + 1) % RB == 0 && i + 1 < D) __builtin_amdgcn_sched_barrier(0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
+    for (int s = 0; s < NS; s++) slab[s] = tab[s * 16 + (lane & 15)];
+}
+
+// out += M v, M a row-major D x D matrix held in slabs (j outer, i inner: D independent accumulation chains in flight)
+template <typename T, int D, int NS>
+__device__ inline void matvec_bc(const T (&m)[NS], const T (&v)[D], T (&out)[D]) {
+    static_for<D>([&](auto jj) {
+        static_for<D>([&](auto ii) {
+            constexpr int e = decltype(ii)::value * D + decltype(jj)::value;
+            fmac_bc<e % 16>(out[decltype(ii)::value], m[e / 16], v[decltype(jj)::value]);
+        });
+    });
 }
 
 template <typename T, int DB, int J, bool WRITE, bool NLL, bool TAIL>
-__device__ inline void replay(const T* __restrict__ c, T* tile_lane, int first_tick, int n, const T (&hav)[DB * J], const T (&kv)[DB * J],
+__device__ inline void replay(const T (&a)[J * DB * DB], const T& ha, const T& kk, T* tile_lane, int first_tick, int n,
                               T (&xs)[DB * J], double& acc, unsigned& nobs) {
     constexpr int D = DB * J;
-    using Lay = XC<D>;
-    const uptr<T> ab = launder(c + Lay::AB);       // once per segment: J*DB*DB uniform scalars, SGPR-resident across the loop
-    T a[J * DB * DB];
-#pragma unroll
-    for (int i = 0; i < J * DB * DB; i++) a[i] = ab[i];
 #pragma unroll 1
     for (int k = 0; k < kChunkX; k++) {
         const T y = tile_lane[k];
-        T hx = 0;
-#pragma unroll
-        for (int i = 0; i < D; i++) hx = fma(hav[i], xs[i], hx);
-        const T v = y - hx;
+        T h0 = 0, h1 = 0, h2 = 0;                                    // three partial sums of HA x: shorter dependent chains
+        static_for<D>([&](auto ii) {
+            constexpr int i = decltype(ii)::value;
+            fmac_bc<i>(i % 3 == 0 ? h0 : (i % 3 == 1 ? h1 : h2), ha, xs[i]);
+        });
+        const T v = y - ((h0 + h1) + h2);
         const bool valid = !TAIL || (first_tick + k < n);
         if (NLL && valid) {
             const double vd = (double)v;
@@ -93,11 +112,12 @@ __device__ inline void replay(const T* __restrict__ c, T* tile_lane, int first_t
         for (int j = 0; j < J; j++)
 #pragma unroll
             for (int r = 0; r < DB; r++) {
-                T sum = kv[j * DB + r] * v;
+                T sum = a[j * DB * DB + r * DB] * xs[j * DB];
 #pragma unroll
-                for (int q = 0; q < DB; q++) sum = fma(a[j * DB * DB + r * DB + q], xs[j * DB + q], sum);
-                xn[j * DB + r] = sum;                               // ihgp.h:90 as A x + K (y - HA x)
+                for (int q = 1; q < DB; q++) sum = fma(a[j * DB * DB + r * DB + q], xs[j * DB + q], sum);
+                xn[j * DB + r] = sum;
             }
+        static_for<D>([&](auto ii) { fmac_bc<decltype(ii)::value>(xn[decltype(ii)::value], kk, v); });   // ihgp.h:90 as A x + K (y - HA x)
 #pragma unroll
         for (int i = 0; i < D; i++) xs[i] = valid ? xn[i] : xs[i];
         if (WRITE) tile_lane[k] = xn[0];                            // ihgp.h:91 `yhat = xnew(0, 0)`, literally
@@ -167,27 +187,66 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
     double acc = 0.0;
     unsigned nobs = 0;
     const bool scan_ok = c[Lay::SCANOK] != T(0);
-    // HA and K of this latent, replicated in vector registers for the replay loop (the asm pins them there: as uniform
-    // values the compiler would otherwise park them in scalar registers and run out)
-    T hav[D], kv[D];
+    // Two register plans.  PF (everything but fp64 with 9+ states): the scan powers and the response table are streamed in at
+    // the start of every segment (L2-resident, coalesced, issued ahead of the phases that use them), which leaves room to
+    // fetch the NEXT segment of the stream into registers during the replay.  !PF: no registers to spare for that, so the four
+    // scan powers stay resident for the whole sweep instead and the stream is fetched at the segment start.
+    constexpr bool PF = !(sizeof(T) == 8 && D > 8);
+    constexpr int NSL = Lay::LS / 16, NSG = Lay::GN / 16, NRES = 4;
+    T ha = c[Lay::HA16 + (lane & 15)], kk = c[Lay::K16 + (lane & 15)];
+    const int nlev = (int)c[Lay::NLEV];
+    T sp[NRES][NSL];
+    if (!PF) {
 #pragma unroll
-    for (int i = 0; i < D; i++) {
-        hav[i] = c[Lay::HA + i];
-        kv[i] = c[Lay::K + i];
-        asm volatile("" : "+v"(hav[i]), "+v"(kv[i]));
+        for (int lv = 0; lv < NRES; lv++) load_slabs<T, NSL>(c + Lay::SP + lv * Lay::LS, lane, sp[lv]);
     }
+
+    // The stream of the NEXT segment is fetched into registers while the current one is replayed (the replay needs few
+    // registers and no memory), so a wave never sits waiting for HBM at a segment boundary.
+    V pre[CK / EPV];
+    auto fetch = [&](size_t t0, int n) {
+        int lo = lane;
+        asm volatile("" : "+v"(lo));       // recompute the lane addresses here: hoisted out of the loop they would be 32 live registers
+#pragma unroll
+        for (int r = 0; r < CK / EPV; r++) {
+            const int e = (r * 64 + lane) * EPV;
+            V v{};                                                   // always (re)defined: dead between its use and the next fetch
+            // (uniform base + 32-bit lane offset: 64-bit per-lane addresses for all the loads would cost 32 registers)
+            if (e < n) v = nt_load(reinterpret_cast<const V*>(row + t0) + (r * 64 + lo));
+            pre[r] = v;
+        }
+    };
+    if (PF && Tlen > 0) fetch(0, (int)(Tlen < (size_t)SEG ? Tlen : (size_t)SEG));
 
     for (size_t t0 = 0; t0 < Tlen; t0 += SEG) {
         const int n = (int)(Tlen - t0 < (size_t)SEG ? Tlen - t0 : (size_t)SEG);
+        // ---- issue this segment's table traffic first: the response slabs (used once per segment, so streamed rather than
+        // kept) and the diagonal blocks of A for the replay (scalar loads; the SGPRs are idle until then) ----
+        const uptr<T> cu = launder(c);
+        constexpr int NSG0 = NSG / 2, NSG1 = NSG - NSG0;           // two halves: the second is fetched while the first is used
+        T g0[NSG0], g1[NSG1];
+        load_slabs<T, NSG0>(cu + Lay::G, lane, g0);
+        if constexpr (PF) load_slabs<T, NSG1>(cu + Lay::G + NSG0 * 16, lane, g1);
+        T ablk[J * DB * DB];
+#pragma unroll
+        for (int i = 0; i < J * DB * DB; i++) ablk[i] = cu[Lay::AB + i];
         // ---- stage in: coalesced 16-byte loads, chunk-major into the padded tile ----
 #pragma unroll
         for (int r = 0; r < CK / EPV; r++) {
             const int e = (r * 64 + lane) * EPV;
             T vals[EPV];
-            if (e < n) unpack<T>(nt_load(reinterpret_cast<const V*>(row + t0 + e)), vals);
+            if constexpr (PF) unpack<T>(pre[r], vals);
+            else if (e < n) unpack<T>(nt_load(reinterpret_cast<const V*>(row + t0 + e)), vals);
 #pragma unroll
             for (int q = 0; q < EPV; q++) if (e + q >= n) vals[q] = T(0);        // beyond the stream: inert zeros
             *reinterpret_cast<V*>(tile + (e / CK) * STRIDE + (e % CK)) = pack<T>(vals);
+        }
+        if constexpr (PF) __builtin_amdgcn_sched_barrier(0);         // (the prefetch registers are free from here on)
+        if constexpr (PF) {
+#pragma unroll
+            for (int lv = 0; lv < NRES; lv++) load_slabs<T, NSL>(cu + Lay::SP + lv * Lay::LS, lane, sp[lv]);   // (M^16, M^32: on demand below)
+        } else {
+            load_slabs<T, NSG1>(cu + Lay::G + NSG0 * 16, lane, g1);
         }
         wave_lds_fence();
         // ---- chunk response z = sum_k g_k y_k, and the missing-data test ----
@@ -195,34 +254,47 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
 #pragma unroll
         for (int i = 0; i < D; i++) z[i] = T(0);
         bool bad = false;
-#pragma unroll 1
-        for (int kv = 0; kv < CK / EPV; kv++) {
+        static_for<CK / EPV>([&](auto kvv) {
+            constexpr int kv = decltype(kvv)::value;
             T yv[EPV];
             unpack<T>(*reinterpret_cast<const V*>(tile_lane + kv * EPV), yv);
-            const uptr<T> g = launder(c + Lay::G + kv * EPV * D);
-#pragma unroll
-            for (int q = 0; q < EPV; q++) {
-                bad = bad || (yv[q] != yv[q]);
-#pragma unroll
-                for (int i = 0; i < D; i++) z[i] = fma(g[q * D + i], yv[q], z[i]);
-            }
-        }
+            static_for<EPV>([&](auto qq) {
+                constexpr int k = kv * EPV + decltype(qq)::value;
+                bad = bad || (yv[decltype(qq)::value] != yv[decltype(qq)::value]);
+                static_for<D>([&](auto ii) {
+                    constexpr int e = k * D + decltype(ii)::value, sl = e / 16;
+                    if constexpr (sl < NSG0) fmac_bc<e % 16>(z[decltype(ii)::value], g0[sl], yv[decltype(qq)::value]);
+                    else fmac_bc<e % 16>(z[decltype(ii)::value], g1[sl - NSG0], yv[decltype(qq)::value]);
+                });
+            });
+            // keep the scheduler from hoisting every LDS read of the chunk to the top (that alone would be 64 registers)
+            if constexpr (PF && kv % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+        });
+        const size_t left = t0 + SEG < Tlen ? Tlen - (t0 + SEG) : 0;
+        const int nnext = (int)(left < (size_t)SEG ? left : (size_t)SEG);
         if (!scan_ok || __builtin_amdgcn_ballot_w64(bad) != 0) {
+            if constexpr (PF) { fetch(t0 + SEG, nnext); __builtin_amdgcn_sched_barrier(0); }
             sequential<T, D, WRITE, NLL>(c, tile, STRIDE, n, lane, xc, acc, nobs);
         } else {
             // ---- carry-in on lane 0, then the 64-lane Kogge-Stone scan with uniform powers ----
             T t[D];
 #pragma unroll
             for (int i = 0; i < D; i++) t[i] = T(0);
-            matvec_u<T, D>(c + Lay::SP, xc, t);
+            matvec_bc<T, D, NSL>(sp[0], xc, t);
 #pragma unroll
             for (int i = 0; i < D; i++) z[i] += (lane == 0) ? t[i] : T(0);
 #pragma unroll
             for (int lv = 0; lv < 6; lv++) {
+                if (lv >= nlev) break;                               // uniform: the remaining powers are negligible
                 const int s = 1 << lv, addr = ((lane - s) & 63) * 4;
 #pragma unroll
                 for (int i = 0; i < D; i++) { const T m = bperm<T>(addr, z[i]); t[i] = lane >= s ? m : T(0); }
-                matvec_u<T, D>(c + Lay::SP + lv * D * D, t, z);
+                if (lv < NRES) matvec_bc<T, D, NSL>(sp[lv < NRES ? lv : 0], t, z);
+                else {
+                    T hi[NSL];
+                    load_slabs<T, NSL>(cu + Lay::SP + lv * Lay::LS, lane, hi);
+                    matvec_bc<T, D, NSL>(hi, t, z);
+                }
             }
             // ---- start state of every lane = end state of the lane before it ----
             T xs[D];
@@ -231,8 +303,13 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
 #pragma unroll
                 for (int i = 0; i < D; i++) { const T m = bperm<T>(addr, z[i]); xs[i] = lane >= 1 ? m : xc[i]; }
             }
-            if (n == SEG) replay<T, DB, J, WRITE, NLL, false>(c, tile_lane, lane * CK, n, hav, kv, xs, acc, nobs);
-            else replay<T, DB, J, WRITE, NLL, true>(c, tile_lane, lane * CK, n, hav, kv, xs, acc, nobs);
+            if constexpr (PF) {
+                __builtin_amdgcn_sched_barrier(0);
+                fetch(t0 + SEG, nnext);                              // next segment's stream, in flight during the replay
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (n == SEG) replay<T, DB, J, WRITE, NLL, false>(ablk, ha, kk, tile_lane, lane * CK, n, xs, acc, nobs);
+            else replay<T, DB, J, WRITE, NLL, true>(ablk, ha, kk, tile_lane, lane * CK, n, xs, acc, nobs);
             const int jl = (n - 1) / CK;                             // the lane that holds the last tick
 #pragma unroll
             for (int i = 0; i < D; i++) xc[i] = read_lane(xs[i], jl);
@@ -240,10 +317,16 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
         // ---- stage out ----
         if (WRITE) {
             wave_lds_fence();
+            int lo = lane;
+            if constexpr (PF) asm volatile("" : "+v"(lo));
 #pragma unroll
             for (int r = 0; r < CK / EPV; r++) {
                 const int e = (r * 64 + lane) * EPV;
-                if (e < n) nt_store(*reinterpret_cast<const V*>(tile + (e / CK) * STRIDE + (e % CK)), reinterpret_cast<V*>(orow + t0 + e));
+                if (e < n) {
+                    const V out = *reinterpret_cast<const V*>(tile + (e / CK) * STRIDE + (e % CK));
+                    if constexpr (PF) nt_store(out, reinterpret_cast<V*>(orow + t0) + (r * 64 + lo));
+                    else nt_store(out, reinterpret_cast<V*>(orow + t0 + e));
+                }
             }
         }
         wave_lds_fence();

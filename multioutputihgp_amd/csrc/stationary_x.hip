@@ -75,8 +75,9 @@ __global__ void __launch_bounds__(64) stack_update_kernel(double dt, const doubl
     double* o64 = cb64 + l * L::SIZE;
     float* o32 = cb32 + l * L::SIZE;
     auto put = [&](int off, double v) { o64[off] = v; o32[off] = (float)v; };
+    for (int i = L::AB; i < L::SIZE; i++) put(i, 0.0);                   // padding of the slab tables
     for (int i = 0; i < NN; i++) { put(L::AKHA + i, AKHA[i]); put(L::A + i, A[i]); }
-    for (int i = 0; i < D; i++) { put(L::K + i, K[i]); put(L::HA + i, HA[i]); }
+    for (int i = 0; i < D; i++) { put(L::K + i, K[i]); put(L::HA + i, HA[i]); put(L::K16 + i, K[i]); put(L::HA16 + i, HA[i]); }
     put(L::S, S); put(L::LOGS, log(S)); put(L::ITERS, (double)dare_iters);
     for (int j = 0; j < J; j++)
         for (int a = 0; a < DB; a++)
@@ -92,10 +93,16 @@ __global__ void __launch_bounds__(64) stack_update_kernel(double dt, const doubl
     }
     for (int i = 0; i < NN; i++) T1[i] = AKHA[i];
     for (int q = 1; q < kChunkX; q <<= 1) mm<D>(T1, T1, T1);            // M = AKHA^CK
+    int nlev64 = 1, nlev32 = 1;
     for (int lv = 0; lv < 6; lv++) {
-        for (int i = 0; i < NN; i++) { put(L::SP + lv * NN + i, T1[i]); ok = ok && (fabs(T1[i]) < 1e18); }   // false for NaN too
+        double big = 0.0;
+        for (int i = 0; i < NN; i++) { put(L::SP + lv * L::LS + i, T1[i]); ok = ok && (fabs(T1[i]) < 1e18); big = fmax(big, fabs(T1[i])); }   // false for NaN too
+        if (big * D >= 1e-20) nlev64 = lv + 1;
+        if (big * D >= 1e-10) nlev32 = lv + 1;
         mm<D>(T1, T1, T1);
     }
+    o64[L::NLEV] = (double)nlev64;
+    o32[L::NLEV] = (float)nlev32;
     put(L::SCANOK, ok ? 1.0 : 0.0);
     if (!ok) { atomicAdd(&n_unstable[0], 1); atomicAdd(&n_unstable[1], 1); }
 }
