@@ -1,4 +1,4 @@
-// stationary_x.hip -- IHGP::update (filter-mode part, ihgp.h:117-133) for STACKED models: one lane per latent, fp64.
+// stationary_x.hip -- IHGP::update (filter-mode part, ihgp.h:117-133) for STACKED models: one wavefront per latent, fp64.
 //
 // A stacked model is the sum of J Matern components observed through one output (include/moihgp.h, MOIHGP_STACK): not a
 // class of the reference, but exactly what its IHGP<StateSpace> template computes for a StateSpace whose F and Pinf are
@@ -32,84 +32,182 @@ __device__ void component(double magnitude, double lengthscale, double* F, doubl
     }
 }
 
+// ---- wave-cooperative dense helpers: a D x D matrix lives in (wave-private) LDS, lane e owns entries e, e+64, e+128.
+// Every entry is accumulated in the same k order as a plain sequential loop (and FP contraction is off), so results -- and
+// with them the DARE iteration count -- are those of a one-thread evaluation.
+__device__ inline void lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+template <int D>
+__device__ inline void wmm(const double* A, const double* B, double* C, int lane) {          // C = A B (C may alias A or B)
+    double r[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        const int e = lane + 64 * q;
+        double sum = 0.0;
+        if (e < D * D) {
+            const int i = e / D, j = e % D;
+            for (int k = 0; k < D; k++) sum += A[i * D + k] * B[k * D + j];
+        }
+        r[q] = sum;
+    }
+    lds_sync();
+#pragma unroll
+    for (int q = 0; q < 3; q++) if (lane + 64 * q < D * D) C[lane + 64 * q] = r[q];
+    lds_sync();
+}
+template <int D>
+__device__ inline void wmt(const double* A, double* At, int lane) {                           // At = A^T (no aliasing)
+#pragma unroll
+    for (int q = 0; q < 3; q++) { const int e = lane + 64 * q; if (e < D * D) At[(e % D) * D + e / D] = A[e]; }
+    lds_sync();
+}
+template <int D>
+__device__ inline void wmv(const double* A, const double* x, double* y, int lane) {            // y = A x (y may alias x)
+    double sum = 0.0;
+    if (lane < D) for (int k = 0; k < D; k++) sum += A[lane * D + k] * x[k];
+    lds_sync();
+    if (lane < D) y[lane] = sum;
+    lds_sync();
+}
+
 template <int DB, int J>
 __global__ void __launch_bounds__(64) stack_update_kernel(double dt, const double* __restrict__ params, size_t n,
                                                           double* __restrict__ cb64, float* __restrict__ cb32,
                                                           int* __restrict__ n_unstable) {
     constexpr int D = DB * J, NN = D * D, P = 2 * J + 1;
     using L = XC<D>;
-    size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ double sA[NN], sAT[NN], sQ[NN], sP[NN], sT1[NN], sT2[NN], sAKHA[NN], sH[D], sV1[D], sV2[D], sV3[D], sK[D], sHA[D];
+    const size_t l = blockIdx.x;                                   // one wavefront per latent
+    const int lane = threadIdx.x;
     if (l >= n) return;
     const double* prm = params + l * P;
     const double R = prm[2 * J];
-    double A[NN], Pinf[NN], H[D], Q[NN], PP[NN], T1[NN], T2[NN];
-    for (int i = 0; i < NN; i++) { A[i] = 0.0; Pinf[i] = 0.0; }
-    for (int i = 0; i < D; i++) H[i] = 0.0;
-    for (int j = 0; j < J; j++) {
+    for (int e = lane; e < NN; e += 64) { sA[e] = 0.0; sT1[e] = 0.0; }     // sT1 = Pinf for now
+    if (lane < D) sH[lane] = (lane % DB == 0) ? 1.0 : 0.0;
+    lds_sync();
+    if (lane < J) {                                                   // ihgp.h:120, block by block (one lane per block)
         double F[DB * DB], Pj[DB * DB], E[DB * DB];
-        component<DB>(prm[2 * j], prm[2 * j + 1], F, Pj);
+        component<DB>(prm[2 * lane], prm[2 * lane + 1], F, Pj);
         for (int i = 0; i < DB * DB; i++) F[i] *= dt;
-        expm<DB>(F, E);                                                  // ihgp.h:120, block j
+        expm<DB>(F, E);
         for (int a = 0; a < DB; a++)
             for (int b = 0; b < DB; b++) {
-                A[(j * DB + a) * D + j * DB + b] = E[a * DB + b];
-                Pinf[(j * DB + a) * D + j * DB + b] = Pj[a * DB + b];
+                sA[(lane * DB + a) * D + lane * DB + b] = E[a * DB + b];
+                sT1[(lane * DB + a) * D + lane * DB + b] = Pj[a * DB + b];
             }
-        H[j * DB] = 1.0;
     }
-    mt<D>(A, T2);
-    mm<D>(A, Pinf, T1); mm<D>(T1, T2, T2);
-    for (int i = 0; i < NN; i++) T1[i] = Pinf[i] - T2[i];              // ihgp.h:121
-    for (int i = 0; i < D; i++)
-        for (int j = 0; j < D; j++) Q[i * D + j] = (T1[i * D + j] + T1[j * D + i]) / 2.0;   // ihgp.h:122
-    int dare_iters = dare<D>(A, H, Q, R, PP);                          // ihgp.h:125
-    double K[D], HA[D], AKHA[NN];
-    mv<D>(PP, H, K);
+    lds_sync();
+    wmt<D>(sA, sAT, lane);
+    wmm<D>(sA, sT1, sT2, lane);                                       // A Pinf
+    wmm<D>(sT2, sAT, sT2, lane);                                      // A Pinf A^T
+    for (int e = lane; e < NN; e += 64) sP[e] = sT1[e] - sT2[e];      // ihgp.h:121 (sP as scratch)
+    lds_sync();
+    for (int e = lane; e < NN; e += 64) sQ[e] = (sP[e] + sP[(e % D) * D + e / D]) / 2.0;     // ihgp.h:122
+    lds_sync();
+
+    // ---- DARE, utils/dare.h:10-33 with Ad = A, Bd = H^T ----
+    for (int e = lane; e < NN; e += 64) sP[e] = sQ[e];
+    lds_sync();
+    int dare_iters = kDareMaxIter;
+    for (int it = 0; it < kDareMaxIter; it++) {
+        wmm<D>(sAT, sP, sT1, lane);                                   // AdT P
+        wmm<D>(sT1, sA, sT2, lane);                                   // AdT P Ad
+        wmv<D>(sP, sH, sV1, lane);                                    // PB = P Bd
+        double g = R;
+        for (int i = 0; i < D; i++) g += sH[i] * sV1[i];              // R + BdT P Bd (every lane, same order)
+        wmv<D>(sAT, sV1, sV2, lane);                                  // APB = AdT P Bd
+        {   // BtP[j] = sum_i Bd[i] P[i][j];  BPA[j] = sum_k BtP[k] Ad[k][j]
+            double sum = 0.0;
+            if (lane < D) for (int i = 0; i < D; i++) sum += sH[i] * sP[i * D + lane];
+            lds_sync();
+            if (lane < D) sV3[lane] = sum;
+            lds_sync();
+            sum = 0.0;
+            if (lane < D) for (int k = 0; k < D; k++) sum += sV3[k] * sA[k * D + lane];
+            lds_sync();
+            if (lane < D) sV3[lane] = sum;                            // BPA
+            lds_sync();
+        }
+        const double ginv = 1.0 / g;
+        double diff = -INFINITY;
+        for (int e = lane; e < NN; e += 64) {
+            const int i = e / D, j = e % D;
+            const double v = sT2[e] - sV2[i] * ginv * sV3[j] + sQ[e];   // dare.h:23
+            sT1[e] = v;
+            const double dlt = v - sP[e];
+            if (dlt > diff) diff = dlt;                               // maxCoeff, dare.h:25
+        }
+        for (int o = 32; o >= 1; o >>= 1) { const double other = __shfl_xor(diff, o, 64); if (other > diff) diff = other; }
+        diff = fabs(diff);
+        lds_sync();
+        for (int e = lane; e < NN; e += 64) sP[e] = (sT1[e] + sT1[(e % D) * D + e / D]) / 2.0;   // dare.h:26
+        lds_sync();
+        if (diff < kDareTol) { dare_iters = it + 1; break; }
+    }
+    wmv<D>(sP, sH, sV1, lane);                                        // PP H^T
     double S = R;
-    for (int i = 0; i < D; i++) S += H[i] * K[i];                       // ihgp.h:126
-    for (int i = 0; i < D; i++) K[i] = K[i] / S;                        // ihgp.h:127
-    for (int j = 0; j < D; j++) { double t = 0.0; for (int i = 0; i < D; i++) t += H[i] * A[i * D + j]; HA[j] = t; }   // ihgp.h:129
-    for (int i = 0; i < D; i++)
-        for (int j = 0; j < D; j++) AKHA[i * D + j] = A[i * D + j] - K[i] * HA[j];   // ihgp.h:130
+    for (int i = 0; i < D; i++) S += sH[i] * sV1[i];                  // ihgp.h:126
+    if (lane < D) sK[lane] = sV1[lane] / S;                           // ihgp.h:127
+    {
+        double t = 0.0;
+        if (lane < D) for (int i = 0; i < D; i++) t += sH[i] * sA[i * D + lane];
+        if (lane < D) sHA[lane] = t;                                  // ihgp.h:129
+    }
+    lds_sync();
+    for (int e = lane; e < NN; e += 64) sAKHA[e] = sA[e] - sK[e / D] * sHA[e % D];             // ihgp.h:130
+    lds_sync();
 
     double* o64 = cb64 + l * L::SIZE;
     float* o32 = cb32 + l * L::SIZE;
     auto put = [&](int off, double v) { o64[off] = v; o32[off] = (float)v; };
-    for (int i = L::AB; i < L::SIZE; i++) put(i, 0.0);                   // padding of the slab tables
-    for (int i = 0; i < NN; i++) { put(L::AKHA + i, AKHA[i]); put(L::A + i, A[i]); }
-    for (int i = 0; i < D; i++) { put(L::K + i, K[i]); put(L::HA + i, HA[i]); put(L::K16 + i, K[i]); put(L::HA16 + i, HA[i]); }
-    put(L::S, S); put(L::LOGS, log(S)); put(L::ITERS, (double)dare_iters);
-    for (int j = 0; j < J; j++)
-        for (int a = 0; a < DB; a++)
-            for (int b = 0; b < DB; b++) put(L::AB + j * DB * DB + a * DB + b, A[(j * DB + a) * D + j * DB + b]);
+    // every entry of the block is written exactly once (the slab tables with their zero padding)
+    for (int e = lane; e < NN; e += 64) { put(L::AKHA + e, sAKHA[e]); put(L::A + e, sA[e]); }
+    if (lane < D) { put(L::K + lane, sK[lane]); put(L::HA + lane, sHA[lane]); }
+    if (lane < 16) { put(L::K16 + lane, lane < D ? sK[lane] : 0.0); put(L::HA16 + lane, lane < D ? sHA[lane] : 0.0); }
+    if (lane == 0) { put(L::S, S); put(L::LOGS, log(S)); put(L::ITERS, (double)dare_iters); }
+    for (int e = lane; e < L::HA16 - L::AB; e += 64) {
+        const int j = e / (DB * DB), a = (e / DB) % DB, b = e % DB;
+        put(L::AB + e, e < J * DB * DB ? sA[(j * DB + a) * D + j * DB + b] : 0.0);
+    }
+    for (int e = kChunkX * D + lane; e < L::GN; e += 64) put(L::G + e, 0.0);
 
     // tables of the segment solve (recursion_x.hip): g_k = AKHA^(CK-1-k) K, and M^(2^lv) with M = AKHA^CK
     bool ok = true;
-    double g[D];
-    for (int i = 0; i < D; i++) g[i] = K[i];
+    if (lane < D) sV1[lane] = sK[lane];
+    lds_sync();
     for (int k = kChunkX - 1; k >= 0; k--) {
-        for (int i = 0; i < D; i++) { put(L::G + k * D + i, g[i]); ok = ok && (fabs(g[i]) < 1e18); }
-        mv<D>(AKHA, g, g);
+        if (lane < D) { put(L::G + k * D + lane, sV1[lane]); ok = ok && (fabs(sV1[lane]) < 1e18); }
+        wmv<D>(sAKHA, sV1, sV1, lane);
     }
-    for (int i = 0; i < NN; i++) T1[i] = AKHA[i];
-    for (int q = 1; q < kChunkX; q <<= 1) mm<D>(T1, T1, T1);            // M = AKHA^CK
+    for (int e = lane; e < NN; e += 64) sT1[e] = sAKHA[e];
+    lds_sync();
+    for (int q = 1; q < kChunkX; q <<= 1) wmm<D>(sT1, sT1, sT1, lane);  // M = AKHA^CK
     int nlev64 = 1, nlev32 = 1;
     for (int lv = 0; lv < 6; lv++) {
         double big = 0.0;
-        for (int i = 0; i < NN; i++) { put(L::SP + lv * L::LS + i, T1[i]); ok = ok && (fabs(T1[i]) < 1e18); big = fmax(big, fabs(T1[i])); }   // false for NaN too
+        for (int e = lane; e < L::LS; e += 64) {
+            const double v = e < NN ? sT1[e] : 0.0;
+            put(L::SP + lv * L::LS + e, v); ok = ok && (fabs(v) < 1e18); big = fmax(big, fabs(v));   // false for NaN too
+        }
+        for (int o = 32; o >= 1; o >>= 1) big = fmax(big, __shfl_xor(big, o, 64));
         if (big * D >= 1e-20) nlev64 = lv + 1;
         if (big * D >= 1e-10) nlev32 = lv + 1;
-        mm<D>(T1, T1, T1);
+        wmm<D>(sT1, sT1, sT1, lane);
     }
-    o64[L::NLEV] = (double)nlev64;
-    o32[L::NLEV] = (float)nlev32;
-    put(L::SCANOK, ok ? 1.0 : 0.0);
-    if (!ok) { atomicAdd(&n_unstable[0], 1); atomicAdd(&n_unstable[1], 1); }
+    ok = __builtin_amdgcn_ballot_w64(!ok) == 0;
+    if (lane == 0) {
+        o64[L::NLEV] = (double)nlev64;
+        o32[L::NLEV] = (float)nlev32;
+        put(L::SCANOK, ok ? 1.0 : 0.0);
+        if (!ok) { atomicAdd(&n_unstable[0], 1); atomicAdd(&n_unstable[1], 1); }
+    }
 }
 
 template <int DB, int J>
 void launch_t(double dt, const double* params, size_t n, double* cb64, float* cb32, int* n_unstable, hipStream_t s) {
-    hipLaunchKernelGGL((stack_update_kernel<DB, J>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, dt, params, n, cb64, cb32, n_unstable);
+    hipLaunchKernelGGL((stack_update_kernel<DB, J>), dim3((unsigned)n), dim3(64), 0, s, dt, params, n, cb64, cb32, n_unstable);
 }
 
 }  // namespace
