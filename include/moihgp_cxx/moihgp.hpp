@@ -14,6 +14,7 @@
 #include <cstddef>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 extern "C" {
@@ -47,9 +48,10 @@ public:
     MOIHGP(const MOIHGP&) = delete;
     MOIHGP& operator=(const MOIHGP&) = delete;
 
+    // (y may be an expression such as `y - mean` of the caller's vector library, so its type is independent of yhat's / grad's)
     // moihgp.h:148  step(x, y, dx, xnew, yhat, dxnew)
-    template <class VecList, class Vec, class VecListList>
-    void step(const VecList& x, const Vec& y, const VecListList& dx, VecList& xnew, Vec& yhat, VecListList& dxnew) {
+    template <class VecList, class VecIn, class Vec, class VecListList>
+    void step(const VecList& x, const VecIn& y, const VecListList& dx, VecList& xnew, Vec& yhat, VecListList& dxnew) {
         pack_x(x); pack_y(y); pack_dx(dx);
         gp32_step1(_gp, _x.data(), _y.data(), _dx.data(), _xnew.data(), _yhat.data(), _dxnew.data());
         unpack_x(xnew); unpack_y(yhat); unpack_dx(dxnew);
@@ -62,8 +64,8 @@ public:
         unpack_x(xnew); unpack_dx(dxnew);
     }
     // moihgp.h:304  step(x, y, xnew, yhat)
-    template <class VecList, class Vec>
-    void step(const VecList& x, const Vec& y, VecList& xnew, Vec& yhat) {
+    template <class VecList, class VecIn, class Vec>
+    void step(const VecList& x, const VecIn& y, VecList& xnew, Vec& yhat) {
         pack_x(x); pack_y(y);
         gp32_step3(_gp, _x.data(), _y.data(), _xnew.data(), _yhat.data());
         unpack_x(xnew); unpack_y(yhat);
@@ -82,8 +84,8 @@ public:
         gp32_update(_gp, _p.data());
     }
     // moihgp.h:460  negLogLikelihood(x, y, dx, grad)
-    template <class VecList, class Vec, class VecListList>
-    double negLogLikelihood(const VecList& x, const Vec& y, const VecListList& dx, Vec& grad) {
+    template <class VecList, class VecIn, class Vec, class VecListList>
+    double negLogLikelihood(const VecList& x, const VecIn& y, const VecListList& dx, Vec& grad) {
         pack_x(x); pack_y(y); pack_dx(dx);
         double loss = gp32_lik1(_gp, _x.data(), _y.data(), _dx.data(), _p.data());
         if ((size_t)grad.size() != _num_param) grad.resize(_num_param);
@@ -97,9 +99,27 @@ public:
         return gp32_lik2(_gp, _x.data(), _y.data());
     }
     // moihgp.h:721  getParams()  -> [U row-major | S | sigma | (magnitude, lengthscale, noise) x L]
-    std::vector<double> getParams() {
-        std::vector<double> p(_num_param);
-        gp32_get_params(_gp, p.data());
+    // The reference returns an Eigen::VectorXd; this returns a value that converts to whatever vector type the caller
+    // initialises or assigns from it (std::vector<double>, Eigen::VectorXd, ...: anything with resize(n) and operator[]).
+    struct Params {
+        std::vector<double> values;
+        operator const std::vector<double>&() const { return values; }
+        template <class V, class = decltype(std::declval<V&>().resize(std::declval<size_t>())), class = decltype(std::declval<V&>()[0])>
+        operator V() const {
+            V v;
+            v.resize(values.size());
+            for (size_t i = 0; i < values.size(); i++) v[i] = values[i];
+            return v;
+        }
+        size_t size() const { return values.size(); }
+        double operator[](size_t i) const { return values[i]; }
+        std::vector<double>::const_iterator begin() const { return values.begin(); }
+        std::vector<double>::const_iterator end() const { return values.end(); }
+    };
+    Params getParams() {
+        Params p;
+        p.values.resize(_num_param);
+        gp32_get_params(_gp, p.values.data());
         return p;
     }
     size_t getIGPDim() { return _dim; }                   // moihgp.h:691

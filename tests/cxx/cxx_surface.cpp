@@ -19,7 +19,7 @@ int main() {
         for (auto& a : dx) for (auto& b : a) for (auto& v : b) if (scanf("%lf", &v) != 1) return 2;
         int nticks; if (scanf("%d", &nticks) != 1) return 2;
         gp.update(params);
-        Vec p = gp.getParams();
+        Vec p = gp.getParams();                               // converts from MOIHGP::Params
         printf("%zu %zu %zu\n", d, P, np);
         for (double v : p) printf("%.17g ", v); printf("\n");
         for (int t = 0; t < nticks; t++) {
