@@ -121,6 +121,7 @@ struct moihgp_gp {
     double* dwork = nullptr;   // L*L + L, lazily (missing-output projection)
     double* dpolar = nullptr;  // M*L + 2*L*L + 8, lazily (device polar factor)
     int* dfallback = nullptr;  // [L] flags of latents redone by the sequential gradient kernel
+    double* dxscratch = nullptr; // stacked kernels, few latents: per-slice NLL partials
     bool U_host_stale = false; // the device holds a newer U than the host mirror (fetched on getParams)
     double *hin = nullptr, *hout = nullptr, *hgrad = nullptr;   // page-locked per-tick staging (hout / hgrad are device-mapped)
     std::vector<void*> pinned; // caller buffers page-locked through moihgp_pin_host_buffer
@@ -137,7 +138,7 @@ struct moihgp_gp {
 
 static void gp_free(moihgp_gp* g) {
     if (!g) return;
-    void* ptrs[] = {g->dU, g->dS, g->dsqrtS, g->dinvsqrtS, g->dsigma, g->dparams, g->cb64, g->cb32, g->dx, g->dpart, g->dTy, g->dUty, g->dTyhat, g->dloss, g->dgrad, g->dscratch, g->dwork, g->dpolar, g->dfallback, g->dwin, g->dunstable};
+    void* ptrs[] = {g->dU, g->dS, g->dsqrtS, g->dinvsqrtS, g->dsigma, g->dparams, g->cb64, g->cb32, g->dx, g->dpart, g->dTy, g->dUty, g->dTyhat, g->dloss, g->dgrad, g->dscratch, g->dwork, g->dpolar, g->dfallback, g->dwin, g->dunstable, g->dxscratch};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (void* p : g->pinned) (void)hipHostUnregister(p);
@@ -496,8 +497,13 @@ int moihgp_filter_stream(moihgp_gp* gp, int dtype, const void* Ty, size_t T, siz
         e1 = gp->prof_ev[2 * gp->prof_n + 1];
         gp->prof_n++;
     }
-    if (kernel_stack(gp->kernel))
-        return launch_filter_stream_x(gp->kernel, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cb32, x, yhat, nll, (hipStream_t)stream, e0, e1);
+    if (kernel_stack(gp->kernel)) {
+        const size_t slen = gp->L < 1024 ? gp->L * 16 : 0;              // per-slice NLL partials of the time split (few latents only)
+        if (slen && !gp->dxscratch) gp->dxscratch = dev_alloc<double>(slen);
+        const char* fs = std::getenv("MOIHGP_FILTER_SPLIT");            // tuning / test hook, as for the reference models: 1 = off, n = slices
+        return launch_filter_stream_x(gp->kernel, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cb32, x, yhat, nll, (hipStream_t)stream, e0, e1,
+                                      gp->dxscratch, slen, fs ? std::atoi(fs) : 0);
+    }
     // time split across the wavefronts of a workgroup when there are too few latents to fill the chip
     int nsplit = 1; size_t Tslice = T;
     filter_split_plan(dtype, T, gp->L, &nsplit, &Tslice);

@@ -89,7 +89,7 @@ __device__ inline void matvec_bc(const T (&m)[NS], const T (&v)[D], T (&out)[D])
 }
 
 template <typename T, int DB, int J, bool WRITE, bool NLL, bool TAIL>
-__device__ inline void replay(const T (&a)[J * DB * DB], const T& ha, const T& kk, T* tile_lane, int first_tick, int n,
+__device__ inline void replay(const T (&a)[J * DB * DB], const T& ha, const T& kk, T* tile_lane, int first_tick, int n, int head,
                               T (&xs)[DB * J], double& acc, unsigned& nobs) {
     constexpr int D = DB * J;
 #pragma unroll 1
@@ -102,7 +102,7 @@ __device__ inline void replay(const T (&a)[J * DB * DB], const T& ha, const T& k
         });
         const T v = y - ((h0 + h1) + h2);
         const bool valid = !TAIL || (first_tick + k < n);
-        if (NLL && valid) {
+        if (NLL && valid && (!TAIL || first_tick + k >= head)) {       // (head: warm-up ticks of a time slice are not counted)
             const double vd = (double)v;
             acc = fma(vd, vd, acc);                                 // ihgp.h:206-207, pre-step state
             nobs++;
@@ -126,7 +126,7 @@ __device__ inline void replay(const T (&a)[J * DB * DB], const T& ha, const T& k
 
 // n ticks of the tile, one after the other: lane i < D owns row i of AKHA (and of A for missing ticks), lane D owns HA.
 template <typename T, int D, bool WRITE, bool NLL>
-__device__ inline void sequential(const T* __restrict__ c, T* tile, int stride, int n, int lane, T (&xc)[D], double& acc, unsigned& nobs) {
+__device__ inline void sequential(const T* __restrict__ c, T* tile, int stride, int n, int head, int lane, T (&xc)[D], double& acc, unsigned& nobs) {
     using Lay = XC<D>;
     T rowF[D], rowP[D], kk = 0, xv = 0;
     const int r = lane < D ? lane : 0;
@@ -153,7 +153,7 @@ __device__ inline void sequential(const T* __restrict__ c, T* tile, int stride, 
             s = fma(kk, y, s);
             if (NLL) {
                 const double v = (double)(y - read_lane(s, D));      // lane D computed HA x
-                if (lane == 0) { acc = fma(v, v, acc); nobs++; }
+                if (lane == 0 && t >= head) { acc = fma(v, v, acc); nobs++; }
             }
         }
         xv = s;
@@ -163,10 +163,15 @@ __device__ inline void sequential(const T* __restrict__ c, T* tile, int stride, 
     for (int i = 0; i < D; i++) xc[i] = read_lane(xv, i);
 }
 
-template <typename T, int DB, int J, bool WRITE, bool NLL, int WPB>
+// SPLIT (few latents, WPB == 1): workgroup (l, s) of the 2-D grid handles time slice s of latent l.  A slice after the first
+// starts from a ZERO state a warm-up of CK * 2^nlev ticks before its first tick: the true state there would only enter
+// through AKHA^(CK 2^nlev) = M^(2^nlev), which the update kernel has flagged as below 1e-20 (1e-10 in fp32) -- the criterion
+// by which the scan already drops its upper levels.  Warm-up ticks are neither counted nor written.  Latents that do not
+// decay that fast (nlev = 6, or unstable) are run whole by slice 0.  Per-slice NLL partials go to nll_part [L][nslice].
+template <typename T, int DB, int J, bool WRITE, bool NLL, int WPB, bool SPLIT>
 __global__ void __launch_bounds__(64 * WPB)
 filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, const T* __restrict__ cbT, const double* __restrict__ cb64,
-                T* __restrict__ x, T* __restrict__ yhat, double* __restrict__ nll) {
+                T* __restrict__ x, T* __restrict__ yhat, double* __restrict__ nll, int nslice, int segs_per_slice, double* __restrict__ nll_part) {
     constexpr int D = DB * J;
     using V = typename VecOf<T>::type;
     using Lay = XC<D>;
@@ -174,7 +179,8 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
     __shared__ __attribute__((aligned(16))) T tiles[WPB][64 * STRIDE];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const size_t l = (size_t)blockIdx.x * WPB + wave;
+    const size_t l = SPLIT ? (size_t)blockIdx.x : (size_t)blockIdx.x * WPB + wave;   // SPLIT: grid = (latents, slices)
+    const int slice = SPLIT ? (int)blockIdx.y : 0;
     if (l >= L) return;                                              // no workgroup barrier below
     const T* __restrict__ c = cbT + l * Lay::SIZE;
     T* tile = tiles[wave];
@@ -186,7 +192,7 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
     for (int i = 0; i < D; i++) xc[i] = x[l * D + i];
     double acc = 0.0;
     unsigned nobs = 0;
-    const bool scan_ok = c[Lay::SCANOK] != T(0);
+    const bool scan_ok = __builtin_amdgcn_readfirstlane((int)(c[Lay::SCANOK] != T(0))) != 0;
     // Two register plans.  PF (everything but fp64 with 9+ states): the scan powers and the response table are streamed in at
     // the start of every segment (L2-resident, coalesced, issued ahead of the phases that use them), which leaves room to
     // fetch the NEXT segment of the stream into registers during the replay.  !PF: no registers to spare for that, so the four
@@ -194,7 +200,27 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
     constexpr bool PF = !(sizeof(T) == 8 && D > 8);
     constexpr int NSL = Lay::LS / 16, NSG = Lay::GN / 16, NRES = 4;
     T ha = c[Lay::HA16 + (lane & 15)], kk = c[Lay::K16 + (lane & 15)];
-    const int nlev = (int)c[Lay::NLEV];
+    const int nlev = __builtin_amdgcn_readfirstlane((int)c[Lay::NLEV]);
+    // the ticks this wave sweeps: [t_start, t_end), of which [t_begin, t_end) count (everything, unless SPLIT)
+    size_t t_begin = 0, t_end = Tlen, t_start = 0;
+    bool last = true;
+    if (SPLIT) {
+        const bool split_ok = scan_ok && nlev <= 5;                  // M^(2^nlev) is in the table and negligible
+        if (split_ok) {
+            t_begin = (size_t)slice * segs_per_slice * SEG;
+            t_end = t_begin + (size_t)segs_per_slice * SEG < Tlen ? t_begin + (size_t)segs_per_slice * SEG : Tlen;
+        }
+        if ((!split_ok && slice > 0) || t_begin >= t_end) {          // nothing to do for this slice
+            if (NLL && lane == 0) nll_part[l * nslice + slice] = 0.0;
+            if (Tlen > 0 || slice > 0) return;
+        }
+        if (split_ok && slice > 0) {
+            t_start = t_begin - ((size_t)CK << nlev);                // t_begin >= SEG = 64 CK >= CK 2^nlev
+#pragma unroll
+            for (int i = 0; i < D; i++) xc[i] = T(0);
+        }
+        last = (t_end == Tlen);
+    }
     T sp[NRES][NSL];
     if (!PF) {
 #pragma unroll
@@ -216,10 +242,11 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
             pre[r] = v;
         }
     };
-    if (PF && Tlen > 0) fetch(0, (int)(Tlen < (size_t)SEG ? Tlen : (size_t)SEG));
+    if (PF && t_end > t_start) fetch(t_start, (int)(t_end - t_start < (size_t)SEG ? t_end - t_start : (size_t)SEG));
 
-    for (size_t t0 = 0; t0 < Tlen; t0 += SEG) {
-        const int n = (int)(Tlen - t0 < (size_t)SEG ? Tlen - t0 : (size_t)SEG);
+    for (size_t t0 = t_start; t0 < t_end; t0 += SEG) {
+        const int n = (int)(t_end - t0 < (size_t)SEG ? t_end - t0 : (size_t)SEG);
+        const int head = SPLIT && t_begin > t0 ? (int)(t_begin - t0) : 0;      // warm-up ticks at the front of this segment
         // ---- issue this segment's table traffic first: the response slabs (used once per segment, so streamed rather than
         // kept) and the diagonal blocks of A for the replay (scalar loads; the SGPRs are idle until then) ----
         const uptr<T> cu = launder(c);
@@ -270,11 +297,11 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
             // keep the scheduler from hoisting every LDS read of the chunk to the top (that alone would be 64 registers)
             if constexpr (PF && kv % 4 == 3) __builtin_amdgcn_sched_barrier(0);
         });
-        const size_t left = t0 + SEG < Tlen ? Tlen - (t0 + SEG) : 0;
+        const size_t left = t0 + SEG < t_end ? t_end - (t0 + SEG) : 0;
         const int nnext = (int)(left < (size_t)SEG ? left : (size_t)SEG);
         if (!scan_ok || __builtin_amdgcn_ballot_w64(bad) != 0) {
             if constexpr (PF) { fetch(t0 + SEG, nnext); __builtin_amdgcn_sched_barrier(0); }
-            sequential<T, D, WRITE, NLL>(c, tile, STRIDE, n, lane, xc, acc, nobs);
+            sequential<T, D, WRITE, NLL>(c, tile, STRIDE, n, head, lane, xc, acc, nobs);
         } else {
             // ---- carry-in on lane 0, then the 64-lane Kogge-Stone scan with uniform powers ----
             T t[D];
@@ -308,8 +335,8 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
                 fetch(t0 + SEG, nnext);                              // next segment's stream, in flight during the replay
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (n == SEG) replay<T, DB, J, WRITE, NLL, false>(ablk, ha, kk, tile_lane, lane * CK, n, xs, acc, nobs);
-            else replay<T, DB, J, WRITE, NLL, true>(ablk, ha, kk, tile_lane, lane * CK, n, xs, acc, nobs);
+            if (n == SEG && head == 0) replay<T, DB, J, WRITE, NLL, false>(ablk, ha, kk, tile_lane, lane * CK, n, 0, xs, acc, nobs);
+            else replay<T, DB, J, WRITE, NLL, true>(ablk, ha, kk, tile_lane, lane * CK, n, head, xs, acc, nobs);
             const int jl = (n - 1) / CK;                             // the lane that holds the last tick
 #pragma unroll
             for (int i = 0; i < D; i++) xc[i] = read_lane(xs[i], jl);
@@ -322,7 +349,7 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
 #pragma unroll
             for (int r = 0; r < CK / EPV; r++) {
                 const int e = (r * 64 + lane) * EPV;
-                if (e < n) {
+                if (e < n && e >= head) {                            // (head is a multiple of CK: whole vectors)
                     const V out = *reinterpret_cast<const V*>(tile + (e / CK) * STRIDE + (e % CK));
                     if constexpr (PF) nt_store(out, reinterpret_cast<V*>(orow + t0) + (r * 64 + lo));
                     else nt_store(out, reinterpret_cast<V*>(orow + t0 + e));
@@ -331,7 +358,7 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
         }
         wave_lds_fence();
     }
-    if (lane == 0) {
+    if (lane == 0 && last) {
 #pragma unroll
         for (int i = 0; i < D; i++) x[l * D + i] = xc[i];
     }
@@ -340,22 +367,36 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
         for (int o = 32; o >= 1; o >>= 1) { acc += __shfl_xor(acc, o, 64); nobs += __shfl_xor(nobs, o, 64); }
         if (lane == 0) {
             const double* c64 = cb64 + l * Lay::SIZE;
-            nll[l] = 0.5 * (acc / c64[Lay::S] + (double)nobs * c64[Lay::LOGS]);
+            const double v = 0.5 * (acc / c64[Lay::S] + (double)nobs * c64[Lay::LOGS]);
+            if (SPLIT) nll_part[l * nslice + slice] = v; else nll[l] = v;
         }
     }
 }
 
-template <typename T, int DB, int J, int WPB>
+// nll[l] = sum over the slices, in slice order (deterministic)
+__global__ void __launch_bounds__(256) sum_slices_kernel(const double* __restrict__ part, size_t L, int nslice, double* __restrict__ nll) {
+    const size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= L) return;
+    double s = 0.0;
+    for (int k = 0; k < nslice; k++) s += part[l * nslice + k];
+    nll[l] = s;
+}
+
+template <typename T, int DB, int J, int WPB, bool SPLIT>
 int launch_x(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, const double* cb64, void* x, void* yhat, double* nll,
-             hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
-    dim3 block(64 * WPB), grid((unsigned)((L + WPB - 1) / WPB));
+             hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, int nslice, int segs_per_slice, double* nll_part) {
+    dim3 block(64 * WPB), grid(SPLIT ? (unsigned)L : (unsigned)((L + WPB - 1) / WPB), SPLIT ? (unsigned)nslice : 1u);
     const T* ty = static_cast<const T*>(Ty);
     T* xs = static_cast<T*>(x);
     T* yh = static_cast<T*>(yhat);
-    if (yhat && nll) hipExtLaunchKernelGGL((filter_x_kernel<T, DB, J, true, true, WPB>), grid, block, 0, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xs, yh, nll);
-    else if (yhat) hipExtLaunchKernelGGL((filter_x_kernel<T, DB, J, true, false, WPB>), grid, block, 0, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xs, yh, nll);
-    else if (nll) hipExtLaunchKernelGGL((filter_x_kernel<T, DB, J, false, true, WPB>), grid, block, 0, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xs, yh, nll);
-    else hipExtLaunchKernelGGL((filter_x_kernel<T, DB, J, false, false, WPB>), grid, block, 0, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xs, yh, nll);
+#define MOIHGP_X_LAUNCH(W_, N_) hipExtLaunchKernelGGL((filter_x_kernel<T, DB, J, W_, N_, WPB, SPLIT>), grid, block, 0, stream, ev0, ev1, 0, \
+                                                      ty, Tlen, ld, L, cbT, cb64, xs, yh, nll, nslice, segs_per_slice, nll_part)
+    if (yhat && nll) MOIHGP_X_LAUNCH(true, true);
+    else if (yhat) MOIHGP_X_LAUNCH(true, false);
+    else if (nll) MOIHGP_X_LAUNCH(false, true);
+    else MOIHGP_X_LAUNCH(false, false);
+#undef MOIHGP_X_LAUNCH
+    if (SPLIT && nll) hipLaunchKernelGGL(sum_slices_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, stream, nll_part, L, nslice, nll);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_last_error("filter_x_kernel launch: %s", hipGetErrorString(e)); return 2; }
     return 0;
@@ -363,22 +404,31 @@ int launch_x(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, con
 
 template <typename T, int DB, int J>
 int launch_xd(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, const double* cb64, void* x, void* yhat, double* nll,
-              hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
-    // few latents: one wavefront per workgroup, so that they spread over the compute units
-    if (L < 1024) return launch_x<T, DB, J, 1>(Ty, Tlen, ld, L, cbT, cb64, x, yhat, nll, stream, ev0, ev1);
-    return launch_x<T, DB, J, 4>(Ty, Tlen, ld, L, cbT, cb64, x, yhat, nll, stream, ev0, ev1);
+              hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, double* scratch, size_t scratch_len, int force_slices) {
+    constexpr size_t SEG = 64 * (size_t)kChunkX;
+    if (L >= 1024) return launch_x<T, DB, J, 4, false>(Ty, Tlen, ld, L, cbT, cb64, x, yhat, nll, stream, ev0, ev1, 1, 0, nullptr);
+    // few latents: one wavefront per workgroup, and the stream cut into time slices (one wavefront each) while that adds
+    // wavefronts the chip can still use
+    const size_t nseg = (Tlen + SEG - 1) / SEG;
+    size_t want = force_slices > 0 ? (size_t)force_slices : (2048 + L - 1) / L;
+    if (want > nseg) want = nseg;
+    if (want * L > scratch_len) want = scratch_len / L;
+    if (want < 1) want = 1;                                            // (one slice = the whole stream: same kernel)
+    const size_t per = nseg ? (nseg + want - 1) / want : 1, n = nseg ? (nseg + per - 1) / per : 1;
+    return launch_x<T, DB, J, 1, true>(Ty, Tlen, ld, L, cbT, cb64, x, yhat, nll, stream, ev0, ev1, (int)n, (int)per, scratch);
 }
 
 }  // namespace
 
 int launch_filter_stream_x(int kernel, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* cb64, const float* cb32,
-                           void* x, void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+                           void* x, void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1,
+                           double* scratch, size_t scratch_len, int force_slices) {
     if (L == 0) return 0;
     const int base = kernel_base(kernel), J = kernel_stack(kernel);
 #define MOIHGP_X_CASE(DBB, JJ)                                                                                        \
     if (base == (DBB == 2 ? 0 : 1) && J == JJ)                                                                        \
-        return dtype == 0 ? launch_xd<double, DBB, JJ>(Ty, T, ld, L, cb64, cb64, x, yhat, nll, stream, ev0, ev1)      \
-                          : launch_xd<float, DBB, JJ>(Ty, T, ld, L, cb32, cb64, x, yhat, nll, stream, ev0, ev1)
+        return dtype == 0 ? launch_xd<double, DBB, JJ>(Ty, T, ld, L, cb64, cb64, x, yhat, nll, stream, ev0, ev1, scratch, scratch_len, force_slices)      \
+                          : launch_xd<float, DBB, JJ>(Ty, T, ld, L, cb32, cb64, x, yhat, nll, stream, ev0, ev1, scratch, scratch_len, force_slices)
     MOIHGP_X_CASE(2, 2); MOIHGP_X_CASE(2, 3); MOIHGP_X_CASE(2, 4);
     MOIHGP_X_CASE(3, 2); MOIHGP_X_CASE(3, 3); MOIHGP_X_CASE(3, 4);
 #undef MOIHGP_X_CASE
