@@ -198,7 +198,9 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
     // fetch the NEXT segment of the stream into registers during the replay.  !PF: no registers to spare for that, so the four
     // scan powers stay resident for the whole sweep instead and the stream is fetched at the segment start.
     constexpr bool PF = !(sizeof(T) == 8 && D > 8);
-    constexpr int NSL = Lay::LS / 16, NSG = Lay::GN / 16, NRES = 4;
+    // (scan powers held in registers: one fewer in the split kernels of the resident plan, which carry the slice bookkeeping
+    // on top and must not overflow into AGPRs -- see tools/check_dpp_hazard.py)
+    constexpr int NSL = Lay::LS / 16, NSG = Lay::GN / 16, NRES = (!PF && SPLIT) ? 3 : 4;
     T ha = c[Lay::HA16 + (lane & 15)], kk = c[Lay::K16 + (lane & 15)];
     const int nlev = __builtin_amdgcn_readfirstlane((int)c[Lay::NLEV]);
     // the ticks this wave sweeps: [t_start, t_end), of which [t_begin, t_end) count (everything, unless SPLIT)

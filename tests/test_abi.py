@@ -81,3 +81,13 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     with pytest.raises(_lib.MoihgpError) as ei:
         _lib.load_library()
     assert "no CPU fallback" in str(ei.value)
+
+
+def test_no_dpp_hazard_in_device_code(hip_built):
+    """recursion_x.hip's broadcast FMAs are inline-asm DPP instructions: the compiler does not guard those against the GFX9
+    "VALU writes a VGPR, DPP reads it within two issue slots" hazard, so the built gfx950 code is scanned for it."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_dpp_hazard", os.path.join(ROOT, "tools", "check_dpp_hazard.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    hazards, ndpp = mod.scan(mod.disassemble(os.path.join(ROOT, "build", "obj", "recursion_x.o")))
+    assert ndpp > 1000 and hazards == [], hazards[:5]

@@ -574,11 +574,12 @@ def test_stacked_ragged_shapes_vs_oracle(env, kern, dtype, L, T):
     assert rel_err(nll.cpu().numpy()[ok], o["nll_per_latent"][ok]) < tol * 10
     _, x2, nll2 = bank.filter(Tyd, T=T, x=torch.from_numpy(x0).to(dtype).cuda(), want_yhat=False)
     yh3, x3, _ = bank.filter(Tyd, T=T, x=torch.from_numpy(x0).to(dtype).cuda(), want_nll=False)
+    _, x4, _ = bank.filter(Tyd, T=T, x=torch.from_numpy(x0).to(dtype).cuda(), want_yhat=False, want_nll=False)   # state only
     torch.cuda.synchronize()
     # the nll-only / yhat-only instantiations agree with the fused one to rounding (overflowed latents hold inf / NaN in all)
     rt = 1e-12 if dtype == torch.float64 else 1e-5
     same = lambda a, b: torch.allclose(a, b, rtol=rt, atol=rt * float(torch.nan_to_num(b, nan=0.0, posinf=0.0, neginf=0.0).abs().max()), equal_nan=True)
-    assert same(nll2, nll) and same(x2, xT) and same(x3, xT) and same(yh3[:, :T], yhat[:, :T])
+    assert same(nll2, nll) and same(x2, xT) and same(x3, xT) and same(x4, xT) and same(yh3[:, :T], yhat[:, :T])
 
 
 @pytest.mark.parametrize("kern", ["Matern52x2", "Matern52x4"])
