@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-row measurements of the hot-path scope table beside the CPU oracle, one JSON object per row.
 
-    python tools/bench_rows.py [--rows update,grad,project,tick] [--L 4096] [--T 10000] [--M 4096]
+    python tools/bench_rows.py [--rows update,grad,project,tick,window,stacked] [--L 4096] [--T 10000] [--M 4096]
 
   update   A7  IHGP::update for L latents (ihgp.h:117-201) on device           vs oracle orc_ihgp_update (all cores)
   grad     A2+A5 sensitivity/gradient sweep over streams (ihgp.h:37-57,:212-222)  vs oracle orc_grad_stream (all cores)
@@ -88,6 +88,42 @@ def row_project(a):
     return out
 
 
+def row_stacked(a):
+    """Stacked-state latents: update and filter at BASELINE.json's d = 6 / d = 12 shapes, fp64 and fp32,
+    beside the CPU port (wide oracle build, all cores)."""
+    from multioutputihgp_amd.streams import LatentBank
+    from oracle import cref
+    out = []
+    for kern, L, T in (("Matern52x2", 256, a.T), ("Matern52x2", a.L, a.T), ("Matern52x4", a.L, a.T), ("Matern32x2", a.L, a.T)):
+        prm = synth_params(L, 0, np.random.default_rng(SEED), kern)
+        bank = LatentBank(0.1, prm, kernel=kern)
+        t0 = time.perf_counter()
+        for _ in range(5): bank.update(prm)
+        t_upd = (time.perf_counter() - t0) / 5
+        for dtype, name in ((torch.float64, "f64"), (torch.float32, "f32")):
+            Ty = synth_stream(L, 0, T, dtype, "cuda", SEED + 1)
+            x = torch.zeros((L, bank.d), dtype=dtype, device="cuda")
+            yh = torch.empty_like(Ty); nll = torch.empty((L,), dtype=torch.float64, device="cuda")
+            for _ in range(3): bank.filter(Ty, T=T, x=x, yhat=yh, nll=nll)
+            bank.profile_enable(20)
+            for _ in range(20):
+                x.zero_(); bank.filter(Ty, T=T, x=x, yhat=yh, nll=nll)
+            ms = float(np.mean(bank.profile_read()))
+            es = 4 if dtype == torch.float32 else 8
+            rec = dict(row="stacked filter+NLL", kernel=kern, state_dim=bank.d, dtype=name, latents=L, ticks=T, update_ms=t_upd * 1e3,
+                       kernel_ms=ms, steps_per_s=L * T / (ms * 1e-3), algorithmic_GBps=2 * es * L * T / (ms * 1e-3) / 1e9,
+                       frac_hbm=2 * es * L * T / (ms * 1e-3) / 1e9 / 8000.0)
+            if dtype == torch.float64 and L >= 1024:
+                Ls = 512
+                nth = min(os.cpu_count() or 1, int(cref.lib(wide=True).orc_max_threads()))
+                igps = cref.ihgp_array(kern, 0.1, prm[:Ls])
+                Tyh = Ty[:Ls, :T].cpu().numpy()
+                t0 = time.perf_counter(); cref.filter_stream(igps, Tyh, nthreads=nth); tc = time.perf_counter() - t0
+                rec.update(cpu_steps_per_s=Ls * T / tc, cpu_threads=nth, cpu_sample=f"{Ls} latents x {T} ticks, wide oracle build, OpenMP")
+            out.append(rec)
+    return out
+
+
 def row_tick(a):
     from multioutputihgp_amd import MOIHGP
     from oracle import cref
@@ -148,11 +184,11 @@ def row_window(a):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--rows", default="update,grad,project,tick,window")
+    ap.add_argument("--rows", default="update,grad,project,tick,window,stacked")
     ap.add_argument("--L", type=int, default=4096); ap.add_argument("--T", type=int, default=10000); ap.add_argument("--M", type=int, default=4096)
     a = ap.parse_args()
     torch.cuda.set_device(0)
     for r in a.rows.split(","):
-        res = {"update": row_update, "grad": row_grad, "project": row_project, "tick": row_tick, "window": row_window}[r](a)
+        res = {"update": row_update, "grad": row_grad, "project": row_project, "tick": row_tick, "window": row_window, "stacked": row_stacked}[r](a)
         for rec in (res if isinstance(res, list) else [res]):
             print(json.dumps(rec), flush=True)
