@@ -10,6 +10,7 @@
 
 #include <cmath>
 #include <cstdarg>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -123,7 +124,10 @@ struct moihgp_gp {
     int* dfallback = nullptr;  // [L] flags of latents redone by the sequential gradient kernel
     double* dxscratch = nullptr; // stacked kernels, few latents: per-slice NLL partials
     bool U_host_stale = false; // the device holds a newer U than the host mirror (fetched on getParams)
-    double *hin = nullptr, *hout = nullptr, *hgrad = nullptr;   // page-locked per-tick staging (hout / hgrad are device-mapped)
+    double *hin = nullptr, *hout = nullptr, *hgrad = nullptr;   // page-locked, device-mapped per-tick staging
+    unsigned long long* hflag = nullptr;                        // mapped completion word of the fused small-model step
+    unsigned long long seq = 0;
+    bool fused_ok = false;
     std::vector<void*> pinned; // caller buffers page-locked through moihgp_pin_host_buffer
     // window objective (moihgp_window_set / moihgp_window_eval)
     WindowBufs win{};
@@ -145,6 +149,7 @@ static void gp_free(moihgp_gp* g) {
     if (g->hin) (void)hipHostFree(g->hin);
     if (g->hout) (void)hipHostFree(g->hout);
     if (g->hgrad) (void)hipHostFree(g->hgrad);
+    if (g->hflag) (void)hipHostFree(g->hflag);
     for (hipEvent_t e : g->prof_ev) (void)hipEventDestroy(e);
     if (g->stream) (void)hipStreamDestroy(g->stream);
     delete g;
@@ -235,7 +240,11 @@ static moihgp_gp* gp_create(int kernel, double dt, size_t M, size_t L, bool late
             g->dx = dev_alloc<double>(nin);
             g->dy = g->dx + L * g->d;
             g->ddx = g->dy + M;
-            MOIHGP_HIP_FATAL(hipHostMalloc((void**)&g->hin, sizeof(double) * nin, hipHostMallocDefault));
+            MOIHGP_HIP_FATAL(hipHostMalloc((void**)&g->hin, sizeof(double) * nin, hipHostMallocMapped));
+            MOIHGP_HIP_FATAL(hipHostMalloc((void**)&g->hflag, 64, hipHostMallocMapped));
+            *g->hflag = 0;
+            const char* fe = std::getenv("MOIHGP_TICK_FUSED");            // 0: always take the multi-kernel path
+            g->fused_ok = fused_step_fits(M, L) && !(fe && fe[0] == '0');
             MOIHGP_HIP_FATAL(hipHostMalloc((void**)&g->hout, sizeof(double) * (nin + 8), hipHostMallocMapped));
             if (g->num_param * sizeof(double) <= (size_t)1 << 20)
                 MOIHGP_HIP_FATAL(hipHostMalloc((void**)&g->hgrad, sizeof(double) * g->num_param, hipHostMallocMapped));
@@ -285,12 +294,32 @@ static void do_project(moihgp_gp* g, const double* y_host) {
 static void do_step(moihgp_gp* g, const double* x, const double* y, const double* dx, double* xnew, double* yhat, double* dxnew) {
     if (g->latents_only) { set_last_error("per-tick ABI needs a full MOIHGP object"); std::fprintf(stderr, "%s\n", g_last_error); std::abort(); }
     const size_t L = g->L, d = g->d, P = g->P, M = g->M;
-    stage_inputs(g, x, y, dx);
-    if (y) do_project(g, y);
-    TickArgs a = g->tick();
     double* o_x = g->hout;                       // mapped host block: [xnew | yhat | dxnew | loss]
     double* o_y = o_x + L * d;
     double* o_dx = o_y + M;
+    if (g->fused_ok && !(y && has_nan(y, M))) {
+        // small model, every output observed: one workgroup does project -> step -> unproject on the mapped blocks
+        double* h = g->hin;
+        std::memcpy(h, x, sizeof(double) * L * d);
+        if (y) std::memcpy(h + L * d, y, sizeof(double) * M);
+        if (dx) std::memcpy(h + L * d + M, dx, sizeof(double) * L * P * d);
+        const unsigned long long seq = ++g->seq;
+        launch_fused_step(g->tick(), h, y ? h + L * d : nullptr, dx ? h + L * d + M : nullptr, o_x, yhat ? o_y : nullptr, dx ? o_dx : nullptr,
+                          g->hflag, seq, g->stream);
+        volatile unsigned long long* f = g->hflag;
+        for (long spins = 0; *f != seq; spins++) {
+            __builtin_ia32_pause();
+            if (spins > 4000000) { MOIHGP_HIP_FATAL(hipStreamSynchronize(g->stream)); break; }   // far beyond any healthy call: let the runtime report
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        std::memcpy(xnew, o_x, sizeof(double) * L * d);
+        if (yhat) std::memcpy(yhat, o_y, sizeof(double) * M);
+        if (dx && dxnew) std::memcpy(dxnew, o_dx, sizeof(double) * L * P * d);
+        return;
+    }
+    stage_inputs(g, x, y, dx);
+    if (y) do_project(g, y);
+    TickArgs a = g->tick();
     launch_step_tick(a, g->dx, y ? g->dTy : nullptr, dx ? g->ddx : nullptr, o_x, g->dTyhat, dx ? o_dx : nullptr, g->stream);
     if (yhat) launch_unproject_tick(a, g->dTyhat, o_y, g->stream);
     MOIHGP_HIP_FATAL(hipStreamSynchronize(g->stream));

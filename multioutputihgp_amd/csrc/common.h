@@ -133,6 +133,10 @@ void launch_project_tick_missing(const TickArgs& a, const double* y, double* Ty,
 void launch_step_tick(const TickArgs& a, const double* x, const double* Ty /*NULL: predict only*/, const double* dx,
                       double* xnew, double* Tyhat, double* dxnew, hipStream_t s);
 void launch_unproject_tick(const TickArgs& a, const double* Tyhat, double* yhat, hipStream_t s);
+// small models: MOIHGP::step as one workgroup, host-mapped inputs / outputs, completion signalled through *flag = seq
+bool fused_step_fits(size_t M, size_t L);
+void launch_fused_step(const TickArgs& a, const double* x, const double* y, const double* dx, double* xnew, double* yhat, double* dxnew,
+                       unsigned long long* flag, unsigned long long seq, hipStream_t s);
 // NLL of one tick: loss (device scalar) and, if grad != NULL, the full gradient vector
 // [M*L + L + 1 + L*P] (moihgp.h:460-611).  scratch: >= 4*L + 8 doubles.
 void launch_nll_tick(const TickArgs& a, const double* x, const double* y, const double* Ty, const double* Uty,

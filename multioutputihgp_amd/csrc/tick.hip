@@ -280,6 +280,87 @@ void launch_step_tick(const TickArgs& a, const double* x, const double* Ty, cons
     MOIHGP_HIP_FATAL(hipGetLastError());
 }
 
+// ---- small models: the whole of MOIHGP::step (moihgp.h:148-428, no missing outputs) as ONE workgroup -------------------------
+// project -> L filter steps -> unproject with workgroup barriers in between, inputs read straight from page-locked mapped host
+// memory, outputs and finally a sequence number written straight back to it: a call is one launch and a spin on that number
+// (8-10 us) instead of a copy, three or four launches and a stream synchronisation (20-24 us).
+template <int D>
+__global__ void __launch_bounds__(256) fused_step_kernel(size_t M, size_t L, const double* __restrict__ cb, const double* __restrict__ U,
+                                                         const double* __restrict__ S, const double* __restrict__ x,
+                                                         const double* __restrict__ y, const double* __restrict__ dx,
+                                                         double* __restrict__ xnew, double* __restrict__ yhat, double* __restrict__ dxnew,
+                                                         volatile unsigned long long* flag, unsigned long long seq) {
+    using Lay = CB<D>;
+    extern __shared__ double sm[];
+    double* sy = sm;            // [M]
+    double* sTy = sm + M;       // [L]
+    double* sTyh = sTy + L;     // [L]
+    const int tid = threadIdx.x;
+    if (y) {
+        for (size_t m = tid; m < M; m += 256) sy[m] = y[m];
+        __syncthreads();
+        for (size_t l = tid; l < L; l += 256) {                          // moihgp.h:181
+            double s = 0.0;
+            for (size_t m = 0; m < M; m++) s += U[m * L + l] * sy[m];
+            sTy[l] = (1.0 / sqrt(S[l])) * s;
+        }
+        __syncthreads();
+    }
+    for (size_t l = tid; l < L; l += 256) {                              // ihgp.h:37-100, as step_tick_kernel
+        const double* c = cb + l * Lay::SIZE;
+        double xs[D], xn[D];
+        for (int i = 0; i < D; i++) xs[i] = x[l * D + i];
+        const bool miss = (y == nullptr);
+        const double yl = miss ? 0.0 : sTy[l];
+        const double* Mx = c + (miss ? Lay::A : Lay::AKHA);
+        for (int i = 0; i < D; i++) {
+            double s = 0.0;
+            for (int k = 0; k < D; k++) s += Mx[i * D + k] * xs[k];
+            xn[i] = miss ? s : s + c[Lay::K + i] * yl;
+        }
+        for (int i = 0; i < D; i++) xnew[l * D + i] = xn[i];
+        sTyh[l] = xn[0];
+        if (dx && dxnew) {
+            for (int p = 0; p < P; p++) {
+                const double* dM = c + (miss ? Lay::DA : Lay::DAKHA) + p * D * D;
+                for (int i = 0; i < D; i++) {
+                    double a = 0.0, b = 0.0;
+                    for (int k = 0; k < D; k++) { a += dM[i * D + k] * xs[k]; b += Mx[i * D + k] * dx[(l * P + p) * D + k]; }
+                    double v = a + b;
+                    if (!miss) v += c[Lay::DK + p * D + i] * yl;
+                    dxnew[(l * P + p) * D + i] = v;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (yhat) {                                                          // moihgp.h:222-225, one wave per output row
+        const int lane = tid & 63;
+        for (size_t m = tid >> 6; m < M; m += 4) {
+            double s = 0.0;
+            for (size_t l = lane; l < L; l += 64) s += U[m * L + l] * (sqrt(S[l]) * sTyh[l]);
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            if (lane == 0) yhat[m] = s;
+        }
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) *flag = seq;
+}
+
+// (measured: one workgroup wins up to a few thousand mixing entries -- 8x4: 24 -> 13 us per call; at 256x256 it loses, 77 vs 28 us)
+bool fused_step_fits(size_t M, size_t L) { return M * L <= 8192 && (M + 2 * L) * sizeof(double) <= 48 * 1024; }
+
+void launch_fused_step(const TickArgs& a, const double* x, const double* y, const double* dx, double* xnew, double* yhat, double* dxnew,
+                       unsigned long long* flag, unsigned long long seq, hipStream_t s) {
+    const size_t smem = (a.M + 2 * a.L) * sizeof(double);
+    if (a.d == 2)
+        hipLaunchKernelGGL(fused_step_kernel<2>, dim3(1), dim3(256), smem, s, a.M, a.L, a.cb64, a.U, a.S, x, y, dx, xnew, yhat, dxnew, flag, seq);
+    else
+        hipLaunchKernelGGL(fused_step_kernel<3>, dim3(1), dim3(256), smem, s, a.M, a.L, a.cb64, a.U, a.S, x, y, dx, xnew, yhat, dxnew, flag, seq);
+    MOIHGP_HIP_FATAL(hipGetLastError());
+}
+
 void launch_unproject_tick(const TickArgs& a, const double* Tyhat, double* yhat, hipStream_t s) {
     hipLaunchKernelGGL(unproject_tick_kernel, dim3(nblk(a.M, 4)), dim3(256), 0, s, a.M, a.L, a.U, a.S, Tyhat, yhat);
     MOIHGP_HIP_FATAL(hipGetLastError());
