@@ -291,6 +291,16 @@ static void do_project(moihgp_gp* g, const double* y_host) {
     }
 }
 
+// completion of a fused small-model kernel: spin on the sequence number it writes last into mapped host memory
+static void wait_flag(moihgp_gp* g, unsigned long long seq) {
+    volatile unsigned long long* f = g->hflag;
+    for (long spins = 0; *f != seq; spins++) {
+        __builtin_ia32_pause();
+        if (spins > 4000000) { MOIHGP_HIP_FATAL(hipStreamSynchronize(g->stream)); break; }   // far beyond any healthy call: let the runtime report
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+}
+
 static void do_step(moihgp_gp* g, const double* x, const double* y, const double* dx, double* xnew, double* yhat, double* dxnew) {
     if (g->latents_only) { set_last_error("per-tick ABI needs a full MOIHGP object"); std::fprintf(stderr, "%s\n", g_last_error); std::abort(); }
     const size_t L = g->L, d = g->d, P = g->P, M = g->M;
@@ -306,12 +316,7 @@ static void do_step(moihgp_gp* g, const double* x, const double* y, const double
         const unsigned long long seq = ++g->seq;
         launch_fused_step(g->tick(), h, y ? h + L * d : nullptr, dx ? h + L * d + M : nullptr, o_x, yhat ? o_y : nullptr, dx ? o_dx : nullptr,
                           g->hflag, seq, g->stream);
-        volatile unsigned long long* f = g->hflag;
-        for (long spins = 0; *f != seq; spins++) {
-            __builtin_ia32_pause();
-            if (spins > 4000000) { MOIHGP_HIP_FATAL(hipStreamSynchronize(g->stream)); break; }   // far beyond any healthy call: let the runtime report
-        }
-        std::atomic_thread_fence(std::memory_order_acquire);
+        wait_flag(g, seq);
         std::memcpy(xnew, o_x, sizeof(double) * L * d);
         if (yhat) std::memcpy(yhat, o_y, sizeof(double) * M);
         if (dx && dxnew) std::memcpy(dxnew, o_dx, sizeof(double) * L * P * d);
@@ -331,11 +336,22 @@ static void do_step(moihgp_gp* g, const double* x, const double* y, const double
 static double do_lik(moihgp_gp* g, const double* x, const double* y, const double* dx, double* grad) {
     if (g->latents_only) { set_last_error("per-tick ABI needs a full MOIHGP object"); std::fprintf(stderr, "%s\n", g_last_error); std::abort(); }
     const size_t L = g->L, d = g->d, P = g->P, M = g->M;
+    double* o_loss = g->hout + L * d + M + L * P * d;
+    const bool small_grad = g->hgrad != nullptr;                         // gradient written straight to mapped host memory
+    if (g->fused_ok && small_grad && fused_lik_fits(M, L) && !has_nan(y, M)) {
+        double* h = g->hin;
+        std::memcpy(h, x, sizeof(double) * L * d);
+        std::memcpy(h + L * d, y, sizeof(double) * M);
+        if (dx) std::memcpy(h + L * d + M, dx, sizeof(double) * L * P * d);
+        const unsigned long long seq = ++g->seq;
+        launch_fused_lik(g->tick(), h, h + L * d, dx ? h + L * d + M : nullptr, o_loss, g->hgrad, g->hflag, seq, g->stream);
+        wait_flag(g, seq);
+        if (dx && grad) std::memcpy(grad, g->hgrad, sizeof(double) * g->num_param);
+        return *o_loss;
+    }
     stage_inputs(g, x, y, dx);
     do_project(g, y);
     TickArgs a = g->tick();
-    double* o_loss = g->hout + L * d + M + L * P * d;
-    const bool small_grad = g->hgrad != nullptr;                         // gradient written straight to mapped host memory
     launch_nll_tick(a, g->dx, g->dy, g->dTy, g->dUty, dx ? g->ddx : nullptr, o_loss, small_grad ? g->hgrad : g->dgrad, g->dscratch, g->stream);
     if (dx && grad && !small_grad) MOIHGP_HIP_FATAL(hipMemcpyAsync(grad, g->dgrad, sizeof(double) * g->num_param, hipMemcpyDeviceToHost, g->stream));
     MOIHGP_HIP_FATAL(hipStreamSynchronize(g->stream));

@@ -135,6 +135,9 @@ void launch_step_tick(const TickArgs& a, const double* x, const double* Ty /*NUL
 void launch_unproject_tick(const TickArgs& a, const double* Tyhat, double* yhat, hipStream_t s);
 // small models: MOIHGP::step as one workgroup, host-mapped inputs / outputs, completion signalled through *flag = seq
 bool fused_step_fits(size_t M, size_t L);
+bool fused_lik_fits(size_t M, size_t L);
+void launch_fused_lik(const TickArgs& a, const double* x, const double* y, const double* dx, double* loss, double* grad,
+                      unsigned long long* flag, unsigned long long seq, hipStream_t s);
 void launch_fused_step(const TickArgs& a, const double* x, const double* y, const double* dx, double* xnew, double* yhat, double* dxnew,
                        unsigned long long* flag, unsigned long long seq, hipStream_t s);
 // NLL of one tick: loss (device scalar) and, if grad != NULL, the full gradient vector

@@ -148,28 +148,32 @@ __global__ void __launch_bounds__(256) unproject_tick_kernel(size_t M, size_t L,
 
 // Per-latent NLL terms: loss_l (ihgp.h:204-209), grad_l (ihgp.h:212-222), pv_l (moihgp.h:505-512).
 template <int D>
+__device__ inline void igp_nll_one(const double* __restrict__ c, const double* __restrict__ xl, double yraw, double y,
+                                   const double* __restrict__ dxl /* [P][D] or NULL */, double* lossv, double* pv, double* igrad /* [P] */) {
+    using Lay = CB<D>;
+    const double S = c[Lay::S];
+    double hx = 0.0, hak = 0.0;
+    for (int i = 0; i < D; i++) { hx += c[Lay::HA + i] * xl[i]; hak += c[Lay::HA + i] * c[Lay::K + i]; }
+    const double v = y - hx;
+    *lossv = 0.5 * (v * v / S + log(S));                                 // ihgp.h:207
+    if (dxl) {
+        *pv = (yraw - hx) * (1 - hak) / S;                               // moihgp.h:510-511 (raw y(idx), sic)
+        for (int p = 0; p < P; p++) {
+            double a = 0.0, b = 0.0;
+            for (int i = 0; i < D; i++) { a += c[Lay::HDA + p * D + i] * xl[i]; b += c[Lay::HA + i] * dxl[p * D + i]; }
+            double dv = -a - b;                                          // ihgp.h:218
+            igrad[p] = (v * dv - 0.5 * (v * v / S - 1) * c[Lay::DS + p]) / S;   // ihgp.h:219
+        }
+    }
+}
+
+template <int D>
 __global__ void igp_nll_kernel(size_t L, const double* __restrict__ cb, const double* __restrict__ x,
                                const double* __restrict__ yraw, const double* __restrict__ Ty, const double* __restrict__ dx,
                                double* __restrict__ lossv, double* __restrict__ pv, double* __restrict__ igrad) {
-    using Lay = CB<D>;
     size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= L) return;
-    const double* c = cb + l * Lay::SIZE;
-    const double S = c[Lay::S];
-    double hx = 0.0, hak = 0.0;
-    for (int i = 0; i < D; i++) { hx += c[Lay::HA + i] * x[l * D + i]; hak += c[Lay::HA + i] * c[Lay::K + i]; }
-    const double y = Ty[l];
-    const double v = y - hx;
-    lossv[l] = 0.5 * (v * v / S + log(S));                               // ihgp.h:207
-    if (dx) {
-        pv[l] = (yraw[l] - hx) * (1 - hak) / S;                          // moihgp.h:510-511 (raw y(idx), sic)
-        for (int p = 0; p < P; p++) {
-            double a = 0.0, b = 0.0;
-            for (int i = 0; i < D; i++) { a += c[Lay::HDA + p * D + i] * x[l * D + i]; b += c[Lay::HA + i] * dx[(l * P + p) * D + i]; }
-            double dv = -a - b;                                          // ihgp.h:218
-            igrad[l * P + p] = (v * dv - 0.5 * (v * v / S - 1) * c[Lay::DS + p]) / S;   // ihgp.h:219
-        }
-    }
+    igp_nll_one<D>(cb + l * CB<D>::SIZE, x + l * D, yraw[l], Ty[l], dx ? dx + l * P * D : nullptr, lossv + l, pv + l, igrad + l * P);
 }
 
 // resid2[m] = (y - U U^T y)_m^2  (moihgp.h:501 / :651): one wave per output row.
@@ -199,14 +203,10 @@ __device__ double block_sum(double v, double* red) {
 }
 
 // loss and the S / sigma / per-latent gradient entries (moihgp.h:503, :553-563, :598-609): one workgroup.
-__global__ void __launch_bounds__(256) nll_finalize_kernel(size_t M, size_t L, const double* __restrict__ S,
-                                                           const double* __restrict__ sigma_p, const double* __restrict__ Uty,
-                                                           const double* __restrict__ lossv, const double* __restrict__ pv,
-                                                           const double* __restrict__ igrad, const double* __restrict__ resid2,
-                                                           double* __restrict__ loss, double* __restrict__ grad) {
-    __shared__ double red[256];
+__device__ inline void nll_finalize_body(size_t M, size_t L, const double* __restrict__ S, double sigma, const double* Uty,
+                                         const double* lossv, const double* pv, const double* igrad, const double* resid2,
+                                         double* __restrict__ loss, double* __restrict__ grad, double* red) {
     const int tid = threadIdx.x, nt = blockDim.x;
-    const double sigma = *sigma_p;
     double a = 0.0, b = 0.0, c = 0.0;
     for (size_t l = tid; l < L; l += nt) { a += S[l]; c += lossv[l]; }
     for (size_t m = tid; m < M; m += nt) b += resid2[m];
@@ -230,6 +230,15 @@ __global__ void __launch_bounds__(256) nll_finalize_kernel(size_t M, size_t L, c
     }
     const double gsum = block_sum(gs, red);
     if (tid == 0) grad[sizeU + L] = 0.5 * (m_n - nrm / sigma) / sigma + gsum;   // moihgp.h:563
+}
+
+__global__ void __launch_bounds__(256) nll_finalize_kernel(size_t M, size_t L, const double* __restrict__ S,
+                                                           const double* __restrict__ sigma_p, const double* __restrict__ Uty,
+                                                           const double* __restrict__ lossv, const double* __restrict__ pv,
+                                                           const double* __restrict__ igrad, const double* __restrict__ resid2,
+                                                           double* __restrict__ loss, double* __restrict__ grad) {
+    __shared__ double red[256];
+    nll_finalize_body(M, L, S, *sigma_p, Uty, lossv, pv, igrad, resid2, loss, grad, red);
 }
 
 // U-gradient (moihgp.h:538-552).  U is a polar factor (moihgp.h:438-446) so its singular values are
@@ -358,6 +367,69 @@ void launch_fused_step(const TickArgs& a, const double* x, const double* y, cons
         hipLaunchKernelGGL(fused_step_kernel<2>, dim3(1), dim3(256), smem, s, a.M, a.L, a.cb64, a.U, a.S, x, y, dx, xnew, yhat, dxnew, flag, seq);
     else
         hipLaunchKernelGGL(fused_step_kernel<3>, dim3(1), dim3(256), smem, s, a.M, a.L, a.cb64, a.U, a.S, x, y, dx, xnew, yhat, dxnew, flag, seq);
+    MOIHGP_HIP_FATAL(hipGetLastError());
+}
+
+// The same for MOIHGP::negLogLikelihood (moihgp.h:460-688, every output observed): projection, per-latent terms, residual,
+// loss, and with dx the whole gradient vector, one workgroup, results and the sequence number straight to mapped host memory.
+template <int D>
+__global__ void __launch_bounds__(256) fused_lik_kernel(size_t M, size_t L, const double* __restrict__ cb, const double* __restrict__ U,
+                                                        const double* __restrict__ S, const double* __restrict__ sigma_p,
+                                                        const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ dx,
+                                                        double* __restrict__ loss, double* __restrict__ grad,
+                                                        volatile unsigned long long* flag, unsigned long long seq) {
+    extern __shared__ double sm[];
+    double* sy = sm;                 // [M]
+    double* sres = sy + M;           // [M]
+    double* sUty = sres + M;         // [L]
+    double* sTy = sUty + L;          // [L]
+    double* slos = sTy + L;          // [L]
+    double* spv = slos + L;          // [L]
+    double* sig = spv + L;           // [L][P]
+    double* red = sig + L * P;       // [256]
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (size_t m = tid; m < M; m += 256) sy[m] = y[m];
+    __syncthreads();
+    for (size_t l = tid; l < L; l += 256) {                              // moihgp.h:181
+        double s = 0.0;
+        for (size_t m = 0; m < M; m++) s += U[m * L + l] * sy[m];
+        sUty[l] = s;
+        sTy[l] = (1.0 / sqrt(S[l])) * s;
+    }
+    __syncthreads();
+    for (size_t l = tid; l < L; l += 256) {
+        spv[l] = 0.0;
+        igp_nll_one<D>(cb + l * CB<D>::SIZE, x + l * D, sy[l], sTy[l], dx ? dx + l * P * D : nullptr, slos + l, spv + l, sig + l * P);
+    }
+    for (size_t m = tid >> 6; m < M; m += 4) {                           // moihgp.h:501 / :651, one wave per row
+        double s = 0.0;
+        for (size_t l = lane; l < L; l += 64) s += U[m * L + l] * sUty[l];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) { const double r = sy[m] - s; sres[m] = r * r; }
+    }
+    __syncthreads();
+    const double sigma = *sigma_p;
+    nll_finalize_body(M, L, S, sigma, sUty, slos, spv, sig, sres, loss, dx ? grad : nullptr, red);
+    if (dx && grad)
+        for (size_t idx = tid; idx < M * L; idx += 256) {                // moihgp.h:538-552 in its rank-1 form (ugrad_kernel)
+            const size_t r = idx / L, c = idx % L;
+            grad[idx] = sy[r] * (spv[c] * (1.0 / sqrt(S[c])) - sUty[c] / sigma);
+        }
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) *flag = seq;
+}
+
+static size_t fused_lik_smem(size_t M, size_t L) { return (2 * M + (4 + P) * L + 256) * sizeof(double); }
+bool fused_lik_fits(size_t M, size_t L) { return M * L <= 8192 && M >= L && fused_lik_smem(M, L) <= 48 * 1024; }
+
+void launch_fused_lik(const TickArgs& a, const double* x, const double* y, const double* dx, double* loss, double* grad,
+                      unsigned long long* flag, unsigned long long seq, hipStream_t s) {
+    const size_t smem = fused_lik_smem(a.M, a.L);
+    if (a.d == 2)
+        hipLaunchKernelGGL(fused_lik_kernel<2>, dim3(1), dim3(256), smem, s, a.M, a.L, a.cb64, a.U, a.S, a.sigma, x, y, dx, loss, grad, flag, seq);
+    else
+        hipLaunchKernelGGL(fused_lik_kernel<3>, dim3(1), dim3(256), smem, s, a.M, a.L, a.cb64, a.U, a.S, a.sigma, x, y, dx, loss, grad, flag, seq);
     MOIHGP_HIP_FATAL(hipGetLastError());
 }
 
