@@ -1,4 +1,4 @@
-// stationary.hip -- batched IHGP::update on the device: one lane per latent, fp64 always.
+// stationary.hip -- batched IHGP::update on the device: 16 latents per 64-lane workgroup, fp64 always.
 //
 // Restates, for every latent independently, reference include/moihgp/ihgp.h:117-201:
 //   A = expm(dt F); Q = sym(Pinf - A Pinf A^T); PP = DARE(A, H^T, Q, R); S, K, HA, AKHA;
@@ -67,167 +67,227 @@ __device__ void ss_build(int kernel, const double* params, SS<D>& s) {
     (void)kernel;
 }
 
+// One workgroup of 64 lanes updates kLPB = 16 latents in three phases, so that the independent fixed-point chains of a latent
+// run side by side instead of one after the other on a single lane (the 100-iteration loops are latency chains):
+//   phase 1   lanes  0..15: A, Q, DARE, S, K, HA, AKHA (ihgp.h:120-133)     lanes 16..31: the 2d x 2d block expm of the one
+//             hyper-parameter with dF != 0, which does not depend on the DARE (ihgp.h:163-167)
+//   phase 2   lanes  0..47: one (latent, hyper-parameter) pair each: dQ, QLyap, DLyap, dS, dK, dAKHA, HdA (ihgp.h:136-200)
+//   phase 3   lanes  0..31: the scan tables of recursion.hip, one (latent, stream precision) pair each
+// Every quantity is computed by exactly the expressions of the one-lane evaluation, in the same order.
+constexpr int kLPB = 16;
+
+template <int D>
+struct Shared {               // per latent, in LDS
+    double A[D * D], PP[D * D], AAKH[D * D], AKHA[D * D], dA1[D * D];
+    double K[D], HA[D], AK[D], PPHt[D], HPP[D];
+    double S;
+};
+
 template <int D>
 __global__ void __launch_bounds__(64) ihgp_update_kernel(int kernel, double dt, const double* __restrict__ params,
                                                          size_t n, double* __restrict__ cb64, float* __restrict__ cb32,
                                                          int* __restrict__ n_unstable) {
     using L = CB<D>;
     constexpr int P = kNumIgpParam, NN = D * D;
-    size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= n) return;
-    double prm[3] = {params[l * 3 + 0], params[l * 3 + 1], params[l * 3 + 2]};
-    SS<D> s;
-    ss_build<D>(kernel, prm, s);
-    double out[L::SIZE];
-    for (int i = 0; i < L::SIZE; i++) out[i] = 0.0;
+    __shared__ Shared<D> sh[kLPB];
+    const int tid = threadIdx.x;
+    const size_t l0 = (size_t)blockIdx.x * kLPB;
 
-    double A[NN], AT[NN], T1[NN], T2[NN], Q[NN], PP[NN];
-    for (int i = 0; i < NN; i++) T1[i] = dt * s.F[i];
-    expm<D>(T1, A);                                                    // ihgp.h:120
-    mt<D>(A, AT);
-    mm<D>(A, s.Pinf, T1); mm<D>(T1, AT, T2);
-    for (int i = 0; i < NN; i++) T1[i] = s.Pinf[i] - T2[i];             // ihgp.h:121
-    for (int i = 0; i < D; i++)
-        for (int j = 0; j < D; j++) Q[i * D + j] = (T1[i * D + j] + T1[j * D + i]) / 2.0;   // ihgp.h:122
-    int dare_iters = dare<D>(A, s.H, Q, s.R, PP);                       // ihgp.h:125
-    double PPHt[D], HPP[D], K[D], HA[D], AK[D], AAKH[NN];
-    mv<D>(PP, s.H, PPHt);
-    double S = s.R;
-    for (int i = 0; i < D; i++) S += s.H[i] * PPHt[i];                  // ihgp.h:126
-    for (int i = 0; i < D; i++) K[i] = PPHt[i] / S;                     // ihgp.h:127
-    for (int j = 0; j < D; j++) { double t = 0.0; for (int i = 0; i < D; i++) t += s.H[i] * PP[i * D + j]; HPP[j] = t; }
-    for (int j = 0; j < D; j++) { double t = 0.0; for (int i = 0; i < D; i++) t += s.H[i] * A[i * D + j]; HA[j] = t; }   // ihgp.h:129
-    for (int i = 0; i < D; i++)
-        for (int j = 0; j < D; j++) out[L::AKHA + i * D + j] = A[i * D + j] - K[i] * HA[j];   // ihgp.h:130
-    mv<D>(A, K, AK);                                                    // ihgp.h:132
-    for (int i = 0; i < D; i++)
-        for (int j = 0; j < D; j++) AAKH[i * D + j] = A[i * D + j] - AK[i] * s.H[j];   // ihgp.h:133
-    for (int i = 0; i < NN; i++) out[L::A + i] = A[i];
-    for (int i = 0; i < D; i++) { out[L::K + i] = K[i]; out[L::HA + i] = HA[i]; }
-    out[L::S] = S;
-    out[L::LOGS] = log(S);
-    out[L::ITERS] = (double)dare_iters;
-
-    for (int p = 0; p < P; p++) {                                       // ihgp.h:136
-        double dA[NN], dAT[NN], dQ[NN], QL[NN], dPP[NN];
-        bool dF_zero = all_zero<D>(s.dF[p]), dPinf_zero = all_zero<D>(s.dPinf[p]), dR_zero = (s.dR[p] == 0.0);
-        if (dF_zero) {                                                  // ihgp.h:141
-            for (int i = 0; i < NN; i++) dA[i] = 0.0;
-            if (dPinf_zero) {
-                for (int i = 0; i < NN; i++) dQ[i] = 0.0;
-            } else {
-                mm<D>(A, s.dPinf[p], T1); mm<D>(T1, AT, T2);
-                for (int i = 0; i < NN; i++) dQ[i] = s.dPinf[p][i] - T2[i];   // ihgp.h:150
-            }
-            if (dR_zero) {
-                for (int i = 0; i < NN; i++) QL[i] = dQ[i];             // ihgp.h:154
-            } else {
-                // ihgp.h:158 is `AK * AK^T * dR` ((d x d) * (1 x 1), an invalid Eigen product);
-                // evaluated with its evident meaning AK dR AK^T, as ihgp.h:183 writes it.
+    // ---- phase 1 ----
+    if (tid < 2 * kLPB) {
+        const int li = tid % kLPB;
+        const size_t l = l0 + li;
+        if (l < n) {
+            double prm[3] = {params[l * 3 + 0], params[l * 3 + 1], params[l * 3 + 2]};
+            SS<D> s;
+            ss_build<D>(kernel, prm, s);
+            Shared<D>& q = sh[li];
+            if (tid < kLPB) {
+                double* o64 = cb64 + l * L::SIZE;
+                float* o32 = cb32 + l * L::SIZE;
+                auto put = [&](int off, double v) { o64[off] = v; o32[off] = (float)v; };
+                double A[NN], AT[NN], T1[NN], T2[NN], Q[NN], PP[NN];
+                for (int i = 0; i < NN; i++) T1[i] = dt * s.F[i];
+                expm<D>(T1, A);                                                    // ihgp.h:120
+                mt<D>(A, AT);
+                mm<D>(A, s.Pinf, T1); mm<D>(T1, AT, T2);
+                for (int i = 0; i < NN; i++) T1[i] = s.Pinf[i] - T2[i];             // ihgp.h:121
                 for (int i = 0; i < D; i++)
-                    for (int j = 0; j < D; j++) QL[i * D + j] = AK[i] * s.dR[p] * AK[j] + dQ[i * D + j];
-            }
-        } else {
-            constexpr int M2 = 2 * D;
-            double FF[M2 * M2], EF[M2 * M2];
-            for (int i = 0; i < M2 * M2; i++) FF[i] = 0.0;
-            for (int i = 0; i < D; i++)
-                for (int j = 0; j < D; j++) {                           // ihgp.h:163-166
-                    FF[i * M2 + j] = dt * s.F[i * D + j];
-                    FF[(D + i) * M2 + (D + j)] = dt * s.F[i * D + j];
-                    FF[(D + i) * M2 + j] = dt * s.dF[p][i * D + j];
-                }
-            expm<M2>(FF, EF);
-            for (int i = 0; i < D; i++)
-                for (int j = 0; j < D; j++) dA[i * D + j] = EF[(D + i) * M2 + j];   // ihgp.h:167
-            mt<D>(dA, dAT);
-            double dAPAt[NN], APdAt[NN];
-            mm<D>(dA, s.Pinf, T1); mm<D>(T1, AT, dAPAt);
-            mm<D>(A, s.Pinf, T1); mm<D>(T1, dAT, APdAt);
-            if (dPinf_zero) {
-                for (int i = 0; i < NN; i++) dQ[i] = -dAPAt[i] - APdAt[i];   // ihgp.h:171
+                    for (int j = 0; j < D; j++) Q[i * D + j] = (T1[i * D + j] + T1[j * D + i]) / 2.0;   // ihgp.h:122
+                int dare_iters = dare<D>(A, s.H, Q, s.R, PP);                       // ihgp.h:125
+                double PPHt[D], HPP[D], K[D], HA[D], AK[D];
+                mv<D>(PP, s.H, PPHt);
+                double S = s.R;
+                for (int i = 0; i < D; i++) S += s.H[i] * PPHt[i];                  // ihgp.h:126
+                for (int i = 0; i < D; i++) K[i] = PPHt[i] / S;                     // ihgp.h:127
+                for (int j = 0; j < D; j++) { double t = 0.0; for (int i = 0; i < D; i++) t += s.H[i] * PP[i * D + j]; HPP[j] = t; }
+                for (int j = 0; j < D; j++) { double t = 0.0; for (int i = 0; i < D; i++) t += s.H[i] * A[i * D + j]; HA[j] = t; }   // ihgp.h:129
+                mv<D>(A, K, AK);                                                    // ihgp.h:132
+                for (int i = 0; i < D; i++)
+                    for (int j = 0; j < D; j++) {
+                        q.AKHA[i * D + j] = A[i * D + j] - K[i] * HA[j];            // ihgp.h:130
+                        q.AAKH[i * D + j] = A[i * D + j] - AK[i] * s.H[j];          // ihgp.h:133
+                        q.A[i * D + j] = A[i * D + j];
+                        q.PP[i * D + j] = PP[i * D + j];
+                    }
+                for (int i = 0; i < D; i++) { q.K[i] = K[i]; q.HA[i] = HA[i]; q.AK[i] = AK[i]; q.PPHt[i] = PPHt[i]; q.HPP[i] = HPP[i]; }
+                q.S = S;
+                for (int i = 0; i < NN; i++) { put(L::AKHA + i, q.AKHA[i]); put(L::A + i, A[i]); }
+                for (int i = 0; i < D; i++) { put(L::K + i, K[i]); put(L::HA + i, HA[i]); }
+                put(L::S, S);
+                put(L::LOGS, log(S));
+                put(L::ITERS, (double)dare_iters);
+                for (int p = 0; p < P; p++) put(L::PARAMS + p, prm[p]);
             } else {
-                mm<D>(A, s.dPinf[p], T1); mm<D>(T1, AT, T2);
-                for (int i = 0; i < NN; i++) dQ[i] = s.dPinf[p][i] - dAPAt[i] - T2[i] - APdAt[i];   // ihgp.h:175
+                // the lengthscale is the only hyper-parameter with dF != 0 in both models (matern32ss.h:57-58, matern52ss.h:62-64)
+                constexpr int M2 = 2 * D;
+                double FF[M2 * M2], EF[M2 * M2];
+                for (int i = 0; i < M2 * M2; i++) FF[i] = 0.0;
+                for (int i = 0; i < D; i++)
+                    for (int j = 0; j < D; j++) {                                   // ihgp.h:163-166
+                        FF[i * M2 + j] = dt * s.F[i * D + j];
+                        FF[(D + i) * M2 + (D + j)] = dt * s.F[i * D + j];
+                        FF[(D + i) * M2 + j] = dt * s.dF[1][i * D + j];
+                    }
+                expm<M2>(FF, EF);
+                for (int i = 0; i < D; i++)
+                    for (int j = 0; j < D; j++) q.dA1[i * D + j] = EF[(D + i) * M2 + j];   // ihgp.h:167
             }
-            double t1[NN], t2[NN], dAPPHt[D], HPPdAT[D];
-            mm<D>(dA, PP, T1); mm<D>(T1, AT, t1);
-            mm<D>(A, PP, T1); mm<D>(T1, dAT, t2);
-            mv<D>(dA, PPHt, dAPPHt);
-            for (int j = 0; j < D; j++) { double t = 0.0; for (int k = 0; k < D; k++) t += HPP[k] * dAT[k * D + j]; HPPdAT[j] = t; }
-            for (int i = 0; i < D; i++)
-                for (int j = 0; j < D; j++) {                           // ihgp.h:179 / :183
-                    double v = t1[i * D + j] + t2[i * D + j] - dAPPHt[i] * AK[j] - AK[i] * HPPdAT[j];
-                    if (!dR_zero) v += AK[i] * s.dR[p] * AK[j];
-                    QL[i * D + j] = v + dQ[i * D + j];
-                }
         }
-        int its = dlyap<D>(AAKH, QL, dPP);                               // ihgp.h:187
-        double dS = s.dR[p];
-        for (int i = 0; i < D; i++)
-            for (int j = 0; j < D; j++) dS += s.H[i] * dPP[i * D + j] * s.H[j];   // ihgp.h:188
-        double dK[D];
-        for (int i = 0; i < D; i++) {                                    // ihgp.h:189
-            double t = 0.0;
-            for (int j = 0; j < D; j++) t += (dPP[i * D + j] - PP[i * D + j] * dS / S) * s.H[j];
-            dK[i] = t / S;
-        }
-        out[L::DS + p] = dS;
-        out[L::ITERS + 1 + p] = (double)its;
-        for (int i = 0; i < D; i++) out[L::DK + p * D + i] = dK[i];
-        for (int i = 0; i < NN; i++) out[L::DA + p * NN + i] = dA[i];
-        if (dF_zero) {                                                   // ihgp.h:192-193
-            for (int i = 0; i < D; i++)
-                for (int j = 0; j < D; j++) out[L::DAKHA + p * NN + i * D + j] = -dK[i] * HA[j];
-            for (int i = 0; i < D; i++) out[L::HDA + p * D + i] = 0.0;
-        } else {                                                         // ihgp.h:197-198
-            double HdA[D];
-            for (int j = 0; j < D; j++) { double t = 0.0; for (int i = 0; i < D; i++) t += s.H[i] * dA[i * D + j]; HdA[j] = t; }
-            for (int i = 0; i < D; i++)
-                for (int j = 0; j < D; j++) out[L::DAKHA + p * NN + i * D + j] = dA[i * D + j] - dK[i] * HA[j] - K[i] * HdA[j];
-            for (int i = 0; i < D; i++) out[L::HDA + p * D + i] = HdA[i];
-        }
-        out[L::PARAMS + p] = prm[p];
     }
-    double* o64 = cb64 + l * L::SIZE;
-    float* o32 = cb32 + l * L::SIZE;
-    for (int i = 0; i < L::G; i++) { o64[i] = out[i]; o32[i] = (float)out[i]; }
-    // tables of the segment solve (recursion.hip), one set per stream dtype because the chunk length differs
-    for (int pass = 0; pass < 2; pass++) {
-        const int ck = pass == 0 ? kChunk64 : kChunk32;
-        double tab[L::SIZE - L::G];
-        for (int i = 0; i < L::SIZE - L::G; i++) tab[i] = 0.0;
-        double* G = tab;                       // [16][D]
-        double* SP = tab + (L::SP - L::G);      // [4][NN]
-        double* PJ = tab + (L::PJ - L::G);      // [16][NN]
-        const double* AKHA = out + L::AKHA;
-        double g[D], M[NN];
-        for (int i = 0; i < D; i++) g[i] = K[i];
-        for (int k = ck - 1; k >= 0; k--) {      // g_k = AKHA^(ck-1-k) K
-            for (int i = 0; i < D; i++) G[k * D + i] = g[i];
-            mv<D>(AKHA, g, g);
+    __syncthreads();
+
+    // ---- phase 2 ----
+    if (tid < P * kLPB) {
+        const int li = tid % kLPB, p = tid / kLPB;
+        const size_t l = l0 + li;
+        if (l < n) {
+            double prm[3] = {params[l * 3 + 0], params[l * 3 + 1], params[l * 3 + 2]};
+            SS<D> s;
+            ss_build<D>(kernel, prm, s);
+            const Shared<D>& q = sh[li];
+            double* o64 = cb64 + l * L::SIZE;
+            float* o32 = cb32 + l * L::SIZE;
+            auto put = [&](int off, double v) { o64[off] = v; o32[off] = (float)v; };
+            double A[NN], AT[NN], PP[NN], AAKH[NN], T1[NN], T2[NN];
+            for (int i = 0; i < NN; i++) { A[i] = q.A[i]; PP[i] = q.PP[i]; AAKH[i] = q.AAKH[i]; }
+            mt<D>(A, AT);
+            const double S = q.S;
+            double dA[NN], dAT[NN], dQ[NN], QL[NN], dPP[NN];
+            const bool dF_zero = all_zero<D>(s.dF[p]), dPinf_zero = all_zero<D>(s.dPinf[p]), dR_zero = (s.dR[p] == 0.0);
+            if (dF_zero) {                                                  // ihgp.h:141
+                for (int i = 0; i < NN; i++) dA[i] = 0.0;
+                if (dPinf_zero) {
+                    for (int i = 0; i < NN; i++) dQ[i] = 0.0;
+                } else {
+                    mm<D>(A, s.dPinf[p], T1); mm<D>(T1, AT, T2);
+                    for (int i = 0; i < NN; i++) dQ[i] = s.dPinf[p][i] - T2[i];   // ihgp.h:150
+                }
+                if (dR_zero) {
+                    for (int i = 0; i < NN; i++) QL[i] = dQ[i];             // ihgp.h:154
+                } else {
+                    // ihgp.h:158 is `AK * AK^T * dR` ((d x d) * (1 x 1), an invalid Eigen product);
+                    // evaluated with its evident meaning AK dR AK^T, as ihgp.h:183 writes it.
+                    for (int i = 0; i < D; i++)
+                        for (int j = 0; j < D; j++) QL[i * D + j] = q.AK[i] * s.dR[p] * q.AK[j] + dQ[i * D + j];
+                }
+            } else {
+                for (int i = 0; i < NN; i++) dA[i] = q.dA1[i];              // ihgp.h:167 (phase 1; dF != 0 only for p == 1)
+                mt<D>(dA, dAT);
+                double dAPAt[NN], APdAt[NN];
+                mm<D>(dA, s.Pinf, T1); mm<D>(T1, AT, dAPAt);
+                mm<D>(A, s.Pinf, T1); mm<D>(T1, dAT, APdAt);
+                if (dPinf_zero) {
+                    for (int i = 0; i < NN; i++) dQ[i] = -dAPAt[i] - APdAt[i];   // ihgp.h:171
+                } else {
+                    mm<D>(A, s.dPinf[p], T1); mm<D>(T1, AT, T2);
+                    for (int i = 0; i < NN; i++) dQ[i] = s.dPinf[p][i] - dAPAt[i] - T2[i] - APdAt[i];   // ihgp.h:175
+                }
+                double t1[NN], t2[NN], dAPPHt[D], HPPdAT[D];
+                mm<D>(dA, PP, T1); mm<D>(T1, AT, t1);
+                mm<D>(A, PP, T1); mm<D>(T1, dAT, t2);
+                double PPHt[D];
+                for (int i = 0; i < D; i++) PPHt[i] = q.PPHt[i];
+                mv<D>(dA, PPHt, dAPPHt);
+                for (int j = 0; j < D; j++) { double t = 0.0; for (int k = 0; k < D; k++) t += q.HPP[k] * dAT[k * D + j]; HPPdAT[j] = t; }
+                for (int i = 0; i < D; i++)
+                    for (int j = 0; j < D; j++) {                           // ihgp.h:179 / :183
+                        double v = t1[i * D + j] + t2[i * D + j] - dAPPHt[i] * q.AK[j] - q.AK[i] * HPPdAT[j];
+                        if (!dR_zero) v += q.AK[i] * s.dR[p] * q.AK[j];
+                        QL[i * D + j] = v + dQ[i * D + j];
+                    }
+            }
+            int its = dlyap<D>(AAKH, QL, dPP);                               // ihgp.h:187
+            double dS = s.dR[p];
+            for (int i = 0; i < D; i++)
+                for (int j = 0; j < D; j++) dS += s.H[i] * dPP[i * D + j] * s.H[j];   // ihgp.h:188
+            double dK[D];
+            for (int i = 0; i < D; i++) {                                    // ihgp.h:189
+                double t = 0.0;
+                for (int j = 0; j < D; j++) t += (dPP[i * D + j] - PP[i * D + j] * dS / S) * s.H[j];
+                dK[i] = t / S;
+            }
+            put(L::DS + p, dS);
+            put(L::ITERS + 1 + p, (double)its);
+            for (int i = 0; i < D; i++) put(L::DK + p * D + i, dK[i]);
+            for (int i = 0; i < NN; i++) put(L::DA + p * NN + i, dA[i]);
+            if (dF_zero) {                                                   // ihgp.h:192-193
+                for (int i = 0; i < D; i++)
+                    for (int j = 0; j < D; j++) put(L::DAKHA + p * NN + i * D + j, -dK[i] * q.HA[j]);
+                for (int i = 0; i < D; i++) put(L::HDA + p * D + i, 0.0);
+            } else {                                                         // ihgp.h:197-198
+                double HdA[D];
+                for (int j = 0; j < D; j++) { double t = 0.0; for (int i = 0; i < D; i++) t += s.H[i] * dA[i * D + j]; HdA[j] = t; }
+                for (int i = 0; i < D; i++)
+                    for (int j = 0; j < D; j++) put(L::DAKHA + p * NN + i * D + j, dA[i * D + j] - dK[i] * q.HA[j] - q.K[i] * HdA[j]);
+                for (int i = 0; i < D; i++) put(L::HDA + p * D + i, HdA[i]);
+            }
         }
-        for (int i = 0; i < NN; i++) M[i] = AKHA[i];
-        for (int q = 1; q < ck; q <<= 1) mm<D>(M, M, M);   // M = AKHA^ck
-        double Pw[NN];
-        for (int i = 0; i < NN; i++) Pw[i] = M[i];
-        for (int lv = 0; lv < 4; lv++) {
-            for (int i = 0; i < NN; i++) SP[lv * NN + i] = Pw[i];
-            mm<D>(Pw, Pw, Pw);
+    }
+
+    // ---- phase 3: tables of the segment solve (recursion.hip), one set per stream dtype because the chunk length differs ----
+    if (tid < 2 * kLPB) {
+        const int li = tid % kLPB, pass = tid / kLPB;
+        const size_t l = l0 + li;
+        if (l < n) {
+            const Shared<D>& q = sh[li];
+            double* o64 = cb64 + l * L::SIZE;
+            float* o32 = cb32 + l * L::SIZE;
+            const int ck = pass == 0 ? kChunk64 : kChunk32;
+            double tab[L::SIZE - L::G];
+            for (int i = 0; i < L::SIZE - L::G; i++) tab[i] = 0.0;
+            double* G = tab;                       // [16][D]
+            double* SP = tab + (L::SP - L::G);      // [4][NN]
+            double* PJ = tab + (L::PJ - L::G);      // [16][NN]
+            double AKHA[NN], g[D], M[NN];
+            for (int i = 0; i < NN; i++) AKHA[i] = q.AKHA[i];
+            for (int i = 0; i < D; i++) g[i] = q.K[i];
+            for (int k = ck - 1; k >= 0; k--) {      // g_k = AKHA^(ck-1-k) K
+                for (int i = 0; i < D; i++) G[k * D + i] = g[i];
+                mv<D>(AKHA, g, g);
+            }
+            for (int i = 0; i < NN; i++) M[i] = AKHA[i];
+            for (int w = 1; w < ck; w <<= 1) mm<D>(M, M, M);   // M = AKHA^ck
+            double Pw[NN];
+            for (int i = 0; i < NN; i++) Pw[i] = M[i];
+            for (int lv = 0; lv < 4; lv++) {
+                for (int i = 0; i < NN; i++) SP[lv * NN + i] = Pw[i];
+                mm<D>(Pw, Pw, Pw);
+            }
+            for (int i = 0; i < NN; i++) Pw[i] = M[i];
+            for (int r = 0; r < 16; r++) {
+                for (int i = 0; i < NN; i++) PJ[r * NN + i] = Pw[i];
+                mm<D>(Pw, M, Pw);
+            }
+            // scan usable?  every entry finite and far from the overflow threshold of the block's precision
+            const double lim = pass == 0 ? 1e150 : 1e18;
+            bool ok = true;
+            for (int i = 0; i < L::SCANOK - L::G; i++) ok = ok && (fabs(tab[i]) < lim);      // false for NaN too
+            tab[L::SCANOK - L::G] = ok ? 1.0 : 0.0;
+            if (!ok) atomicAdd(&n_unstable[pass], 1);
+            if (pass == 0) for (int i = 0; i < L::SIZE - L::G; i++) o64[L::G + i] = tab[i];
+            else for (int i = 0; i < L::SIZE - L::G; i++) o32[L::G + i] = (float)tab[i];
         }
-        for (int i = 0; i < NN; i++) Pw[i] = M[i];
-        for (int r = 0; r < 16; r++) {
-            for (int i = 0; i < NN; i++) PJ[r * NN + i] = Pw[i];
-            mm<D>(Pw, M, Pw);
-        }
-        // scan usable?  every entry finite and far from the overflow threshold of the block's precision
-        const double lim = pass == 0 ? 1e150 : 1e18;
-        bool ok = true;
-        for (int i = 0; i < L::SCANOK - L::G; i++) ok = ok && (fabs(tab[i]) < lim);      // false for NaN too
-        tab[L::SCANOK - L::G] = ok ? 1.0 : 0.0;
-        if (!ok) atomicAdd(&n_unstable[pass], 1);
-        if (pass == 0) for (int i = 0; i < L::SIZE - L::G; i++) o64[L::G + i] = tab[i];
-        else for (int i = 0; i < L::SIZE - L::G; i++) o32[L::G + i] = (float)tab[i];
     }
 }
 
@@ -237,7 +297,7 @@ void launch_ihgp_update(int kernel, int d, double dt, const double* params_dev, 
                         int* n_unstable, hipStream_t stream) {
     if (n == 0) return;
     MOIHGP_HIP_FATAL(hipMemsetAsync(n_unstable, 0, 2 * sizeof(int), stream));
-    dim3 block(64), grid((unsigned)((n + 63) / 64));
+    dim3 block(64), grid((unsigned)((n + kLPB - 1) / kLPB));
     if (d == 2)
         hipLaunchKernelGGL(ihgp_update_kernel<2>, grid, block, 0, stream, kernel, dt, params_dev, n, cb64, cb32, n_unstable);
     else
