@@ -1,0 +1,24 @@
+#!/bin/bash
+# HBM traffic of the dominant kernel of a bench config from the PMC counters, one counter per pass as MI355X_MICROARCH.md
+# prescribes (FETCH_SIZE, WRITE_SIZE in KiB; FETCH doubled on gfx950).  usage: tools/pmc_traffic.sh <config> <outdir>
+set -e
+cfg=$1; out=$2
+cd /tmp && export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
+mkdir -p "$out"
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$out/pmc_$c" -o out -- python3 bench.py --config $cfg --steps 5 --warmup 1 --no-cpu > /dev/null 2> "$out/pmc_$c.err"
+done
+python3 - "$out" <<'PY'
+import csv, glob, json, sys
+out = sys.argv[1]
+res = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = sorted(glob.glob(f"{out}/pmc_{c}/**/*counter_collection.csv", recursive=True))[-1]
+    rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == c and ("filter_x_kernel" in r["Kernel_Name"] or "filter_scan_kernel" in r["Kernel_Name"])]
+    v = [float(r["Counter_Value"]) for r in rows]
+    res[c] = dict(launches=len(v), mean_KiB=sum(v) / len(v), kernel=rows[0]["Kernel_Name"][:80], vgpr=rows[0]["VGPR_Count"], lds=rows[0]["LDS_Block_Size"], scratch=rows[0]["Scratch_Size"])
+res["hbm_bytes_per_launch"] = (2.0 * res["FETCH_SIZE"]["mean_KiB"] + res["WRITE_SIZE"]["mean_KiB"]) * 1024.0
+json.dump(res, open(f"{out}/traffic.json", "w"), indent=1)
+print(json.dumps(res))
+PY
