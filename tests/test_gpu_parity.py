@@ -691,3 +691,86 @@ def test_stacked_time_split_matches_unsplit(env, kern, dtype, monkeypatch):
     okn = np.isfinite(yo)
     assert np.abs((yg - yo)[okn]).max() / np.abs(yo[okn]).max() < tol
     assert rel_err(n2.cpu().numpy()[tame], o["nll_per_latent"][tame]) < tol
+
+
+# ------------------------------------------------------------------------------------------ seeded fuzz over shapes and gaps
+def _fuzz_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    kerns = ["Matern32", "Matern52", "Matern52x2", "Matern32x3", "Matern52x4"]
+    out = []
+    for i in range(n):
+        T = int(rng.choice([0, 1, 2, 15, 16, 17, 31, 33, 511, 512, 513, 1023, 1024, 1025, 2047, 2048, 2049, 4100, int(rng.integers(1, 6000))]))
+        out.append((kerns[i % len(kerns)], int(rng.integers(1, 48)), T, float(rng.choice([0.0, 0.0, 0.01, 0.3, 1.0])),
+                    "f64" if rng.random() < 0.5 else "f32", int(rng.integers(0, 2 ** 31))))
+    return out
+
+
+@pytest.mark.parametrize("kern,L,T,nanf,dt_,seed", _fuzz_cases(200, 20260101))
+def test_filter_fuzz_vs_oracle(env, kern, L, T, nanf, dt_, seed):
+    """Random latent counts, lengths around every segment / chunk boundary, missing-data rates from none to all, random
+    start states, both precisions, reference and stacked models: filtered means, final state and NLL against the oracle."""
+    rng = np.random.default_rng(seed)
+    dtype = torch.float64 if dt_ == "f64" else torch.float32
+    stacked = "x" in kern
+    prm = synth_params_stacked(L, int(kern[-1]), rng) if stacked else synth_params(L, rng)
+    bank = env["streams"].LatentBank(0.1, prm, kernel=kern if stacked else KMAP[kern])
+    igps = env["cref"].ihgp_array(kern, 0.1, prm)
+    x0 = 0.3 * rng.standard_normal((L, bank.d))
+    if T == 0:
+        _, xT, nll = bank.filter(torch.zeros((L, 4), dtype=dtype, device="cuda"), T=0, x=torch.from_numpy(x0).to(dtype).cuda())
+        torch.cuda.synchronize()
+        assert rel_err(xT.cpu().numpy(), x0) < 1e-6 and float(nll.abs().sum()) == 0.0
+        return
+    Ty = synth(L, T, rng, nan_frac=nanf if nanf < 1.0 else 0.0)
+    if nanf >= 1.0:
+        Ty[:] = np.nan
+    o = env["cref"].filter_stream(igps, Ty, x0=x0, nthreads=4)
+    yhat, xT, nll = bank.filter(to_dev(Ty, dtype), T=T, x=torch.from_numpy(x0).to(dtype).cuda())
+    torch.cuda.synchronize()
+    tol = FP64_TIGHT if dtype == torch.float64 else FP32_TOL
+    yo = o["yhat"]
+    tame = np.nan_to_num(np.abs(yo), nan=0.0, posinf=np.inf).max(axis=1) < (1e100 if dtype == torch.float64 else 1e20)   # literal-DARE unstable latents aside
+    if not tame.any():
+        return
+    yg = yhat[:, :T].cpu().numpy()
+    scale = max(np.abs(yo[tame]).max(), 1e-300)
+    assert np.abs(yg[tame] - yo[tame]).max() / scale < tol * 10, (kern, L, T, nanf, dt_)
+    xscale = max(np.abs(o["x"][tame]).max(), 1e-6 * np.abs(x0).max())         # (an all-missing stream decays the state to ~0)
+    assert np.abs(xT.cpu().numpy()[tame] - o["x"][tame]).max() / xscale < tol * 10
+    nscale = max(np.abs(o["nll_per_latent"][tame]).max(), 1e-300)
+    assert np.abs(nll.cpu().numpy()[tame] - o["nll_per_latent"][tame]).max() / nscale < tol * 10
+
+
+def _grad_fuzz_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        T = int(rng.choice([1, 2, 7, 8, 9, 16, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 1500, int(rng.integers(1, 2500))]))
+        out.append((["Matern32", "Matern52"][i % 2], int(rng.integers(1, 40)), T, float(rng.choice([0.0, 0.0, 0.02, 0.4])),
+                    "f64" if rng.random() < 0.5 else "f32", int(rng.integers(0, 2 ** 31))))
+    return out
+
+
+@pytest.mark.parametrize("kern,L,T,nanf,dt_,seed", _grad_fuzz_cases(80, 77))
+def test_gradstream_fuzz_vs_oracle(env, kern, L, T, nanf, dt_, seed):
+    """The sensitivity / gradient sweep (A2 + A5) over random shapes around its chunk boundaries, with and without gaps."""
+    rng = np.random.default_rng(seed)
+    dtype = torch.float64 if dt_ == "f64" else torch.float32
+    prm = synth_params(L, rng)
+    bank = env["streams"].LatentBank(0.1, prm, kernel=KMAP[kern])
+    d = bank.d
+    Ty = synth(L, T, rng, nanf)
+    x0 = 0.2 * rng.standard_normal((L, d)); dx0 = 0.05 * rng.standard_normal((L, 3, d))
+    o = env["cref"].grad_stream(env["cref"].ihgp_array(kern, 0.1, prm), Ty, x0=x0, dx0=dx0)
+    r = bank.grad(to_dev(Ty, dtype), T=T, x=torch.from_numpy(x0).to(dtype).cuda(), dx=torch.from_numpy(dx0).to(dtype).cuda(), want_yhat=True)
+    torch.cuda.synchronize()
+    tol = 1e-9 if dtype == torch.float64 else FP32_TOL
+    tame = np.nan_to_num(np.abs(o["yhat"]), nan=0.0).max(axis=1) < 1e6           # literal-DARE unstable latents aside
+    if not tame.any():
+        return
+    def err(a, b, floor=0.0):
+        return float(np.abs(a[tame] - b[tame]).max() / max(np.abs(b[tame]).max(), floor, 1e-300))
+    assert err(r["yhat"][:, :T].cpu().numpy(), o["yhat"]) < tol
+    assert err(r["x"].cpu().numpy(), o["x"]) < tol and err(r["dx"].cpu().numpy(), o["dx"], 1e-6) < tol * 10
+    assert err(r["nll"].cpu().numpy(), o["nll_per_latent"]) < tol
+    assert err(r["grad"].cpu().numpy(), o["grad"], 1e-6) < tol * 10
