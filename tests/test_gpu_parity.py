@@ -774,3 +774,49 @@ def test_gradstream_fuzz_vs_oracle(env, kern, L, T, nanf, dt_, seed):
     assert err(r["x"].cpu().numpy(), o["x"]) < tol and err(r["dx"].cpu().numpy(), o["dx"], 1e-6) < tol * 10
     assert err(r["nll"].cpu().numpy(), o["nll_per_latent"]) < tol
     assert err(r["grad"].cpu().numpy(), o["grad"], 1e-6) < tol * 10
+
+
+def _abi_fuzz_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        L = int(rng.integers(1, 40))
+        M = L + int(rng.choice([0, 0, 1, 3, int(rng.integers(0, 120))]))
+        out.append((["Matern32", "Matern52"][i % 2], M, L, i % 3 != 0, int(rng.integers(0, 2 ** 31))))
+    return out
+
+
+@pytest.mark.parametrize("kern,M,L,fused,seed", _abi_fuzz_cases(45, 5))
+def test_reference_abi_fuzz_vs_oracle(env, kern, M, L, fused, seed, monkeypatch):
+    """The 26-symbol reference ABI over random model sizes on both of its device paths (single-workgroup fused kernels for small
+    models, the multi-kernel path otherwise or when MOIHGP_TICK_FUSED=0): every step overload, both likelihood overloads, a
+    missing-output tick, states fed forward like the reference's callers do."""
+    if not fused:
+        monkeypatch.setenv("MOIHGP_TICK_FUSED", "0")
+    rng = np.random.default_rng(seed)
+    gp = env["MOIHGP"](0.1, M, L, kernel=KMAP[kern])
+    ref = env["cref"].GP(0.1, M, L, kern)
+    ref.set_literal_ugrad(0)
+    d, P = gp.igp_dim, 3
+    params = np.concatenate([(np.eye(M, L) + 0.2 * rng.standard_normal((M, L))).ravel(), rng.uniform(0.5, 2, L), [rng.uniform(0.01, 0.1)], synth_params(L, rng).ravel()])
+    gp.update(params); ref.update(params)
+    assert rel_err(gp.params, ref.params) < FP64_TIGHT
+    x, dx = 0.5 * rng.standard_normal((L, d)), 0.1 * rng.standard_normal((L, P, d))
+    for t in range(4):
+        y = rng.standard_normal(M)
+        l1, g1 = gp.negLogLikelihood(x, y, dx); l2, g2 = ref.negLogLikelihood(x, y, dx)
+        assert abs(l1 - l2) < FP64_TIGHT * max(1.0, abs(l2)) and rel_err(g1, g2) < 1e-8
+        assert abs(gp.negLogLikelihood(x, y) - ref.negLogLikelihood(x, y)) < FP64_TIGHT * max(1.0, abs(l2))
+        a = gp.step(x, y, dx); b = ref.step(x, y, dx)                      # overload 1
+        for u, v in zip(a, b):
+            assert rel_err(u, v) < FP64_TIGHT
+        a3 = gp.step(x, y); b3 = ref.step(x, y)                            # overload 3
+        assert rel_err(a3[0], b3[0]) < FP64_TIGHT and rel_err(a3[1], b3[1]) < FP64_TIGHT
+        if t == 1:
+            a4 = gp.step(x); b4 = ref.step(x)                              # overload 4 (prediction only)
+            assert rel_err(a4[0], b4[0]) < FP64_TIGHT and rel_err(a4[1], b4[1]) < FP64_TIGHT
+        if t == 2 and M > L:
+            ym = y.copy(); ym[rng.choice(M, size=max(1, (M - L) // 2), replace=False)] = np.nan
+            am = gp.step(x, ym); bm = ref.step(x, ym)                      # least-squares projection over the observed rows
+            assert rel_err(am[0], bm[0]) < 1e-7 and rel_err(am[1], bm[1]) < 1e-7
+        x, dx = a[0], a[2]
