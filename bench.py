@@ -9,9 +9,9 @@ unit) = one latent x one tick.  value = N * L * T / seconds_per_pass, whole job.
 Default workload (N=1): BASELINE.json's target configuration "M=4096 outputs, T=10000, Matern-5/2, fp32,
 1xMI355X" (configs[2] without its L-BFGS outer loop, which stays on the host).  N>1: every rank owns 4096
 latents of a 4096*N-output model (weak scaling, configs[3] at N=8); the only collective is the RCCL
-all-reduce of the scalar NLL.  Other configs: --config c2 | c3f64 | c2d6 | c5.
+all-reduce of the scalar NLL.  Other configs: --config c2 | c3f64 | c2d6 | c5 | c4.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c2|c3f64|c2d6|c5] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c2|c3f64|c2d6|c5|c4] [--no-cpu]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 """
@@ -39,7 +39,11 @@ CONFIGS = {
     # stacked state (sum of J Matern-5/2 components): BASELINE.json's d=6 / d=12 shapes; not models of the reference
     "c2d6": (256, 10000, torch.float64, "Matern52x2", "C2 as BASELINE.json words it: M=L=256, T=10000, 2 stacked Matern-5/2 (d=6), fp64, filter+NLL"),
     "c5": (4096, 10000, torch.float64, "Matern52x4", "C5: M=L=4096, T=10000, 4 stacked Matern-5/2 (d=12), fp64, filter+NLL (VALU-bound)"),
+    # one GPU's shard of BASELINE.json configs[3] (32768 latents over 8 GPUs, T = 1e5): the stream is swept in 1e4-tick slabs that
+    # carry the state, the way a stream that does not fit would be fed
+    "c4": (4096, 100000, torch.float32, "Matern52ss", "C4 shard: 4096 latents/GPU (32768 over 8), T=100000 in 10 slabs of 10000 ticks, Matern-5/2 (d=3), fp32, filter+NLL"),
 }
+SLAB = {"c4": 10000}           # ticks per launch; configs not listed are swept in one launch
 ORACLE_KERNEL = {"Matern52ss": "Matern52", "Matern32": "Matern32"}      # product kernel name -> oracle kernel name
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 HBM_COPY_GBPS = 6290.0
@@ -149,6 +153,8 @@ def main():
     from multioutputihgp_amd.streams import LatentBank
 
     Lg_per, T, dtype, kernel, desc = CONFIGS[args.config]
+    slab = SLAB.get(args.config, T)
+    nslab = (T + slab - 1) // slab
     Lglobal = Lg_per * world
     lo, hi = shard_bounds(Lglobal, world, rank)
     L = hi - lo
@@ -160,25 +166,32 @@ def main():
     nll = torch.empty((L,), dtype=torch.float64, device=device)
     x = torch.zeros((L, bank.d), dtype=dtype, device=device)
 
+    nll_acc = torch.zeros((L,), dtype=torch.float64, device=device)
+
     def one_pass():
         x.zero_()
-        bank.filter(Ty, T=T, x=x, yhat=yhat, nll=nll)
-        return allreduce_nll(nll)              # the path's only exchange: 8 bytes, SUM
+        if nslab == 1:
+            bank.filter(Ty, T=T, x=x, yhat=yhat, nll=nll)
+            return allreduce_nll(nll)          # the path's only exchange: 8 bytes, SUM
+        nll_acc.zero_()
+        for k in range(nslab):                 # slabs carry the state x from one launch to the next
+            s0, s1 = k * slab, min(T, (k + 1) * slab)
+            bank.filter(Ty[:, s0:], T=s1 - s0, x=x, yhat=yhat[:, s0:], nll=nll)
+            nll_acc.add_(nll)
+        return allreduce_nll(nll_acc)
 
     for _ in range(args.warmup):
         total = one_pass()
     # kernel-exact durations: HIP event pairs attached to each filter dispatch of the timed region
     # (hipExtLaunchKernel, on the launch stream), read back after the region
-    bank.profile_enable(args.steps)
+    bank.profile_enable(args.steps * nslab)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        x.zero_()
-        bank.filter(Ty, T=T, x=x, yhat=yhat, nll=nll)
-        total = allreduce_nll(nll)
+        total = one_pass()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -194,7 +207,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = Lglobal * T / (elapsed / args.steps)
         es = 4 if dtype == torch.float32 else 8
-        alg_bytes = 2 * es * L * T                      # SURVEY 8d mode F: read Ty + write Tyhat = 2*s B per Kalman step
+        alg_bytes = 2 * es * L * min(slab, T)           # per LAUNCH; SURVEY 8d mode F: read Ty + write Tyhat = 2*s B per Kalman step
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -221,7 +234,7 @@ def main():
             # the other single-GPU configurations of BASELINE.json, measured the same way (kernel-exact events), for context
             others = {}
             for name in sorted(CONFIGS):
-                if name == args.config:
+                if name == args.config or name in SLAB:
                     continue
                 L2, T2, dt2, k2, desc2 = CONFIGS[name]
                 b2 = LatentBank(0.1, synth_params(L2, 0, np.random.default_rng(SEED), k2), kernel=k2)
