@@ -9,9 +9,9 @@ unit) = one latent x one tick.  value = N * L * T / seconds_per_pass, whole job.
 Default workload (N=1): BASELINE.json's target configuration "M=4096 outputs, T=10000, Matern-5/2, fp32,
 1xMI355X" (configs[2] without its L-BFGS outer loop, which stays on the host).  N>1: every rank owns 4096
 latents of a 4096*N-output model (weak scaling, configs[3] at N=8); the only collective is the RCCL
-all-reduce of the scalar NLL.  Other configs: --config c2 | c3f64 | c2d6 | c5 | c4.
+all-reduce of the scalar NLL.  Other configs: --config c1 | c2 | c3f64 | c2d6 | c5 | c4.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c2|c3f64|c2d6|c5|c4] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c1|c2|c3f64|c2d6|c5|c4] [--no-cpu]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 """
@@ -120,12 +120,67 @@ def cpu_baseline(prm, Ty_host, T, nll_gpu_sum, yhat_gpu_sub, sub, kernel="Matern
     ), nll_rel, mean_rel
 
 
+def run_c1(args, rank, world):
+    """BASELINE.json configs[0], the reference's own CPU-runnable case (example.py / example_regression): M = L = 4, T = 500,
+    Matern-3/2, fp64, driven tick by tick through the reference ABI (gp32_step3) exactly as example.py:40-42 does.  It measures
+    call latency, not bandwidth: one step = one ABI call for all 4 latents."""
+    from multioutputihgp_amd import MOIHGP
+    M = L = 4; T = 500
+    rng = np.random.default_rng(SEED)
+    gp = MOIHGP(0.1, M, L, kernel="Matern32")
+    params = gp.params.copy()
+    params[M * L + L + 1:] = synth_params(L, 0, rng).ravel()
+    gp.update(params)
+    Y = np.sin(0.05 * np.arange(T)[:, None] * (1 + np.arange(M)[None, :])) + 0.1 * rng.standard_normal((T, M))
+
+    def one_pass():
+        x = np.zeros((L, gp.igp_dim)); out = np.empty((T, M))
+        for t in range(T):
+            x, out[t] = gp.step(x, Y[t])
+        return x, out
+
+    for _ in range(max(1, min(args.warmup, 2))):
+        one_pass()
+    steps = max(1, min(args.steps, 20))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        xT, Yhat = one_pass()
+    elapsed = time.perf_counter() - t0
+    per_call = elapsed / (steps * T)
+    out = {
+        "metric": "Kalman steps/sec (M outputs x T ticks) + NLL rel-err vs CPU oracle",
+        "value": L * T / (elapsed / steps), "unit": "Kalman steps/s", "n_gpus": 1, "steps": steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "C1 (example.py shape): M=L=4, T=500, Matern-3/2 (d=2), fp64, one gp32_step3 call per tick", "latents_total": L, "ticks": T,
+                   "state_dim": gp.igp_dim, "layout": "host buffers through the per-tick reference ABI"},
+        "roofline": {"bound": "hbm", "achieved": 2 * 8 * L / per_call / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": 2 * 8 * L / per_call / 1e9 / HBM_PEAK_GBPS,
+                     "traffic": None, "kernel": "fused_step_kernel", "kernel_ms": None, "call_us": per_call * 1e6,
+                     "note": "launch-latency bound by construction (64 bytes per call); see the batched entries for throughput"},
+    }
+    if not args.no_cpu:
+        from oracle import cref
+        ref = cref.GP(0.1, M, L, "Matern32")
+        ref.update(gp.params)
+        x = np.zeros((L, gp.igp_dim)); ref_out = np.empty((T, M))
+        t0 = time.perf_counter()
+        for _ in range(20):
+            x = np.zeros((L, gp.igp_dim))
+            for t in range(T):
+                x, ref_out[t] = ref.step(x, Y[t])
+        tc = (time.perf_counter() - t0) / 20
+        out["cpu_baseline"] = dict(value=L * T / tc, unit="Kalman steps/s", cores=1, kind="port",
+                                   sample="full workload, 20 passes, oracle/moihgp_oracle.c through ctypes, one call per tick")
+        out["filtered_mean_rel_err"] = float(np.max(np.abs(Yhat - ref_out)) / np.max(np.abs(ref_out)))
+        out["speedup_vs_cpu_all_cores"] = out["value"] / out["cpu_baseline"]["value"]
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS) + ["c1"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / parity leg")
     args = ap.parse_args()
 
@@ -151,6 +206,9 @@ def main():
 
     from multioutputihgp_amd.sharded import allreduce_nll, shard_bounds
     from multioutputihgp_amd.streams import LatentBank
+
+    if args.config == "c1":
+        return run_c1(args, rank, world)
 
     Lg_per, T, dtype, kernel, desc = CONFIGS[args.config]
     slab = SLAB.get(args.config, T)
