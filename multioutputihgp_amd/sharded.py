@@ -33,6 +33,34 @@ def allreduce_nll(nll_local: torch.Tensor, group=None) -> torch.Tensor:
     return total
 
 
+class PendingSum:
+    """Handle of an all-reduce in flight (allreduce_nll_async): `.wait()` returns the reduced fp64 scalar tensor."""
+
+    def __init__(self, total, work=None, host=None):
+        self._total, self._work, self._host = total, work, host
+
+    def wait(self) -> torch.Tensor:
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+            if self._host is not None:
+                self._total = self._host.to(self._total.device)
+        return self._total
+
+
+def allreduce_nll_async(nll_local: torch.Tensor, group=None) -> PendingSum:
+    """As allreduce_nll, but the collective runs on the communicator's own stream and the caller's stream does not wait for it:
+    the next sweep overlaps the 8-byte exchange of this one (slabs of a long stream, pipelined objective evaluations).  The
+    local sum is taken in stream order first, so the per-latent buffer may be overwritten right away."""
+    total = nll_local.sum(dtype=torch.float64).reshape(1)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if total.is_cuda and dist.get_backend(group) == "gloo":      # CPU rehearsal of the exchange
+            t = total.cpu()
+            return PendingSum(total, dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True), host=t)
+        return PendingSum(total, dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group, async_op=True))
+    return PendingSum(total)
+
+
 def gather_latent_grads(grad_local: torch.Tensor, L: int, group=None) -> torch.Tensor:
     """Per-latent gradients are disjoint across shards: all-gather [L_r, P] blocks into [L, P]
     (mode G only; moihgp.h:608-609 packs them latent-major)."""

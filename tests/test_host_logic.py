@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from multioutputihgp_amd.sharded import allreduce_nll, gather_latent_grads, shard_bounds
+from multioutputihgp_amd.sharded import allreduce_nll, allreduce_nll_async, gather_latent_grads, shard_bounds
 from multioutputihgp_amd.streams import padded_len
 
 
@@ -42,6 +42,14 @@ def _worker(rank, ws, port, L, q):
     tot = allreduce_nll(torch.from_numpy(nll_all[lo:hi].copy()))
     g = gather_latent_grads(torch.from_numpy(grad_all[lo:hi].copy()), L)
     ok = abs(tot.item() - nll_all.sum()) < 1e-12 * max(1, abs(nll_all.sum())) and np.array_equal(g.numpy(), grad_all)
+    # the overlapped form: several reductions in flight, the per-latent buffer reused right after each call
+    buf = torch.from_numpy(nll_all[lo:hi].copy())
+    pend = []
+    for k in range(4):
+        pend.append(allreduce_nll_async(buf * (k + 1)))
+        buf = buf.clone()
+    for k, p_ in enumerate(pend):
+        ok = ok and abs(p_.wait().item() - (k + 1) * nll_all.sum()) < 1e-12 * max(1, abs(nll_all.sum()) * (k + 1))
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 
