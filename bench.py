@@ -261,7 +261,16 @@ def main():
         # stream while pass k+1 sweeps (two in flight at most); all of them are complete before the clock stops
         pending = []
         for k in range(args.steps):
-            pending.append(one_pass(reduce=allreduce_nll_async))
+            try:
+                pending.append(one_pass(reduce=allreduce_nll_async))
+            except RuntimeError as e:              # a communicator without async collectives: finish in the ordered form
+                sys.stderr.write(f"async all-reduce unavailable ({e}); continuing stream-ordered\n")
+                for p_ in pending:
+                    total = p_.wait()
+                pending = []
+                for _ in range(k, args.steps):
+                    total = one_pass()
+                break
             if len(pending) > 2:
                 total = pending.pop(0).wait()
         for p_ in pending:
