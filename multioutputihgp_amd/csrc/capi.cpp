@@ -123,6 +123,8 @@ struct moihgp_gp {
     double* dpolar = nullptr;  // M*L + 2*L*L + 8, lazily (device polar factor)
     int* dfallback = nullptr;  // [L] flags of latents redone by the sequential gradient kernel
     double* dxscratch = nullptr; // stacked kernels, few latents: per-slice NLL partials
+    double* cbd64 = nullptr;     // stacked kernels: sensitivity blocks (XD), fp64; filled once somebody asks for gradients
+    bool sens_wanted = false, sens_valid = false;
     bool U_host_stale = false; // the device holds a newer U than the host mirror (fetched on getParams)
     double *hin = nullptr, *hout = nullptr, *hgrad = nullptr;   // page-locked, device-mapped per-tick staging
     unsigned long long* hflag = nullptr;                        // mapped completion word of the fused small-model step
@@ -142,7 +144,7 @@ struct moihgp_gp {
 
 static void gp_free(moihgp_gp* g) {
     if (!g) return;
-    void* ptrs[] = {g->dU, g->dS, g->dsqrtS, g->dinvsqrtS, g->dsigma, g->dparams, g->cb64, g->cb32, g->dx, g->dpart, g->dTy, g->dUty, g->dTyhat, g->dloss, g->dgrad, g->dscratch, g->dwork, g->dpolar, g->dfallback, g->dwin, g->dunstable, g->dxscratch};
+    void* ptrs[] = {g->dU, g->dS, g->dsqrtS, g->dinvsqrtS, g->dsigma, g->dparams, g->cb64, g->cb32, g->dx, g->dpart, g->dTy, g->dUty, g->dTyhat, g->dloss, g->dgrad, g->dscratch, g->dwork, g->dpolar, g->dfallback, g->dwin, g->dunstable, g->dxscratch, g->cbd64};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (void* p : g->pinned) (void)hipHostUnregister(p);
@@ -166,10 +168,18 @@ static void upload_mixing(moihgp_gp* g) {
 
 static void run_ihgp_update(moihgp_gp* g) {
     MOIHGP_HIP_FATAL(hipMemcpyAsync(g->dparams, g->igp.data(), sizeof(double) * g->L * g->P, hipMemcpyHostToDevice, g->stream));
-    if (kernel_stack(g->kernel)) launch_stack_update(g->kernel, g->dt, g->dparams, g->L, g->cb64, g->cb32, g->dunstable, g->stream);
+    if (kernel_stack(g->kernel)) {
+        // the sensitivities cost nine more 100-iteration Lyapunov solves per latent at d = 12: only for handles that use them
+        launch_stack_update(g->kernel, g->dt, g->dparams, g->L, g->cb64, g->cb32, g->sens_wanted ? g->cbd64 : nullptr, g->dunstable, g->stream);
+        g->sens_valid = g->sens_wanted;
+    }
     else launch_ihgp_update(g->kernel, g->d, g->dt, g->dparams, g->L, g->cb64, g->cb32, g->dunstable, g->stream);
     MOIHGP_HIP_FATAL(hipMemcpyAsync(g->n_unstable, g->dunstable, 2 * sizeof(int), hipMemcpyDeviceToHost, g->stream));
     MOIHGP_HIP_FATAL(hipStreamSynchronize(g->stream));
+}
+
+static void ensure_sensitivities(moihgp_gp* g) {
+    if (kernel_stack(g->kernel) && !g->sens_valid) { g->sens_wanted = true; run_ihgp_update(g); }
 }
 
 static bool compute_polar_fwd(moihgp_gp* g, const double* Uparam);
@@ -217,6 +227,7 @@ static moihgp_gp* gp_create(int kernel, double dt, size_t M, size_t L, bool late
     g->dparams = dev_alloc<double>(L * g->P);
     g->cb64 = dev_alloc<double>(L * cbs);
     g->cb32 = dev_alloc<float>(L * cbs);
+    if (kstack) g->cbd64 = dev_alloc<double>(L * (size_t)xd_size(g->d, g->P));
     g->dfallback = dev_alloc<int>(L);
     g->dunstable = dev_alloc<int>(2);
     g->igp.resize(L * g->P);
@@ -492,7 +503,17 @@ int moihgp_get_latent(moihgp_gp* gp, size_t l, double* A, double* K, double* S, 
     if (!gp || l >= gp->L) { set_last_error("get_latent: bad latent index"); return 1; }
     const int d = gp->d, P = gp->P;
     if (kernel_stack(gp->kernel)) {
-        if (dA || dS || dK || dAKHA || HdA) { set_last_error("get_latent: stacked kernels carry no hyper-parameter sensitivities"); return 1; }
+        if (dA || dS || dK || dAKHA || HdA || iters) {
+            ensure_sensitivities(gp);
+            const int xd = xd_size(d, P);
+            std::vector<double> bd(xd);
+            MOIHGP_HIP_FATAL(hipMemcpy(bd.data(), gp->cbd64 + l * xd, sizeof(double) * xd, hipMemcpyDeviceToHost));
+            // offsets of XD<D, P>: DAKHA, DK, DA, HDA, DS, ITERS in this order
+            const int oDK = P * d * d, oDA = oDK + P * d, oHDA = oDA + P * d * d, oDS = oHDA + P * d, oIT = oDS + P;
+            auto cpd = [&](double* dst, int off, int n) { if (dst) std::memcpy(dst, bd.data() + off, sizeof(double) * n); };
+            cpd(dAKHA, 0, P * d * d); cpd(dK, oDK, P * d); cpd(dA, oDA, P * d * d); cpd(HdA, oHDA, P * d); cpd(dS, oDS, P);
+            if (iters) for (int p = 0; p < P; p++) iters[1 + p] = (int)bd[oIT + p];
+        }
         const int xs = xc_size(d);
         std::vector<double> bx(xs);
         MOIHGP_HIP_FATAL(hipMemcpy(bx.data(), gp->cb64 + l * xs, sizeof(double) * xs, hipMemcpyDeviceToHost));
@@ -594,7 +615,9 @@ int moihgp_grad_stream(moihgp_gp* gp, int dtype, const void* Ty, size_t T, size_
                        double* grad, void* stream) {
     if (int rc = check_stream_args(gp, dtype, Ty, T, ld, x)) return rc;
     if (!dx || !grad) { set_last_error("grad_stream: dx and grad are required"); return 1; }
-    if (kernel_stack(gp->kernel)) { set_last_error("grad_stream: stacked kernels are filter-mode only"); return 1; }
+    ensure_sensitivities(gp);
+    if (kernel_stack(gp->kernel))
+        return launch_grad_stream_x(gp->kernel, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cbd64, x, dx, yhat, nll, grad, (hipStream_t)stream);
     return launch_grad_stream(gp->d, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cb32, x, dx, yhat, nll, grad, gp->dfallback, (hipStream_t)stream);
 }
 

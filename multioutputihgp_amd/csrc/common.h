@@ -74,6 +74,18 @@ struct XC {
     static constexpr int SP     = G + GN;           // [6][LS]  M^(1,2,4,8,16,32), M = AKHA^CK: levels of a 64-lane Kogge-Stone scan
     static constexpr int SIZE   = SP + 6 * LS;      // a multiple of 16: every latent's tables stay 16-aligned
 };
+// Sensitivity block of a stacked latent (fp64 only; gradient sweeps read it): ihgp.h:136-200 for P = 2J + 1 hyper-parameters.
+template <int D, int P>
+struct XD {
+    static constexpr int DAKHA = 0;                    // [P][D*D]
+    static constexpr int DK    = DAKHA + P * D * D;    // [P][D]
+    static constexpr int DA    = DK + P * D;           // [P][D*D]
+    static constexpr int HDA   = DA + P * D * D;       // [P][D]   (H dA)^T
+    static constexpr int DS    = HDA + P * D;          // [P]
+    static constexpr int ITERS = DS + P;               // [P]      DLyap iteration counts
+    static constexpr int SIZE  = (ITERS + P + 3) / 4 * 4;
+};
+constexpr int xd_size(int d, int P) { return (P * (2 * d * d + 2 * d) + 2 * P + 3) / 4 * 4; }
 constexpr int xc_size(int d) {
     return d == 4 ? XC<4>::SIZE : d == 6 ? XC<6>::SIZE : d == 8 ? XC<8>::SIZE : d == 9 ? XC<9>::SIZE : d == 12 ? XC<12>::SIZE : 0;
 }
@@ -100,11 +112,15 @@ void launch_ihgp_update(int kernel, int d, double dt, const double* params_dev, 
 // stationary_x.hip / recursion_x.hip: the same two stages for stacked models (state dim d in {4, 6, 8, 9, 12}).
 // params_dev [n][2J+1] = (magnitude_j, lengthscale_j) x J, noise.
 void launch_stack_update(int kernel, double dt, const double* params_dev, size_t n, double* cb64, float* cb32,
-                         int* n_unstable, hipStream_t stream);
+                         double* cbd64 /* [n] sensitivity blocks XD, or NULL to skip them */, int* n_unstable, hipStream_t stream);
 int launch_filter_stream_x(int kernel, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* cb64, const float* cb32,
                            void* x, void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
                            double* scratch = nullptr /* [scratch_len] per-slice NLL partials of the time split */, size_t scratch_len = 0,
                            int force_slices = 0 /* tuning / test hook: 1 = no split, n > 1 = n slices */);
+
+// grad_x.hip: sensitivity / gradient sweep of the stacked models (needs the XD blocks).
+int launch_grad_stream_x(int kernel, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* cb64, const double* cbd64,
+                         void* x, void* dx, void* yhat, double* nll, double* grad, hipStream_t stream);
 
 // recursion.hip: batched sweeps over series-major streams.
 int launch_filter_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, size_t L,

@@ -7,7 +7,7 @@
 // with the literal solver of utils/dare.h:10-33 on the full D x D system (D = J * d_base <= 12).
 // The matrix exponential is taken block by block (expm of a block-diagonal matrix is block-diagonal); a literal evaluation
 // exponentiates the full matrix as ihgp.h:120 does: the two agree to rounding (checked in tests/).
-// Hyper-parameter sensitivities (ihgp.h:136-200) are not built for stacked models yet: they are filter-mode latents.
+// The hyper-parameter sensitivities (ihgp.h:136-200) follow, one parameter after the other, into a separate fp64 block (XD).
 #include "common.h"
 
 #pragma clang fp contract(off)
@@ -18,17 +18,33 @@ namespace {
 
 // F and Pinf of one component (the reference's model code, restated in stationary.hip's ss_build as well)
 template <int DB>
-__device__ void component(double magnitude, double lengthscale, double* F, double* Pinf) {
-    for (int i = 0; i < DB * DB; i++) { F[i] = 0.0; Pinf[i] = 0.0; }
-    if constexpr (DB == 2) {                                  // matern32ss.h:40-52
+__device__ void component(double magnitude, double lengthscale, double* F, double* Pinf, double* dF_len = nullptr,
+                          double* dPinf_mag = nullptr, double* dPinf_len = nullptr) {
+    for (int i = 0; i < DB * DB; i++) {
+        F[i] = 0.0; Pinf[i] = 0.0;
+        if (dF_len) { dF_len[i] = 0.0; dPinf_mag[i] = 0.0; dPinf_len[i] = 0.0; }
+    }
+    if constexpr (DB == 2) {                                  // matern32ss.h:40-64
         double lam = sqrt(3.0) / lengthscale, lam2 = lam * lam;
+        double len3 = 6.0 / (lengthscale * lengthscale * lengthscale);
         F[1] = 1.0; F[2] = -lam2; F[3] = -2.0 * lam;
         Pinf[0] = magnitude; Pinf[3] = magnitude * lam2;
-    } else {                                                  // matern52ss.h:38-58, `lam = sqrt(3)/l` as there
-        double lam = sqrt(3.0) / lengthscale, lam2 = lam * lam, len2 = lengthscale * lengthscale, len4 = len2 * len2;
-        double kappa = 5.0 / 3.0 * magnitude / len2;
+        if (dF_len) {
+            dF_len[2] = len3; dF_len[3] = 2.0 * lam / lengthscale;
+            dPinf_mag[0] = 1.0; dPinf_mag[3] = lam2;
+            dPinf_len[3] = -magnitude * len3;
+        }
+    } else {                                                  // matern52ss.h:38-75, `lam = sqrt(3)/l` as there
+        double lam = sqrt(3.0) / lengthscale, lam2 = lam * lam, len2 = lengthscale * lengthscale, len3 = len2 * lengthscale, len4 = len2 * len2;
+        double kappa = 5.0 / 3.0 * magnitude / len2, kappa2 = -2.0 * kappa / lengthscale, sq5 = sqrt(5.0);
         F[1] = 1.0; F[5] = 1.0; F[6] = -lam2 * lam; F[7] = -3.0 * lam2; F[8] = -3.0 * lam;
         Pinf[0] = magnitude; Pinf[8] = 25.0 * magnitude / len4; Pinf[4] = kappa; Pinf[6] = -kappa; Pinf[2] = -kappa;
+        if (dF_len) {
+            dF_len[6] = 15.0 * sq5 / len4; dF_len[7] = 30.0 / len3; dF_len[8] = sq5 * lam2;
+            for (int i = 0; i < 9; i++) dPinf_mag[i] = Pinf[i] / magnitude;
+            dPinf_len[4] = kappa2; dPinf_len[6] = -kappa2; dPinf_len[2] = -kappa2;
+            dPinf_len[8] = -100.0 * magnitude / len2 / len3;
+        }
     }
 }
 
@@ -58,6 +74,24 @@ __device__ inline void wmm(const double* A, const double* B, double* C, int lane
     lds_sync();
 }
 template <int D>
+__device__ inline void wmm_bt(const double* A, const double* B, double* C, int lane) {       // C = A B^T (C may alias A or B)
+    double r[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        const int e = lane + 64 * q;
+        double sum = 0.0;
+        if (e < D * D) {
+            const int i = e / D, j = e % D;
+            for (int k = 0; k < D; k++) sum += A[i * D + k] * B[j * D + k];
+        }
+        r[q] = sum;
+    }
+    lds_sync();
+#pragma unroll
+    for (int q = 0; q < 3; q++) if (lane + 64 * q < D * D) C[lane + 64 * q] = r[q];
+    lds_sync();
+}
+template <int D>
 __device__ inline void wmt(const double* A, double* At, int lane) {                           // At = A^T (no aliasing)
 #pragma unroll
     for (int q = 0; q < 3; q++) { const int e = lane + 64 * q; if (e < D * D) At[(e % D) * D + e / D] = A[e]; }
@@ -75,10 +109,13 @@ __device__ inline void wmv(const double* A, const double* x, double* y, int lane
 template <int DB, int J>
 __global__ void __launch_bounds__(64) stack_update_kernel(double dt, const double* __restrict__ params, size_t n,
                                                           double* __restrict__ cb64, float* __restrict__ cb32,
-                                                          int* __restrict__ n_unstable) {
-    constexpr int D = DB * J, NN = D * D, P = 2 * J + 1;
+                                                          double* __restrict__ cbd64, int* __restrict__ n_unstable) {
+    constexpr int D = DB * J, NN = D * D, P = 2 * J + 1, BB = DB * DB;
     using L = XC<D>;
     __shared__ double sA[NN], sAT[NN], sQ[NN], sP[NN], sT1[NN], sT2[NN], sAKHA[NN], sH[D], sV1[D], sV2[D], sV3[D], sK[D], sHA[D];
+    // sensitivities (ihgp.h:136-200)
+    __shared__ double sPinf[NN], sAAKH[NN], sdA[NN], sdPi[NN], sQL[NN], sT3[NN], sAK[D], sPHt[D], sHPP[D];
+    __shared__ double sdAb[J][BB], sdPm[J][BB], sdPl[J][BB];
     const size_t l = blockIdx.x;                                   // one wavefront per latent
     const int lane = threadIdx.x;
     if (l >= n) return;
@@ -97,7 +134,30 @@ __global__ void __launch_bounds__(64) stack_update_kernel(double dt, const doubl
                 sA[(lane * DB + a) * D + lane * DB + b] = E[a * DB + b];
                 sT1[(lane * DB + a) * D + lane * DB + b] = Pj[a * DB + b];
             }
+    } else if (cbd64 && lane >= 16 && lane < 16 + J) {
+        // meanwhile, for the lengthscale of component j: the 2 DB x 2 DB block exponential of ihgp.h:163-167 (block j of dA)
+        const int j = lane - 16;
+        double F[BB], Pj[BB], dFl[BB], dPm[BB], dPl[BB];
+        component<DB>(prm[2 * j], prm[2 * j + 1], F, Pj, dFl, dPm, dPl);
+        constexpr int M2 = 2 * DB;
+        double FF[M2 * M2], EF[M2 * M2];
+        for (int i = 0; i < M2 * M2; i++) FF[i] = 0.0;
+        for (int a = 0; a < DB; a++)
+            for (int b = 0; b < DB; b++) {
+                FF[a * M2 + b] = dt * F[a * DB + b];
+                FF[(DB + a) * M2 + (DB + b)] = dt * F[a * DB + b];
+                FF[(DB + a) * M2 + b] = dt * dFl[a * DB + b];
+            }
+        expm<M2>(FF, EF);
+        for (int a = 0; a < DB; a++)
+            for (int b = 0; b < DB; b++) {
+                sdAb[j][a * DB + b] = EF[(DB + a) * M2 + b];
+                sdPm[j][a * DB + b] = dPm[a * DB + b];
+                sdPl[j][a * DB + b] = dPl[a * DB + b];
+            }
     }
+    lds_sync();
+    for (int e = lane; e < NN; e += 64) sPinf[e] = sT1[e];
     lds_sync();
     wmt<D>(sA, sAT, lane);
     wmm<D>(sA, sT1, sT2, lane);                                       // A Pinf
@@ -203,28 +263,122 @@ __global__ void __launch_bounds__(64) stack_update_kernel(double dt, const doubl
         put(L::SCANOK, ok ? 1.0 : 0.0);
         if (!ok) { atomicAdd(&n_unstable[0], 1); atomicAdd(&n_unstable[1], 1); }
     }
+    if (!cbd64) return;
+
+    // ---- sensitivities, ihgp.h:136-200, one hyper-parameter after the other: p = 2j (magnitude of component j),
+    //      2j + 1 (its lengthscale), 2J (noise).  dF != 0 only for lengthscales; dPinf == 0 only for the noise; dR != 0 only for it.
+    using X = XD<D, P>;
+    double* od = cbd64 + l * X::SIZE;
+    wmv<D>(sP, sH, sPHt, lane);                                       // PP H^T
+    if (lane < D) { double t = 0.0; for (int i = 0; i < D; i++) t += sH[i] * sP[i * D + lane]; sHPP[lane] = t; }   // H PP
+    wmv<D>(sA, sK, sAK, lane);                                        // ihgp.h:132
+    for (int e = lane; e < NN; e += 64) sAAKH[e] = sA[e] - sAK[e / D] * sH[e % D];                // ihgp.h:133
+    lds_sync();
+    wmt<D>(sAAKH, sT3, lane);                                         // Ad^T of the Lyapunov iteration
+    for (int p = 0; p < P; p++) {
+        const int j = p / 2, q = p % 2;
+        const bool noise = (p == 2 * J);
+        const bool dF_zero = noise || q == 0, dR_zero = !noise;
+        const double dR = noise ? 1.0 : 0.0;
+        for (int e = lane; e < NN; e += 64) {
+            const int r = e / D, c = e % D;
+            const bool inb = !noise && r / DB == j && c / DB == j;
+            const int be = (r % DB) * DB + (c % DB);
+            sdA[e] = (inb && q == 1) ? sdAb[j][be] : 0.0;
+            sdPi[e] = inb ? (q == 0 ? sdPm[j][be] : sdPl[j][be]) : 0.0;
+        }
+        lds_sync();
+        if (dF_zero) {                                                // ihgp.h:141
+            if (noise) {
+                for (int e = lane; e < NN; e += 64) sQ[e] = 0.0;      // ihgp.h:146
+            } else {
+                wmm<D>(sA, sdPi, sT1, lane); wmm_bt<D>(sT1, sA, sT2, lane);
+                for (int e = lane; e < NN; e += 64) sQ[e] = sdPi[e] - sT2[e];          // ihgp.h:150
+            }
+            lds_sync();
+            for (int e = lane; e < NN; e += 64)                       // ihgp.h:154 / :158 (as AK dR AK^T)
+                sQL[e] = dR_zero ? sQ[e] : sAK[e / D] * dR * sAK[e % D] + sQ[e];
+            lds_sync();
+        } else {
+            wmm<D>(sdA, sPinf, sT1, lane); wmm_bt<D>(sT1, sA, sT2, lane);               // dA Pinf A^T
+            wmm<D>(sA, sPinf, sT1, lane); wmm_bt<D>(sT1, sdA, sQL, lane);               // A Pinf dA^T
+            wmm<D>(sA, sdPi, sT1, lane); wmm_bt<D>(sT1, sA, sQ, lane);                  // A dPinf A^T
+            for (int e = lane; e < NN; e += 64) sQ[e] = sdPi[e] - sT2[e] - sQ[e] - sQL[e];   // ihgp.h:175
+            lds_sync();
+            wmm<D>(sdA, sP, sT1, lane); wmm_bt<D>(sT1, sA, sT2, lane);                  // dA PP A^T
+            wmm<D>(sA, sP, sT1, lane); wmm_bt<D>(sT1, sdA, sQL, lane);                  // A PP dA^T
+            wmv<D>(sdA, sPHt, sV1, lane);                                                // dA PP H^T
+            wmv<D>(sdA, sHPP, sV2, lane);                                                // (H PP dA^T)^T
+            for (int e = lane; e < NN; e += 64) {                     // ihgp.h:179
+                const double v = sT2[e] + sQL[e] - sV1[e / D] * sAK[e % D] - sAK[e / D] * sV2[e % D];
+                sT1[e] = v + sQ[e];
+            }
+            lds_sync();
+            for (int e = lane; e < NN; e += 64) sQL[e] = sT1[e];
+            lds_sync();
+        }
+        // dPP = DLyap(A - A K H, QLyap), utils/dare.h:36-58 (literal `AdT P Ad - P + Q`); P lives in sQ
+        for (int e = lane; e < NN; e += 64) sQ[e] = sQL[e];
+        lds_sync();
+        int its = kDareMaxIter;
+        for (int it = 0; it < kDareMaxIter; it++) {
+            wmm<D>(sT3, sQ, sT1, lane);
+            wmm<D>(sT1, sAAKH, sT2, lane);
+            double diff = -INFINITY;
+            for (int e = lane; e < NN; e += 64) {
+                const double v = sT2[e] - sQ[e] + sQL[e];             // dare.h:48 (sic)
+                sT1[e] = v;
+                const double dlt = v - sQ[e];
+                if (dlt > diff) diff = dlt;
+            }
+            for (int o = 32; o >= 1; o >>= 1) { const double other = __shfl_xor(diff, o, 64); if (other > diff) diff = other; }
+            diff = fabs(diff);
+            lds_sync();
+            for (int e = lane; e < NN; e += 64) sQ[e] = (sT1[e] + sT1[(e % D) * D + e / D]) / 2.0;
+            lds_sync();
+            if (diff < kDareTol) { its = it + 1; break; }
+        }
+        double dS = dR;
+        for (int i = 0; i < D; i++)
+            for (int c = 0; c < D; c++) dS += sH[i] * sQ[i * D + c] * sH[c];             // ihgp.h:188
+        if (lane < D) {                                               // ihgp.h:189
+            double t = 0.0;
+            for (int c = 0; c < D; c++) t += (sQ[lane * D + c] - sP[lane * D + c] * dS / S) * sH[c];
+            sV1[lane] = t / S;                                        // dK
+        }
+        if (lane < D) { double t = 0.0; for (int i = 0; i < D; i++) t += sH[i] * sdA[i * D + lane]; sV2[lane] = t; }   // H dA
+        lds_sync();
+        if (lane == 0) { od[X::DS + p] = dS; od[X::ITERS + p] = (double)its; }
+        if (lane < D) { od[X::DK + p * D + lane] = sV1[lane]; od[X::HDA + p * D + lane] = dF_zero ? 0.0 : sV2[lane]; }
+        for (int e = lane; e < NN; e += 64) {
+            od[X::DA + p * NN + e] = sdA[e];
+            od[X::DAKHA + p * NN + e] = dF_zero ? -sV1[e / D] * sHA[e % D]                               // ihgp.h:192
+                                                : sdA[e] - sV1[e / D] * sHA[e % D] - sK[e / D] * sV2[e % D];   // ihgp.h:197
+        }
+        lds_sync();
+    }
 }
 
 template <int DB, int J>
-void launch_t(double dt, const double* params, size_t n, double* cb64, float* cb32, int* n_unstable, hipStream_t s) {
-    hipLaunchKernelGGL((stack_update_kernel<DB, J>), dim3((unsigned)n), dim3(64), 0, s, dt, params, n, cb64, cb32, n_unstable);
+void launch_t(double dt, const double* params, size_t n, double* cb64, float* cb32, double* cbd64, int* n_unstable, hipStream_t s) {
+    hipLaunchKernelGGL((stack_update_kernel<DB, J>), dim3((unsigned)n), dim3(64), 0, s, dt, params, n, cb64, cb32, cbd64, n_unstable);
 }
 
 }  // namespace
 
-void launch_stack_update(int kernel, double dt, const double* params_dev, size_t n, double* cb64, float* cb32, int* n_unstable,
-                         hipStream_t stream) {
+void launch_stack_update(int kernel, double dt, const double* params_dev, size_t n, double* cb64, float* cb32, double* cbd64,
+                         int* n_unstable, hipStream_t stream) {
     if (n == 0) return;
     MOIHGP_HIP_FATAL(hipMemsetAsync(n_unstable, 0, 2 * sizeof(int), stream));
     const int base = kernel_base(kernel), J = kernel_stack(kernel);
     if (base == 0) {
-        if (J == 2) launch_t<2, 2>(dt, params_dev, n, cb64, cb32, n_unstable, stream);
-        else if (J == 3) launch_t<2, 3>(dt, params_dev, n, cb64, cb32, n_unstable, stream);
-        else launch_t<2, 4>(dt, params_dev, n, cb64, cb32, n_unstable, stream);
+        if (J == 2) launch_t<2, 2>(dt, params_dev, n, cb64, cb32, cbd64, n_unstable, stream);
+        else if (J == 3) launch_t<2, 3>(dt, params_dev, n, cb64, cb32, cbd64, n_unstable, stream);
+        else launch_t<2, 4>(dt, params_dev, n, cb64, cb32, cbd64, n_unstable, stream);
     } else {
-        if (J == 2) launch_t<3, 2>(dt, params_dev, n, cb64, cb32, n_unstable, stream);
-        else if (J == 3) launch_t<3, 3>(dt, params_dev, n, cb64, cb32, n_unstable, stream);
-        else launch_t<3, 4>(dt, params_dev, n, cb64, cb32, n_unstable, stream);
+        if (J == 2) launch_t<3, 2>(dt, params_dev, n, cb64, cb32, cbd64, n_unstable, stream);
+        else if (J == 3) launch_t<3, 3>(dt, params_dev, n, cb64, cb32, cbd64, n_unstable, stream);
+        else launch_t<3, 4>(dt, params_dev, n, cb64, cb32, cbd64, n_unstable, stream);
     }
     MOIHGP_HIP_FATAL(hipGetLastError());
 }

@@ -95,9 +95,8 @@ class LatentBank:
 
     def latent(self, l: int) -> dict:
         d, P = self.d, self.P
-        out = dict(A=np.zeros((d, d)), K=np.zeros(d), S=np.zeros(1), HA=np.zeros(d), AKHA=np.zeros((d, d)))
-        if not self.stacked:
-            out.update(dA=np.zeros((P, d, d)), dS=np.zeros(P), dK=np.zeros((P, d)), dAKHA=np.zeros((P, d, d)), HdA=np.zeros((P, d)))
+        out = dict(A=np.zeros((d, d)), K=np.zeros(d), S=np.zeros(1), HA=np.zeros(d), AKHA=np.zeros((d, d)),
+                   dA=np.zeros((P, d, d)), dS=np.zeros(P), dK=np.zeros((P, d)), dAKHA=np.zeros((P, d, d)), HdA=np.zeros((P, d)))
         iters = (C.c_int * (1 + P))()
         ptrs = [out[k].ctypes.data_as(c_double_p) if k in out else None for k in ("A", "K", "S", "HA", "AKHA", "dA", "dS", "dK", "dAKHA", "HdA")]
         _check(self._lib.moihgp_get_latent(self._h, l, *ptrs, iters), self._lib)

@@ -166,6 +166,31 @@ def gen_stacked():
             cres = cref.filter_stream(cref.ihgp_array(kern, 0.1, params), Ty, x0=x0)
             assert rel(cres["yhat"], yhat) < 1e-10 and rel(cres["x"], xT) < 1e-10 and rel(cres["nll_per_latent"], nll) < 1e-10
             out.update({f"{tag}_Ty": Ty, f"{tag}_x0": x0, f"{tag}_yhat": yhat, f"{tag}_xT": xT, f"{tag}_nll": nll})
+        # sensitivities (ihgp.h:136-200) and a short gradient sweep with a few gaps
+        P = 2 * J + 1
+        sens = {k: [] for k in ("dA", "dAKHA", "dK", "dS", "HdA", "dlyap_iters")}
+        for l in range(L):
+            g.update(params[l])
+            c = cref.ihgp_update(kern, 0.1, params[l])
+            vals = dict(dA=np.array(g.dA), dAKHA=np.array(g.dAKHA), dK=np.array([k[:, 0] for k in g.dK]),
+                        dS=np.array([v[0, 0] for v in g.dS]), HdA=np.array([h[:, 0] for h in g.HdA]))
+            for k, v in vals.items():
+                assert rel(c.mat(k), v) < 1e-10 or np.max(np.abs(v)) == 0, (kern, k, rel(c.mat(k), v))
+                sens[k].append(v)
+            assert list(c.dlyap_iters)[:P] == list(g.dlyap_iters)
+            sens["dlyap_iters"].append(np.array(g.dlyap_iters))
+        out.update({k: np.array(v) for k, v in sens.items()})
+        Tg = 200
+        Ty = synth_stream(L, Tg, rng, 0.02)
+        x0 = 0.1 * rng.standard_normal((L, d)); dx0 = 0.05 * rng.standard_normal((L, P, d))
+        yhat = np.zeros((L, Tg)); xT = np.zeros_like(x0); dxT = np.zeros_like(dx0); nll = np.zeros(L); grad = np.zeros((L, P))
+        for l in range(L):
+            g.update(params[l])
+            r = onp.filter_stream(g, Ty[l], x0=x0[l], dx0=dx0[l], want_grad=True)
+            yhat[l], xT[l], dxT[l], nll[l], grad[l] = r["yhat"], r["x"], r["dx"], r["nll"], r["grad"]
+        cg = cref.grad_stream(cref.ihgp_array(kern, 0.1, params), Ty, x0=x0, dx0=dx0)
+        assert rel(cg["yhat"], yhat) < 1e-10 and rel(cg["dx"], dxT) < 1e-9 and rel(cg["grad"], grad) < 1e-9, (rel(cg["dx"], dxT), rel(cg["grad"], grad))
+        out.update(grad_Ty=Ty, grad_x0=x0, grad_dx0=dx0, grad_yhat=yhat, grad_xT=xT, grad_dxT=dxT, grad_nll=nll, grad_grad=grad)
         np.savez(os.path.join(OUT, f"stacked_{kern}.npz"), **out)
 
 

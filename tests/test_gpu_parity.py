@@ -532,6 +532,18 @@ def test_stacked_vs_golden(env, kern):
         for k in ("A", "K", "HA", "AKHA"):
             assert rel_err(m[k], g[k][l]) < 1e-10, (k, rel_err(m[k], g[k][l]))
         assert abs(m["S"] - g["S"][l]) < 1e-10 * g["S"][l] and m["iters"][0] == int(g["dare_iters"][l])
+    Tg = g["grad_Ty"].shape[1]
+    for dtype, tol in ((torch.float64, 1e-9), (torch.float32, FP32_TOL)):          # gradient sweep golden
+        r = bank.grad(to_dev(g["grad_Ty"], dtype), T=Tg, x=torch.from_numpy(g["grad_x0"]).to(dtype).cuda(),
+                      dx=torch.from_numpy(g["grad_dx0"]).to(dtype).cuda(), want_yhat=True)
+        torch.cuda.synchronize()
+        assert rel_err(r["yhat"][:, :Tg].cpu().numpy(), g["grad_yhat"]) < tol and rel_err(r["dx"].cpu().numpy(), g["grad_dxT"]) < tol * 10
+        assert rel_err(r["grad"].cpu().numpy(), g["grad_grad"]) < tol * 10 and rel_err(r["nll"].cpu().numpy(), g["grad_nll"]) < tol * 10
+    for l in range(bank.L):
+        m = bank.latent(l)
+        for k in ("dA", "dAKHA", "dK", "dS", "HdA"):
+            assert rel_err(m[k], g[k][l]) < 1e-10, (k, rel_err(m[k], g[k][l]))
+        assert list(m["iters"][1:]) == list(g["dlyap_iters"][l])
     for tag in ("dense", "nan5"):
         T = g[f"{tag}_Ty"].shape[1]
         for dtype, tol in ((torch.float64, FP64_TIGHT), (torch.float32, FP32_TOL)):
@@ -608,12 +620,7 @@ def test_stacked_missing_data_and_slabs(env, kern):
     assert rel_err((na + nb).cpu().numpy(), o["nll_per_latent"]) < FP64_TIGHT and rel_err(xb.cpu().numpy(), o["x"]) < FP64_TIGHT
 
 
-def test_stacked_is_filter_mode_only(env):
-    from multioutputihgp_amd import MoihgpError
-    bank = env["streams"].LatentBank(0.1, [[1, 1, 1, 2, 0.1]] * 3, kernel="Matern52x2")
-    Ty = torch.zeros((3, 16), dtype=torch.float64, device="cuda")
-    with pytest.raises(MoihgpError):
-        bank.grad(Ty, T=16)
+def test_stacked_full_objects_are_refused(env):
     # a full MOIHGP object (mixing + per-tick ABI + gradients) with a stacked kernel is refused, with a message
     assert not env["lib"].moihgp_new(1 | (2 << 4), 0.1, 4, 2)
     assert b"stacked" in env["lib"].moihgp_last_error()
@@ -820,3 +827,47 @@ def test_reference_abi_fuzz_vs_oracle(env, kern, M, L, fused, seed, monkeypatch)
             am = gp.step(x, ym); bm = ref.step(x, ym)                      # least-squares projection over the observed rows
             assert rel_err(am[0], bm[0]) < 1e-7 and rel_err(am[1], bm[1]) < 1e-7
         x, dx = a[0], a[2]
+
+
+@pytest.mark.parametrize("kern", STACKED)
+def test_stacked_sensitivities_vs_oracle(env, kern):
+    """IHGP::update's derivative part (ihgp.h:136-200) for stacked models: dA, dAKHA, dK, dS, HdA per hyper-parameter and the
+    DLyap iteration counts against the C oracle (bitwise for Matern-3/2 stacks; the Matern-5/2 ones differ by the block-wise
+    matrix exponential)."""
+    J = int(kern[-1])
+    rng = np.random.default_rng(40 + J)
+    L = 5
+    prm = synth_params_stacked(L, J, rng)
+    bank = env["streams"].LatentBank(0.1, prm, kernel=kern)
+    for l in range(L):
+        m = bank.latent(l)
+        c = env["cref"].ihgp_update(kern, 0.1, prm[l])
+        for k in ("dA", "dAKHA", "dK", "dS", "HdA"):
+            assert rel_err(m[k], c.mat(k)) < 1e-11, (k, rel_err(m[k], c.mat(k)))
+        assert m["iters"][0] == c.dare_iters and list(m["iters"][1:]) == list(c.dlyap_iters)[:2 * J + 1]
+
+
+@pytest.mark.parametrize("kern", STACKED)
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("L,T,nanf", [(3, 1, 0.0), (5, 64, 0.0), (4, 65, 0.0), (7, 130, 0.05), (2, 700, 0.0)])
+def test_stacked_gradstream_vs_oracle(env, kern, dtype, L, T, nanf):
+    J = int(kern[-1])
+    rng = np.random.default_rng(9 * L + T + J)
+    prm = synth_params_stacked(L, J, rng)
+    bank = env["streams"].LatentBank(0.1, prm, kernel=kern)
+    d, P = bank.d, bank.P
+    Ty = synth(L, T, rng, nanf)
+    x0 = 0.2 * rng.standard_normal((L, d)); dx0 = 0.05 * rng.standard_normal((L, P, d))
+    o = env["cref"].grad_stream(env["cref"].ihgp_array(kern, 0.1, prm), Ty, x0=x0, dx0=dx0)
+    r = bank.grad(to_dev(Ty, dtype), T=T, x=torch.from_numpy(x0).to(dtype).cuda(), dx=torch.from_numpy(dx0).to(dtype).cuda(), want_yhat=True)
+    torch.cuda.synchronize()
+    tol = 1e-9 if dtype == torch.float64 else FP32_TOL
+    tame = np.nan_to_num(np.abs(o["yhat"]), nan=0.0).max(axis=1) < 1e6
+    if not tame.any():
+        return
+    def err(a, b, floor=0.0):
+        return float(np.abs(a[tame] - b[tame]).max() / max(np.abs(b[tame]).max(), floor, 1e-300))
+    assert err(r["yhat"][:, :T].cpu().numpy(), o["yhat"]) < tol
+    assert err(r["x"].cpu().numpy(), o["x"]) < tol and err(r["dx"].cpu().numpy(), o["dx"], 1e-6) < tol * 10
+    assert err(r["nll"].cpu().numpy(), o["nll_per_latent"]) < tol * 10
+    assert err(r["grad"].cpu().numpy(), o["grad"], 1e-6) < tol * 10

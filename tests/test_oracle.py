@@ -196,6 +196,13 @@ def test_stacked_golden_and_structure(kern):
             assert rel_err(A[j * db:(j + 1) * db, j * db:(j + 1) * db], single.A) < 1e-13
             A[j * db:(j + 1) * db, j * db:(j + 1) * db] = 0
         assert np.abs(A).max() < 1e-16
+    for l in range(len(igps)):                                     # sensitivities and DLyap iteration counts
+        for k in ("dA", "dAKHA", "dK", "dS", "HdA"):
+            assert rel_err(igps[l].mat(k), g[k][l]) < 1e-10
+        assert list(igps[l].dlyap_iters)[:2 * J + 1] == list(g["dlyap_iters"][l])
+    r = cref.grad_stream(igps, g["grad_Ty"], x0=g["grad_x0"], dx0=g["grad_dx0"])
+    assert rel_err(r["yhat"], g["grad_yhat"]) < 1e-10 and rel_err(r["dx"], g["grad_dxT"]) < 1e-9
+    assert rel_err(r["grad"], g["grad_grad"]) < 1e-9 and rel_err(r["nll_per_latent"], g["grad_nll"]) < 1e-10
     for tag in ("dense", "nan5"):
         r = cref.filter_stream(igps, g[f"{tag}_Ty"], x0=g[f"{tag}_x0"], nthreads=2)
         assert rel_err(r["yhat"], g[f"{tag}_yhat"]) < 1e-10 and rel_err(r["x"], g[f"{tag}_xT"]) < 1e-10
