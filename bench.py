@@ -232,14 +232,15 @@ def main():
         Ty_slabs = [Ty[:, k * slab:min(T, (k + 1) * slab)].contiguous() for k in range(nslab)]
         yhat_slabs = [torch.empty_like(t) for t in Ty_slabs]
 
+    x_zero = torch.zeros_like(x)               # every pass starts from this state; it is never written
+
     def one_pass(reduce=allreduce_nll):
-        x.zero_()
         if nslab == 1:
-            bank.filter(Ty, T=T, x=x, yhat=yhat, nll=nll)
+            bank.filter(Ty, T=T, x=x, x_start=x_zero, yhat=yhat, nll=nll)
             return reduce(nll)                 # the path's only exchange: 8 bytes, SUM
         nll_acc.zero_()
         for k in range(nslab):                 # slabs carry the state x from one launch to the next
-            bank.filter(Ty_slabs[k], T=Ty_slabs[k].shape[1], x=x, yhat=yhat_slabs[k], nll=nll)
+            bank.filter(Ty_slabs[k], T=Ty_slabs[k].shape[1], x=x, x_start=x_zero if k == 0 else None, yhat=yhat_slabs[k], nll=nll)
             nll_acc.add_(nll)
         return reduce(nll_acc)
 

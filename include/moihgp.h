@@ -148,6 +148,11 @@ int         moihgp_get_latent(moihgp_gp* gp, size_t l, double* A, double* K, dou
  * Returns 0 on success, nonzero on invalid arguments (see moihgp_last_error()).            */
 int moihgp_filter_stream(moihgp_gp* gp, int dtype, const void* Ty, size_t T, size_t ld,
                          void* x, void* yhat, double* nll, void* stream);
+/* The same sweep with the start state read from x_in and the end state written to x (x_in == x is the form above).  A caller
+ * that sweeps again and again from one fixed state -- the learners restart every objective evaluation from the same x
+ * (moihgp_regression.h:38, moihgp_online.h:57) -- keeps that state in a buffer of its own and saves a reset per sweep. */
+int moihgp_filter_stream_io(moihgp_gp* gp, int dtype, const void* Ty, size_t T, size_t ld,
+                            const void* x_in, void* x, void* yhat, double* nll, void* stream);
 
 /* As above plus the hyper-parameter sensitivities (ihgp.h:54) and the per-latent NLL gradient
  * (ihgp.h:216-220), summed over ticks:

@@ -114,7 +114,7 @@ void launch_ihgp_update(int kernel, int d, double dt, const double* params_dev, 
 void launch_stack_update(int kernel, double dt, const double* params_dev, size_t n, double* cb64, float* cb32,
                          double* cbd64 /* [n] sensitivity blocks XD, or NULL to skip them */, int* n_unstable, hipStream_t stream);
 int launch_filter_stream_x(int kernel, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* cb64, const float* cb32,
-                           void* x, void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
+                           const void* xin, void* x, void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
                            double* scratch = nullptr /* [scratch_len] per-slice NLL partials of the time split */, size_t scratch_len = 0,
                            int force_slices = 0 /* tuning / test hook: 1 = no split, n > 1 = n slices */);
 
@@ -124,7 +124,8 @@ int launch_grad_stream_x(int kernel, int dtype, const void* Ty, size_t T, size_t
 
 // recursion.hip: batched sweeps over series-major streams.
 int launch_filter_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, size_t L,
-                         const double* cb64, const float* cb32, void* x, void* yhat, double* nll,
+                         const double* cb64, const float* cb32, const void* xin /* start state */, void* x /* end state, may alias xin */,
+                         void* yhat, double* nll,
                          hipStream_t stream, int variant = 0, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
                          int nsplit = 1, size_t Tslice = 0, int n_unstable = 0 /* latents with SCANOK == 0 in this dtype's blocks */);
 // Time split for small L (slices of one latent = wavefronts of one workgroup): nsplit == 1 means none.

@@ -384,8 +384,8 @@ constexpr int kMaxSplit = 8;    // slices per latent = waves per workgroup in sp
 template <typename T, int D, int CK, bool WRITE, bool NLL, int MINW, bool SPLIT, int DBG = 0>
 __global__ void __launch_bounds__(SPLIT ? 64 * kMaxSplit : 64 * kWavesPerBlock, SPLIT ? 1 : MINW)
 filter_scan_kernel(const T* __restrict__ Ty, size_t Ttot, size_t ld, size_t L, const T* __restrict__ cbT,
-                   const double* __restrict__ cb64, T* __restrict__ x, T* __restrict__ yhat, double* __restrict__ nll,
-                   int nsplit, size_t Tslice) {
+                   const double* __restrict__ cb64, const T* xin0 /* start state */, T* x /* end state; may be the same buffer */,
+                   T* __restrict__ yhat, double* __restrict__ nll, int nsplit, size_t Tslice) {
     using V = typename VecOf<T>::type;
     using Lay = CB<D>;
     constexpr int EPV = 16 / sizeof(T);
@@ -456,7 +456,7 @@ filter_scan_kernel(const T* __restrict__ Ty, size_t Ttot, size_t ld, size_t L, c
         // ---- fold the slices before this one into its start state (uniform, <= 7 small mat-vecs) ----
         double xc[D];
 #pragma unroll
-        for (int i = 0; i < D; i++) xc[i] = (double)x[l * D + i];
+        for (int i = 0; i < D; i++) xc[i] = (double)xin0[l * D + i];
         for (int s = 0; s < wave; s++) {
             double xn[D];
 #pragma unroll
@@ -475,7 +475,7 @@ filter_scan_kernel(const T* __restrict__ Ty, size_t Ttot, size_t ld, size_t L, c
         __syncthreads();       // everyone has read x[l] and the maps before anything is overwritten
     } else {
 #pragma unroll
-        for (int i = 0; i < D; i++) xin[i] = x[l * D + i];
+        for (int i = 0; i < D; i++) xin[i] = xin0[l * D + i];
     }
 
     // ---- the real sweep (split + state only: just the last slice needs it) -------------------------
@@ -523,7 +523,7 @@ filter_scan_kernel(const T* __restrict__ Ty, size_t Ttot, size_t ld, size_t L, c
 template <typename T, int D>
 __global__ void __launch_bounds__(64)
 filter_seq_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, const T* __restrict__ cbT, const double* __restrict__ cb64,
-                  T* __restrict__ x, T* __restrict__ yhat, double* __restrict__ nll) {
+                  const T* xin0, T* x, T* __restrict__ yhat, double* __restrict__ nll) {
     using V = typename VecOf<T>::type;
     using Lay = CB<D>;
     constexpr int EPV = 16 / sizeof(T);
@@ -533,7 +533,7 @@ filter_seq_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, co
     if (cb[Lay::SCANOK] != T(0)) return;
     T a[D * D], kk[D], xs[D];
     for (int i = 0; i < D * D; i++) a[i] = cb[Lay::A + i];
-    for (int i = 0; i < D; i++) { kk[i] = cb[Lay::K + i]; xs[i] = x[l * D + i]; }
+    for (int i = 0; i < D; i++) { kk[i] = cb[Lay::K + i]; xs[i] = xin0[l * D + i]; }
     double acc = 0.0, n = 0.0;
     const T* row = Ty + l * ld;
     for (size_t tb = 0; tb < Tlen; tb += EPV) {
@@ -562,7 +562,7 @@ filter_seq_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, co
 }
 
 template <typename T, int D, int CK, int MINW, bool SPLIT>
-int launch_filter_t(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, const double* cb64, void* x,
+int launch_filter_t(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, const double* cb64, const void* xin, void* x,
                     void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, int nsplit, size_t Tslice, int n_unstable) {
     dim3 block(SPLIT ? 64 * nsplit : 64 * kWavesPerBlock);
     dim3 grid(SPLIT ? (unsigned)L : (unsigned)((L + kWavesPerBlock - 1) / kWavesPerBlock));
@@ -570,19 +570,20 @@ int launch_filter_t(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* c
     const size_t smem = (SPLIT ? (size_t)nsplit * (tile + (D * D + D + 2) * sizeof(double)) : (size_t)kWavesPerBlock * tile) +
                         (size_t)(SPLIT ? nsplit : kWavesPerBlock) * 4 * D * D * sizeof(T);
     const T* ty = static_cast<const T*>(Ty);
+    const T* xi = static_cast<const T*>(xin);
     T* xs = static_cast<T*>(x);
     T* yh = static_cast<T*>(yhat);
     // hipExtLaunchKernelGGL attaches the (optional) events to the dispatch itself: kernel-exact timing
     if (yhat && nll)
-        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, true, true, MINW, SPLIT>), grid, block, smem, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xs, yh, nll, nsplit, Tslice);
+        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, true, true, MINW, SPLIT>), grid, block, smem, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nsplit, Tslice);
     else if (yhat)
-        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, true, false, MINW, SPLIT>), grid, block, smem, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xs, yh, nll, nsplit, Tslice);
+        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, true, false, MINW, SPLIT>), grid, block, smem, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nsplit, Tslice);
     else if (nll)
-        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, false, true, MINW, SPLIT>), grid, block, smem, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xs, yh, nll, nsplit, Tslice);
+        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, false, true, MINW, SPLIT>), grid, block, smem, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nsplit, Tslice);
     else
-        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, false, false, MINW, SPLIT>), grid, block, smem, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xs, yh, nll, nsplit, Tslice);
+        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, false, false, MINW, SPLIT>), grid, block, smem, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nsplit, Tslice);
     if (n_unstable > 0)
-        hipLaunchKernelGGL((filter_seq_kernel<T, D>), dim3((unsigned)((L + 63) / 64)), dim3(64), 0, stream, ty, Tlen, ld, L, cbT, cb64, xs, yh, nll);
+        hipLaunchKernelGGL((filter_seq_kernel<T, D>), dim3((unsigned)((L + 63) / 64)), dim3(64), 0, stream, ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_last_error("filter_scan_kernel launch: %s", hipGetErrorString(e)); return 2; }
     return 0;
@@ -606,14 +607,14 @@ void filter_split_plan(int dtype, size_t T, size_t L, int* nsplit, size_t* Tslic
 }
 
 int launch_filter_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* cb64,
-                         const float* cb32, void* x, void* yhat, double* nll, hipStream_t stream, int variant,
+                         const float* cb32, const void* xin, void* x, void* yhat, double* nll, hipStream_t stream, int variant,
                          hipEvent_t ev0, hipEvent_t ev1, int nsplit, size_t Tslice, int n_unstable) {
     if (L == 0) return 0;
     if (nsplit > kMaxSplit) { set_last_error("nsplit > %d", kMaxSplit); return 1; }
 #define MOIHGP_FILTER_CASE(TT, DD, CKK, MW, CB)                                                                                   \
     do {                                                                                                                          \
-        if (nsplit > 1) return launch_filter_t<TT, DD, CKK, 1, true>(Ty, T, ld, L, CB, cb64, x, yhat, nll, stream, ev0, ev1, nsplit, Tslice, n_unstable); \
-        return launch_filter_t<TT, DD, CKK, MW, false>(Ty, T, ld, L, CB, cb64, x, yhat, nll, stream, ev0, ev1, 1, T, n_unstable);             \
+        if (nsplit > 1) return launch_filter_t<TT, DD, CKK, 1, true>(Ty, T, ld, L, CB, cb64, xin, x, yhat, nll, stream, ev0, ev1, nsplit, Tslice, n_unstable); \
+        return launch_filter_t<TT, DD, CKK, MW, false>(Ty, T, ld, L, CB, cb64, xin, x, yhat, nll, stream, ev0, ev1, 1, T, n_unstable);             \
     } while (0)
     // register caps: fp32 <= 128 VGPRs (4 waves/SIMD: all 4096 wavefronts of a 4096-latent shard resident),
     // fp64 uncapped (188 VGPRs, 2 waves/SIMD: capping it to 168 spills and is 35 % slower)
@@ -626,15 +627,15 @@ int launch_filter_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, 
     if (variant == 2 || variant == 4 || variant == 6) {   // tuning probes: plain stores (2), nontemporal loads (4), both (6)
         dim3 block(64 * kWavesPerBlock), grid((unsigned)((L + kWavesPerBlock - 1) / kWavesPerBlock));
         const size_t sm = (size_t)kWavesPerBlock * (64 * 5 * 16 + 36 * 4);
-        if (variant == 2) hipExtLaunchKernelGGL((filter_scan_kernel<float, 3, kChunk32, true, true, 4, false, 2>), grid, block, sm, stream, ev0, ev1, 0, (const float*)Ty, T, ld, L, cb32, cb64, (float*)x, (float*)yhat, nll, 1, T);
-        else if (variant == 4) hipExtLaunchKernelGGL((filter_scan_kernel<float, 3, kChunk32, true, true, 4, false, 4>), grid, block, sm, stream, ev0, ev1, 0, (const float*)Ty, T, ld, L, cb32, cb64, (float*)x, (float*)yhat, nll, 1, T);
-        else hipExtLaunchKernelGGL((filter_scan_kernel<float, 3, kChunk32, true, true, 4, false, 6>), grid, block, sm, stream, ev0, ev1, 0, (const float*)Ty, T, ld, L, cb32, cb64, (float*)x, (float*)yhat, nll, 1, T);
+        if (variant == 2) hipExtLaunchKernelGGL((filter_scan_kernel<float, 3, kChunk32, true, true, 4, false, 2>), grid, block, sm, stream, ev0, ev1, 0, (const float*)Ty, T, ld, L, cb32, cb64, (const float*)xin, (float*)x, (float*)yhat, nll, 1, T);
+        else if (variant == 4) hipExtLaunchKernelGGL((filter_scan_kernel<float, 3, kChunk32, true, true, 4, false, 4>), grid, block, sm, stream, ev0, ev1, 0, (const float*)Ty, T, ld, L, cb32, cb64, (const float*)xin, (float*)x, (float*)yhat, nll, 1, T);
+        else hipExtLaunchKernelGGL((filter_scan_kernel<float, 3, kChunk32, true, true, 4, false, 6>), grid, block, sm, stream, ev0, ev1, 0, (const float*)Ty, T, ld, L, cb32, cb64, (const float*)xin, (float*)x, (float*)yhat, nll, 1, T);
         return 0;
     }
     if (variant == 9) {   // tuning probe (staging only)
         dim3 block(64 * kWavesPerBlock), grid((unsigned)((L + kWavesPerBlock - 1) / kWavesPerBlock));
         hipExtLaunchKernelGGL((filter_scan_kernel<float, 3, kChunk32, true, true, 1, false, 1>), grid, block, (size_t)kWavesPerBlock * (64 * 5 * 16 + 36 * 4), stream, ev0, ev1, 0,
-                              (const float*)Ty, T, ld, L, cb32, cb64, (float*)x, (float*)yhat, nll, 1, T);
+                              (const float*)Ty, T, ld, L, cb32, cb64, (const float*)xin, (float*)x, (float*)yhat, nll, 1, T);
         return 0;
     }
     if (variant == 1) MOIHGP_FILTER_CASE(float, 3, kChunk32, 1, cb32);

@@ -133,11 +133,12 @@ class LatentBank:
 
     def filter(self, Ty: torch.Tensor, T: Optional[int] = None, x: Optional[torch.Tensor] = None,
                want_yhat: bool = True, want_nll: bool = True, yhat: Optional[torch.Tensor] = None,
-               nll: Optional[torch.Tensor] = None, stream=None):
+               nll: Optional[torch.Tensor] = None, stream=None, x_start: Optional[torch.Tensor] = None):
         """One sweep of ihgp.h:81-93 (+ :204-209 on the pre-step state) over T ticks for every latent.
 
         Returns (yhat [L, ld] or None, x [L, d] final state, nll [L] float64 or None).  Asynchronous on
-        the current torch stream.  `x` (initial state) is updated IN PLACE if given."""
+        the current torch stream.  `x` (initial state) is updated IN PLACE if given.  With `x_start` the sweep starts from
+        that state instead (left untouched) and `x` only receives the final state: no reset between repeated sweeps."""
         T, ld = self._check_stream(Ty, T)
         if x is None:
             x = torch.zeros((self.L, self.d), dtype=Ty.dtype, device=Ty.device)
@@ -151,8 +152,11 @@ class LatentBank:
             raise ValueError("x must be a contiguous [L, d] tensor of the stream dtype")
         if want_nll and nll is None:
             nll = torch.empty((self.L,), dtype=torch.float64, device=Ty.device)
-        rc = self._lib.moihgp_filter_stream(
-            self._h, _DT[Ty.dtype], C.c_void_p(Ty.data_ptr()), T, ld, C.c_void_p(x.data_ptr()),
+        if x_start is not None and (x_start.dtype != Ty.dtype or not x_start.is_contiguous() or tuple(x_start.shape) != (self.L, self.d)):
+            raise ValueError("x_start must be a contiguous [L, d] tensor of the stream dtype")
+        rc = self._lib.moihgp_filter_stream_io(
+            self._h, _DT[Ty.dtype], C.c_void_p(Ty.data_ptr()), T, ld, C.c_void_p((x if x_start is None else x_start).data_ptr()),
+            C.c_void_p(x.data_ptr()),
             C.c_void_p(yhat.data_ptr()) if want_yhat else None,
             C.c_void_p(nll.data_ptr()) if want_nll else None, _stream_ptr(stream))
         _check(rc, self._lib)

@@ -871,3 +871,25 @@ def test_stacked_gradstream_vs_oracle(env, kern, dtype, L, T, nanf):
     assert err(r["x"].cpu().numpy(), o["x"]) < tol and err(r["dx"].cpu().numpy(), o["dx"], 1e-6) < tol * 10
     assert err(r["nll"].cpu().numpy(), o["nll_per_latent"]) < tol * 10
     assert err(r["grad"].cpu().numpy(), o["grad"], 1e-6) < tol * 10
+
+
+@pytest.mark.parametrize("kern", ["Matern52", "Matern52x2"])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_filter_separate_start_state(env, kern, dtype):
+    """moihgp_filter_stream_io: the sweep starts from x_start (left untouched) and writes the end state to x -- same results as
+    the in-place form, for many latents, few latents (time split) and repeated sweeps."""
+    stacked = "x" in kern
+    for L, T in ((1100, 1500), (7, 5000)):
+        rng = np.random.default_rng(L)
+        prm = synth_params_stacked(L, 2, rng) if stacked else synth_params(L, rng)
+        bank = env["streams"].LatentBank(0.1, prm, kernel=kern if stacked else KMAP[kern])
+        Tyd = to_dev(synth(L, T, rng), dtype)
+        x0 = torch.from_numpy(0.3 * rng.standard_normal((L, bank.d))).to(dtype).cuda()
+        y1, x1, n1 = bank.filter(Tyd, T=T, x=x0.clone())
+        keep = x0.clone()
+        xo = torch.full_like(x0, 7.0)
+        for _ in range(2):
+            y2, x2, n2 = bank.filter(Tyd, T=T, x=xo, x_start=x0)
+        torch.cuda.synchronize()
+        assert torch.equal(x0, keep) and x2.data_ptr() == xo.data_ptr()
+        assert torch.equal(x2, x1) and torch.equal(n2, n1) and torch.equal(y2[:, :T], y1[:, :T])
