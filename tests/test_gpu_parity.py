@@ -893,3 +893,23 @@ def test_filter_separate_start_state(env, kern, dtype):
         torch.cuda.synchronize()
         assert torch.equal(x0, keep) and x2.data_ptr() == xo.data_ptr()
         assert torch.equal(x2, x1) and torch.equal(n2, n1) and torch.equal(y2[:, :T], y1[:, :T])
+
+
+def test_handles_release_their_device_memory(env):
+    """gp32_del / moihgp_del free everything the handle allocated (device buffers, pinned staging, stream): creating and dropping
+    a few hundred objects of every kind leaves the free device memory where it was."""
+    import gc
+    def churn(n):
+        for i in range(n):
+            gp = env["MOIHGP"](0.1, 12, 5, kernel="Matern52ss")
+            gp.step(np.zeros((5, 3)), np.ones(12))
+            bank = env["streams"].LatentBank(0.1, [[1, 1, 1, 2, 0.1]] * 8, kernel="Matern52x2")
+            Ty = torch.zeros((8, 64), dtype=torch.float64, device="cuda")
+            bank.filter(Ty, T=64); bank.grad(Ty, T=64)
+            del gp, bank, Ty
+        gc.collect(); torch.cuda.synchronize(); torch.cuda.empty_cache()
+    churn(20)
+    free0, _ = torch.cuda.mem_get_info()
+    churn(200)
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 32 * 1024 * 1024, (free0, free1)
