@@ -150,9 +150,11 @@ int moihgp_filter_stream(moihgp_gp* gp, int dtype, const void* Ty, size_t T, siz
                          void* x, void* yhat, double* nll, void* stream);
 /* The same sweep with the start state read from x_in and the end state written to x (x_in == x is the form above).  A caller
  * that sweeps again and again from one fixed state -- the learners restart every objective evaluation from the same x
- * (moihgp_regression.h:38, moihgp_online.h:57) -- keeps that state in a buffer of its own and saves a reset per sweep. */
+ * (moihgp_regression.h:38, moihgp_online.h:57) -- keeps that state in a buffer of its own and saves a reset per sweep.
+ * nll_total (DEVICE double, may be NULL; needs nll): the sum over the latents of nll[], the scalar the optimiser consumes
+ * (moihgp.h:684), added in a fixed order by a one-wavefront kernel queued right behind the sweep. */
 int moihgp_filter_stream_io(moihgp_gp* gp, int dtype, const void* Ty, size_t T, size_t ld,
-                            const void* x_in, void* x, void* yhat, double* nll, void* stream);
+                            const void* x_in, void* x, void* yhat, double* nll, double* nll_total, void* stream);
 
 /* As above plus the hyper-parameter sensitivities (ihgp.h:54) and the per-latent NLL gradient
  * (ihgp.h:216-220), summed over ticks:

@@ -83,7 +83,7 @@ def load_library():
     lib.moihgp_filter_stream.restype = C.c_int
     lib.moihgp_filter_stream.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.moihgp_filter_stream_io.restype = C.c_int
-    lib.moihgp_filter_stream_io.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.moihgp_filter_stream_io.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.moihgp_grad_stream.restype = C.c_int
     lib.moihgp_grad_stream.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.moihgp_project_stream.restype = C.c_int

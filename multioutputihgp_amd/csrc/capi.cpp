@@ -553,13 +553,15 @@ static int check_stream_args(moihgp_gp* gp, int dtype, const void* Ty, size_t T,
 }
 
 int moihgp_filter_stream(moihgp_gp* gp, int dtype, const void* Ty, size_t T, size_t ld, void* x, void* yhat, double* nll, void* stream) {
-    return moihgp_filter_stream_io(gp, dtype, Ty, T, ld, x, x, yhat, nll, stream);
+    return moihgp_filter_stream_io(gp, dtype, Ty, T, ld, x, x, yhat, nll, nullptr, stream);
 }
 
 int moihgp_filter_stream_io(moihgp_gp* gp, int dtype, const void* Ty, size_t T, size_t ld, const void* x_in, void* x, void* yhat, double* nll,
-                            void* stream) {
+                            double* nll_total, void* stream) {
     if (int rc = check_stream_args(gp, dtype, Ty, T, ld, x)) return rc;
     if (!x_in) { set_last_error("null start state"); return 1; }
+    if (nll_total && !nll) { set_last_error("nll_total needs the per-latent nll buffer"); return 1; }
+    if (nll_total && T == 0) MOIHGP_HIP_FATAL(hipMemsetAsync(nll_total, 0, sizeof(double), (hipStream_t)stream));
     if (yhat && ((uintptr_t)yhat & 15) != 0) { set_last_error("yhat base must be 16-byte aligned"); return 1; }
     const char* ve = std::getenv("MOIHGP_FILTER_VARIANT");   // tuning hook: kernel tiling variant
     const int variant = ve ? std::atoi(ve) : 0;
@@ -573,8 +575,10 @@ int moihgp_filter_stream_io(moihgp_gp* gp, int dtype, const void* Ty, size_t T, 
         const size_t slen = gp->L < 1024 ? gp->L * 16 : 0;              // per-slice NLL partials of the time split (few latents only)
         if (slen && !gp->dxscratch) gp->dxscratch = dev_alloc<double>(slen);
         const char* fs = std::getenv("MOIHGP_FILTER_SPLIT");            // tuning / test hook, as for the reference models: 1 = off, n = slices
-        return launch_filter_stream_x(gp->kernel, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cb32, x_in, x, yhat, nll, (hipStream_t)stream, e0, e1,
-                                      gp->dxscratch, slen, fs ? std::atoi(fs) : 0);
+        int rc = launch_filter_stream_x(gp->kernel, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cb32, x_in, x, yhat, nll, (hipStream_t)stream, e0, e1,
+                                        gp->dxscratch, slen, fs ? std::atoi(fs) : 0);
+        if (rc == 0 && nll_total) launch_nll_total(nll, gp->L, nll_total, (hipStream_t)stream);
+        return rc;
     }
     // time split across the wavefronts of a workgroup when there are too few latents to fill the chip
     int nsplit = 1; size_t Tslice = T;
@@ -590,7 +594,7 @@ int moihgp_filter_stream_io(moihgp_gp* gp, int dtype, const void* Ty, size_t T, 
         }
     }
     return launch_filter_stream(gp->d, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cb32, x_in, x, yhat, nll, (hipStream_t)stream, variant, e0, e1,
-                                nsplit, Tslice, gp->n_unstable[dtype == MOIHGP_F64 ? 0 : 1]);
+                                nsplit, Tslice, gp->n_unstable[dtype == MOIHGP_F64 ? 0 : 1], nll_total);
 }
 
 int moihgp_profile_enable(moihgp_gp* gp, int max_launches) {

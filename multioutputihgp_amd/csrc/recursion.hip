@@ -517,6 +517,26 @@ filter_scan_kernel(const T* __restrict__ Ty, size_t Ttot, size_t ld, size_t L, c
     }
 }
 
+// The scalar the optimiser consumes (moihgp.h:684 `loss += ...`): sum of nll[] in a fixed order (thread-strided, a butterfly per
+// wavefront, then the 16 wavefront sums in order), one workgroup, launched right behind the sweep.  (Fusing it into the sweep as a last-arrival reduction was tried: the 4096
+// device-scope atomics on one counter, and any agent-scope fence -- a whole-L2 write-back per wavefront, since the XCDs do not
+// share an L2 -- cost far more than this launch: 136-205 us against 60.)
+__global__ void __launch_bounds__(1024) nll_total_kernel(const double* __restrict__ nll, size_t L, double* __restrict__ total) {
+    __shared__ double red[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double s = 0.0;
+    for (size_t i = tid; i < L; i += 1024) s += nll[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 16; w++) t += red[w];
+        *total = t;
+    }
+}
+
 // Exact sequential filter for the latents flagged unstable (SCANOK == 0): one lane per latent, tick by tick in innovation
 // form (identical in meaning to ihgp.h:81-93 / :204-209, missing ticks included), stream fetched in 16-byte vectors.
 // Launched only when IHGP::update reported such latents; every other lane exits at once.
@@ -563,7 +583,8 @@ filter_seq_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, co
 
 template <typename T, int D, int CK, int MINW, bool SPLIT>
 int launch_filter_t(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, const double* cb64, const void* xin, void* x,
-                    void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, int nsplit, size_t Tslice, int n_unstable) {
+                    void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, int nsplit, size_t Tslice, int n_unstable,
+                    double* total) {
     dim3 block(SPLIT ? 64 * nsplit : 64 * kWavesPerBlock);
     dim3 grid(SPLIT ? (unsigned)L : (unsigned)((L + kWavesPerBlock - 1) / kWavesPerBlock));
     constexpr size_t tile = 64 * (CK / (16 / sizeof(T)) + 1) * 16;                    // padded LDS tile per wave
@@ -584,12 +605,17 @@ int launch_filter_t(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* c
         hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, false, false, MINW, SPLIT>), grid, block, smem, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nsplit, Tslice);
     if (n_unstable > 0)
         hipLaunchKernelGGL((filter_seq_kernel<T, D>), dim3((unsigned)((L + 63) / 64)), dim3(64), 0, stream, ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll);
+    if (total && nll) hipLaunchKernelGGL(nll_total_kernel, dim3(1), dim3(1024), 0, stream, nll, L, total);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_last_error("filter_scan_kernel launch: %s", hipGetErrorString(e)); return 2; }
     return 0;
 }
 
 }  // namespace
+
+void launch_nll_total(const double* nll, size_t L, double* total, hipStream_t stream) {
+    hipLaunchKernelGGL(nll_total_kernel, dim3(1), dim3(1024), 0, stream, nll, L, total);
+}
 
 // Slices per latent for the time split: enough wavefronts to occupy the chip when L is small, each slice a whole
 // number of segments so that only a latent's last slice is ragged; at most kMaxSplit slices (one workgroup).
@@ -608,13 +634,13 @@ void filter_split_plan(int dtype, size_t T, size_t L, int* nsplit, size_t* Tslic
 
 int launch_filter_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* cb64,
                          const float* cb32, const void* xin, void* x, void* yhat, double* nll, hipStream_t stream, int variant,
-                         hipEvent_t ev0, hipEvent_t ev1, int nsplit, size_t Tslice, int n_unstable) {
+                         hipEvent_t ev0, hipEvent_t ev1, int nsplit, size_t Tslice, int n_unstable, double* total) {
     if (L == 0) return 0;
     if (nsplit > kMaxSplit) { set_last_error("nsplit > %d", kMaxSplit); return 1; }
 #define MOIHGP_FILTER_CASE(TT, DD, CKK, MW, CB)                                                                                   \
     do {                                                                                                                          \
-        if (nsplit > 1) return launch_filter_t<TT, DD, CKK, 1, true>(Ty, T, ld, L, CB, cb64, xin, x, yhat, nll, stream, ev0, ev1, nsplit, Tslice, n_unstable); \
-        return launch_filter_t<TT, DD, CKK, MW, false>(Ty, T, ld, L, CB, cb64, xin, x, yhat, nll, stream, ev0, ev1, 1, T, n_unstable);             \
+        if (nsplit > 1) return launch_filter_t<TT, DD, CKK, 1, true>(Ty, T, ld, L, CB, cb64, xin, x, yhat, nll, stream, ev0, ev1, nsplit, Tslice, n_unstable, total); \
+        return launch_filter_t<TT, DD, CKK, MW, false>(Ty, T, ld, L, CB, cb64, xin, x, yhat, nll, stream, ev0, ev1, 1, T, n_unstable, total);             \
     } while (0)
     // register caps: fp32 <= 128 VGPRs (4 waves/SIMD: all 4096 wavefronts of a 4096-latent shard resident),
     // fp64 uncapped (188 VGPRs, 2 waves/SIMD: capping it to 168 spills and is 35 % slower)

@@ -133,12 +133,14 @@ class LatentBank:
 
     def filter(self, Ty: torch.Tensor, T: Optional[int] = None, x: Optional[torch.Tensor] = None,
                want_yhat: bool = True, want_nll: bool = True, yhat: Optional[torch.Tensor] = None,
-               nll: Optional[torch.Tensor] = None, stream=None, x_start: Optional[torch.Tensor] = None):
+               nll: Optional[torch.Tensor] = None, stream=None, x_start: Optional[torch.Tensor] = None,
+               nll_total: Optional[torch.Tensor] = None):
         """One sweep of ihgp.h:81-93 (+ :204-209 on the pre-step state) over T ticks for every latent.
 
         Returns (yhat [L, ld] or None, x [L, d] final state, nll [L] float64 or None).  Asynchronous on
         the current torch stream.  `x` (initial state) is updated IN PLACE if given.  With `x_start` the sweep starts from
-        that state instead (left untouched) and `x` only receives the final state: no reset between repeated sweeps."""
+        that state instead (left untouched) and `x` only receives the final state: no reset between repeated sweeps.
+        `nll_total` (a 1-element float64 CUDA tensor) receives the sum of the per-latent NLLs (one-wavefront kernel queued behind the sweep)."""
         T, ld = self._check_stream(Ty, T)
         if x is None:
             x = torch.zeros((self.L, self.d), dtype=Ty.dtype, device=Ty.device)
@@ -158,7 +160,8 @@ class LatentBank:
             self._h, _DT[Ty.dtype], C.c_void_p(Ty.data_ptr()), T, ld, C.c_void_p((x if x_start is None else x_start).data_ptr()),
             C.c_void_p(x.data_ptr()),
             C.c_void_p(yhat.data_ptr()) if want_yhat else None,
-            C.c_void_p(nll.data_ptr()) if want_nll else None, _stream_ptr(stream))
+            C.c_void_p(nll.data_ptr()) if want_nll else None,
+            C.c_void_p(nll_total.data_ptr()) if (nll_total is not None and want_nll) else None, _stream_ptr(stream))
         _check(rc, self._lib)
         return (yhat if want_yhat else None), x, (nll if want_nll else None)
 

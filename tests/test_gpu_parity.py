@@ -913,3 +913,22 @@ def test_handles_release_their_device_memory(env):
     churn(200)
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 32 * 1024 * 1024, (free0, free1)
+
+
+@pytest.mark.parametrize("kern,L,T", [("Matern52", 4096, 3000), ("Matern52", 1500, 700), ("Matern52", 37, 5000), ("Matern32", 1025, 100), ("Matern52x2", 1100, 2100), ("Matern52x2", 9, 4100)])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_nll_total_from_the_sweep(env, kern, L, T, dtype):
+    """moihgp_filter_stream_io's nll_total: the sum of the per-latent NLLs left on the device by a one-wavefront kernel queued
+    behind the sweep (every path: many / few latents, reference and stacked models), repeated launches."""
+    stacked = "x" in kern
+    rng = np.random.default_rng(L + T)
+    prm = synth_params_stacked(L, 2, rng) if stacked else synth_params(L, rng)
+    bank = env["streams"].LatentBank(0.1, prm, kernel=kern if stacked else KMAP[kern])
+    Tyd = to_dev(synth(L, T, rng), dtype)
+    tot = torch.full((1,), -1.0, dtype=torch.float64, device="cuda")
+    for rep in range(3):
+        _, _, nll = bank.filter(Tyd, T=T, nll_total=tot)
+        torch.cuda.synchronize()
+        ref = nll.sum().item()
+        assert abs(tot.item() - ref) <= 1e-12 * abs(ref), (rep, tot.item(), ref)
+        tot.fill_(-1.0)
