@@ -35,59 +35,6 @@ void set_last_error(const char* fmt, ...) {
     std::abort();
 }
 
-// ---- polar factor  svdU * svdV^T  (moihgp.h:438-446) by one-sided Jacobi rotations ---------------
-// Columns of W = Uparam are rotated pairwise until mutually orthogonal (W = Uparam * V); then
-// polar = W * diag(1/|w_j|) * V^T.  Unique for full column rank, so any convergent SVD gives the
-// same matrix as Eigen's BDCSVD/JacobiSVD up to rounding.
-static bool polar_factor(size_t M, size_t L, const double* Ain, double* out) {
-    if (M < L || L == 0) return false;
-    std::vector<double> W(Ain, Ain + M * L), V(L * L, 0.0);
-    for (size_t i = 0; i < L; i++) V[i * L + i] = 1.0;
-    const double eps = 2.220446049250313e-16;
-    for (int sweep = 0; sweep < 80; sweep++) {
-        bool rotated = false;
-        for (size_t p = 0; p + 1 < L; p++) {
-            for (size_t q = p + 1; q < L; q++) {
-                double a = 0, b = 0, c = 0;
-                for (size_t i = 0; i < M; i++) {
-                    const double wp = W[i * L + p], wq = W[i * L + q];
-                    a += wp * wp; b += wq * wq; c += wp * wq;
-                }
-                if (c == 0.0 || std::fabs(c) <= eps * std::sqrt(a * b)) continue;
-                rotated = true;
-                const double zeta = (b - a) / (2.0 * c);
-                const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
-                const double cs = 1.0 / std::sqrt(1.0 + t * t), sn = cs * t;
-                for (size_t i = 0; i < M; i++) {
-                    const double wp = W[i * L + p], wq = W[i * L + q];
-                    W[i * L + p] = cs * wp - sn * wq;
-                    W[i * L + q] = sn * wp + cs * wq;
-                }
-                for (size_t i = 0; i < L; i++) {
-                    const double vp = V[i * L + p], vq = V[i * L + q];
-                    V[i * L + p] = cs * vp - sn * vq;
-                    V[i * L + q] = sn * vp + cs * vq;
-                }
-            }
-        }
-        if (!rotated) break;
-    }
-    for (size_t j = 0; j < L; j++) {
-        double s = 0;
-        for (size_t i = 0; i < M; i++) s += W[i * L + j] * W[i * L + j];
-        s = std::sqrt(s);
-        if (!(s > 0.0)) return false;
-        for (size_t i = 0; i < M; i++) W[i * L + j] /= s;
-    }
-    for (size_t i = 0; i < M; i++)
-        for (size_t j = 0; j < L; j++) {
-            double s = 0;
-            for (size_t k = 0; k < L; k++) s += W[i * L + k] * V[j * L + k];
-            out[i * L + j] = s;
-        }
-    return true;
-}
-
 template <typename T>
 static T* dev_alloc(size_t n) {
     void* p = nullptr;
@@ -130,6 +77,7 @@ struct moihgp_gp {
     unsigned long long* hflag = nullptr;                        // mapped completion word of the fused small-model step
     unsigned long long seq = 0;
     bool fused_ok = false;
+    bool polar_pending = false;                                 // a small-matrix polar factor whose verdict has not been read yet
     std::vector<void*> pinned; // caller buffers page-locked through moihgp_pin_host_buffer
     // window objective (moihgp_window_set / moihgp_window_eval)
     WindowBufs win{};
@@ -192,7 +140,7 @@ static void draw_U(moihgp_gp* g, unsigned long long seed, bool use_seed) {
     std::vector<double> I(g->M * g->L, 0.0);
     for (size_t r = 0; r < g->M; r++)
         for (size_t c = 0; c < g->L; c++) I[r * g->L + c] = (r == c ? 1.0 : 0.0) + distr(gen);
-    if (g->dU) compute_polar_fwd(g, I.data()); else polar_factor(g->M, g->L, I.data(), g->U.data());
+    compute_polar_fwd(g, I.data());
 }
 
 static moihgp_gp* gp_create(int kernel, double dt, size_t M, size_t L, bool latents_only, const double* params_LP) {
@@ -241,6 +189,8 @@ static moihgp_gp* gp_create(int kernel, double dt, size_t M, size_t L, bool late
         g->S.assign(L, 1.0);                                             // moihgp.h:126
         g->sigma = 1e-2;                                                 // moihgp.h:127
         g->dU = dev_alloc<double>(M * L);
+        MOIHGP_HIP_FATAL(hipHostMalloc((void**)&g->hflag, 64, hipHostMallocMapped));   // [0] completion word of the fused kernels, [1] polar verdict
+        std::memset(g->hflag, 0, 64);
         draw_U(g, 0, false);
         g->dS = dev_alloc<double>(L);
         g->dsqrtS = dev_alloc<double>(L);
@@ -252,8 +202,6 @@ static moihgp_gp* gp_create(int kernel, double dt, size_t M, size_t L, bool late
             g->dy = g->dx + L * g->d;
             g->ddx = g->dy + M;
             MOIHGP_HIP_FATAL(hipHostMalloc((void**)&g->hin, sizeof(double) * nin, hipHostMallocMapped));
-            MOIHGP_HIP_FATAL(hipHostMalloc((void**)&g->hflag, 64, hipHostMallocMapped));
-            *g->hflag = 0;
             const char* fe = std::getenv("MOIHGP_TICK_FUSED");            // 0: always take the multi-kernel path
             g->fused_ok = fused_step_fits(M, L) && !(fe && fe[0] == '0');
             MOIHGP_HIP_FATAL(hipHostMalloc((void**)&g->hout, sizeof(double) * (nin + 8), hipHostMallocMapped));
@@ -370,18 +318,28 @@ static double do_lik(moihgp_gp* g, const double* x, const double* y, const doubl
     return *o_loss;
 }
 
-// U = polar(Uparam) (moihgp.h:433-447).  Newton-Schulz on the device (polar.hip) except for tiny matrices (M L^2 <= 2e4,
-// e.g. the 8x4 demo of example.py), where the host Jacobi routine above costs microseconds against a dozen launches.  MOIHGP_POLAR=device|host forces one.
+// U = polar(Uparam) (moihgp.h:433-447), always on the device: Newton-Schulz on the MFMA GEMMs (polar.hip), or, for small
+// matrices (the 8 x 4 demo of example.py, a 64 x 16 mixing), the same iteration as a single workgroup in LDS -- one launch.
+// MOIHGP_POLAR=gemm forces the multi-kernel path.  The host mirror of U is refreshed lazily (getParams).
 static bool compute_polar(moihgp_gp* g, const double* Uparam);
 static bool compute_polar_fwd(moihgp_gp* g, const double* Uparam) { return compute_polar(g, Uparam); }
 static bool compute_polar(moihgp_gp* g, const double* Uparam) {
     const size_t M = g->M, L = g->L;
-    bool on_device = (double)M * (double)L * (double)L > 2.0e4;   // measured: 256x256 host Jacobi 384 ms vs 1024x1024 device 3.7 ms
-    if (const char* e = std::getenv("MOIHGP_POLAR")) on_device = (e[0] == 'd');
-    if (!on_device) { g->U_host_stale = false; return polar_factor(M, L, Uparam, g->U.data()); }
-    if (!g->dpolar) g->dpolar = dev_alloc<double>(M * L + 2 * L * L + 8 + 3 * L);
+    bool small = polar_small_fits(M, L);
+    if (const char* e = std::getenv("MOIHGP_POLAR")) { if (e[0] == 'g') small = false; }
     MOIHGP_HIP_FATAL(hipMemcpyAsync(g->dU, Uparam, sizeof(double) * M * L, hipMemcpyHostToDevice, g->stream));
-    const int its = polar_factor_device(g->dU, M, L, g->dpolar, g->stream);
+    int its = 0;
+    if (small) {
+        // asynchronous: the kernel leaves its verdict in mapped host memory (and NaN in U if the input is rank deficient);
+        // do_update reads it after the synchronisation that ends the update anyway
+        int* verdict = reinterpret_cast<int*>(g->hflag + 1);
+        *verdict = 0;
+        launch_polar_small(g->dU, M, L, verdict, g->stream);
+        g->polar_pending = true;
+    } else {
+        if (!g->dpolar) g->dpolar = dev_alloc<double>(M * L + 2 * L * L + 8 + 3 * L);
+        its = polar_factor_device(g->dU, M, L, g->dpolar, g->stream);
+    }
     if (its < 0) return false;
     g->U_host_stale = true;                      // 8*M*L bytes over PCIe only when somebody asks (getParams)
     return true;
@@ -399,7 +357,14 @@ static void do_update(moihgp_gp* g, const double* params) {          // moihgp.h
     g->sigma = params[sizeU + L];                                        // moihgp.h:449
     for (size_t i = 0; i < L * (size_t)g->P; i++) g->igp[i] = params[sizeU + L + 1 + i];   // moihgp.h:450-456
     upload_mixing(g);
-    run_ihgp_update(g);
+    run_ihgp_update(g);                                                  // ends with a stream synchronisation
+    if (g->polar_pending) {
+        g->polar_pending = false;
+        if (*reinterpret_cast<volatile int*>(g->hflag + 1) < 0) {
+            set_last_error("update: mixing matrix is rank deficient");
+            std::fprintf(stderr, "libmoihgp: %s\n", g_last_error);
+        }
+    }
 }
 
 static void do_get_params(moihgp_gp* g, double* params) {            // moihgp.h:721-738

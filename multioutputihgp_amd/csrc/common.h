@@ -180,6 +180,9 @@ int launch_matmul_nn(const double* X, size_t M, size_t L, const double* W, doubl
 // A_dev is overwritten with the factor; work needs M*L + 2*L*L + 8 + 3*L doubles.  Returns the iteration count, or
 // -1 if it did not converge (rank-deficient input).
 int polar_factor_device(double* A_dev, size_t M, size_t L, double* work, hipStream_t s);
+// small matrices: the same iteration as one workgroup in LDS (one launch); status_dev: steps taken or -1
+bool polar_small_fits(size_t M, size_t L);
+void launch_polar_small(double* A_dev, size_t M, size_t L, int* status_dev, hipStream_t s);
 
 // window.hip: the learners' windowed objective (moihgp_online.h:61-70) as one device pipeline.
 struct WindowBufs {

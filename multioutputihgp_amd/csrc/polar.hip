@@ -93,7 +93,104 @@ __global__ void ns_weight_kernel(const double* __restrict__ G, double* __restric
     W[idx] = (i == j ? 1.5 : 0.0) - 0.5 * G[idx];
 }
 
+// Small matrices (M L <= 4096, L <= 32: the 8 x 4 demo model, a 64 x 16 mixing ...): the same Newton-Schulz iteration as ONE
+// workgroup with everything in LDS -- the Gram matrix, the scale s^2 = min(||G||_inf, trace G), the weight 3/2 I - 1/2 G, the
+// update, the stopping test -- so that update() of a small model is a single launch instead of a dozen with host round trips.
+// status[0] = number of steps, or -1 if the iteration does not reach orthonormality (rank-deficient input).
+__global__ void __launch_bounds__(256) polar_small_kernel(double* __restrict__ A, int M, int L, int* __restrict__ status) {
+    extern __shared__ double sm[];
+    double* X = sm;                    // [M][L]
+    double* Xn = X + M * L;            // [M][L]
+    double* G = Xn + M * L;            // [L][L]
+    double* red = G + L * L;           // [256]
+    __shared__ double s_err, s_prev, s_scale;
+    __shared__ int s_done;
+    const int tid = threadIdx.x, ML = M * L, LL = L * L;
+    for (int e = tid; e < ML; e += 256) X[e] = A[e];
+    if (tid == 0) { s_prev = 1e300; s_done = -2; }
+    __syncthreads();
+    auto gram = [&]() {
+        for (int e = tid; e < LL; e += 256) {
+            const int i = e / L, j = e % L;
+            double acc = 0.0;
+            for (int m = 0; m < M; m++) acc += X[m * L + i] * X[m * L + j];
+            G[e] = acc;
+        }
+        __syncthreads();
+    };
+    auto block_max = [&](double v) {
+        red[tid] = v;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] = fmax(red[tid], red[tid + o]); __syncthreads(); }
+        const double r = red[0];
+        __syncthreads();
+        return r;
+    };
+    auto block_add = [&](double v) {
+        red[tid] = v;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+        const double r = red[0];
+        __syncthreads();
+        return r;
+    };
+    gram();
+    {   // scale: s^2 = min(max row sum of |G|, trace G) >= sigma_max^2
+        double rs = 0.0, tr = 0.0;
+        for (int i = tid; i < L; i += 256) {
+            double a = 0.0;
+            for (int j = 0; j < L; j++) a += fabs(G[i * L + j]);
+            rs = fmax(rs, a);
+            tr += G[i * L + i];
+        }
+        const double mx = block_max(rs), trace = block_add(tr);
+        const double s2 = fmin(mx, trace);
+        if (tid == 0) s_scale = (s2 > 0.0 && s2 == s2) ? 1.0 / sqrt(s2) : nan("");
+        __syncthreads();
+        const double sc = s_scale;
+        for (int e = tid; e < ML; e += 256) X[e] *= sc;
+        __syncthreads();
+    }
+    for (int it = 1; it <= 200; it++) {
+        gram();
+        double dev = 0.0;
+        for (int e = tid; e < LL; e += 256) dev = fmax(dev, fabs(G[e] - ((e / L) == (e % L) ? 1.0 : 0.0)));
+        bool bad = false;
+        for (int e = tid; e < LL; e += 256) bad = bad || (G[e] != G[e]);
+        const double err = block_max(bad ? 1e300 : dev);
+        if (tid == 0) {
+            if (!(err < 1e299)) s_done = -1;                                             // NaN somewhere
+            else if (err < 1e-14 || (err < 1e-11 && err >= 0.5 * s_prev)) s_done = it - 1;   // orthonormal to rounding
+            else if (it > 80 && err >= s_prev) s_done = -1;                              // stagnating: rank deficient
+            s_prev = err;
+        }
+        __syncthreads();
+        if (s_done != -2) break;
+        for (int e = tid; e < ML; e += 256) {                                            // X (3/2 I - 1/2 G)
+            const int m = e / L, j = e % L;
+            double acc = 0.0;
+            for (int k = 0; k < L; k++) acc += X[m * L + k] * ((k == j ? 1.5 : 0.0) - 0.5 * G[k * L + j]);
+            Xn[e] = acc;
+        }
+        __syncthreads();
+        for (int e = tid; e < ML; e += 256) X[e] = Xn[e];
+        __syncthreads();
+    }
+    const int res = s_done == -2 ? -1 : s_done;
+    for (int e = tid; e < ML; e += 256) A[e] = res < 0 ? nan("") : X[e];     // a rank-deficient input leaves NaN, as update() reports it
+    if (tid == 0) { __threadfence_system(); status[0] = res; }
+}
+
 }  // namespace
+
+bool polar_small_fits(size_t M, size_t L) { return M * L <= 4096 && L <= 32; }
+
+// A_dev (M x L, device) <- its polar factor, one launch; *status_dev (device int) receives the step count or -1
+void launch_polar_small(double* A_dev, size_t M, size_t L, int* status_dev, hipStream_t s) {
+    const size_t smem = (2 * M * L + L * L + 256) * sizeof(double);
+    hipLaunchKernelGGL(polar_small_kernel, dim3(1), dim3(256), smem, s, A_dev, (int)M, (int)L, status_dev);
+    MOIHGP_HIP_FATAL(hipGetLastError());
+}
 
 int polar_factor_device(double* X, size_t M, size_t L, double* work, hipStream_t s) {
     double* G = work;                 // L*L

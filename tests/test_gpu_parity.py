@@ -349,22 +349,33 @@ def test_time_split_matches_unsplit(env, dtype, L, T, nan, monkeypatch):
 
 
 # ------------------------------------------------------------------------------------------ A8: polar factor on the device
-@pytest.mark.parametrize("M,L,noise", [(8, 4, 0.3), (100, 70, 0.2), (300, 300, 0.05), (1024, 512, 0.02), (64, 64, 2.0)])
+@pytest.mark.parametrize("M,L,noise", [(8, 4, 0.3), (100, 70, 0.2), (300, 300, 0.05), (1024, 512, 0.02), (64, 64, 2.0),
+                                       (64, 16, 0.5), (128, 32, 0.2), (1000, 4, 1.0), (40, 20, 2.0), (5, 5, 0.4), (3, 1, 0.0)])
 def test_polar_factor_device_vs_svd(env, M, L, noise, monkeypatch):
-    """MOIHGP::update (moihgp.h:433-447) forms U = svdU svdV^T; the device path is Newton-Schulz on MFMA GEMMs."""
-    monkeypatch.setenv("MOIHGP_POLAR", "device")
+    """MOIHGP::update (moihgp.h:433-447) forms U = svdU svdV^T.  On the device it is Newton-Schulz: one workgroup in LDS for
+    small matrices (M L <= 4096, L <= 32), MFMA GEMMs otherwise (MOIHGP_POLAR=gemm forces those)."""
     rng = np.random.default_rng(M + L)
     gp = env["MOIHGP"](0.1, M, L, kernel="Matern32")
     A = np.eye(M, L) + noise * rng.standard_normal((M, L))
     params = np.concatenate([A.ravel(), rng.uniform(0.5, 2, L), [0.03], synth_params(L, rng).ravel()])
-    gp.update(params)
-    U = gp.params[:M * L].reshape(M, L)
     u, _, vt = np.linalg.svd(A, full_matrices=False)
-    assert rel_err(U, u @ vt) < 1e-11
-    assert np.max(np.abs(U.T @ U - np.eye(L))) < 1e-12
-    monkeypatch.setenv("MOIHGP_POLAR", "host")
-    gp.update(params)
-    assert rel_err(gp.params[:M * L].reshape(M, L), U) < 1e-11
+    for mode in ("", "gemm"):
+        if mode:
+            monkeypatch.setenv("MOIHGP_POLAR", mode)
+        gp.update(params)
+        U = gp.params[:M * L].reshape(M, L)
+        assert rel_err(U, u @ vt) < 1e-11, mode
+        assert np.max(np.abs(U.T @ U - np.eye(L))) < 1e-12
+
+
+def test_polar_factor_rank_deficient_input_is_reported(env, capfd):
+    gp = env["MOIHGP"](0.1, 6, 3, kernel="Matern32")
+    p = gp.params.copy()
+    A = np.ones((6, 3))                               # rank 1
+    p[:18] = A.ravel()
+    gp.update(p)
+    assert np.all(np.isnan(gp.params[:18]))
+    assert b"rank deficient" in env["lib"].moihgp_last_error()
 
 
 # ------------------------------------------------------------------------------------------ A2/A5 scan-structured gradient sweep
