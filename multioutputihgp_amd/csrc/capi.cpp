@@ -1,10 +1,9 @@
-// capi.cpp -- the C ABI of libmoihgp.so: the reference's 28 gp32_*/gp52_* symbols
+// capi.cpp -- the C ABI of libmoihgp.so: the reference's 26 gp32_*/gp52_* symbols
 // (reference moihgp/src/wrapper.cpp:31-624) plus the additive batched entries of include/moihgp.h.
 //
-// Host side = parameter bookkeeping + kernel orchestration only.  Every arithmetic step of the
-// reference path runs in a HIP kernel (stationary.hip, tick.hip, recursion.hip, oilmm.hip); the one
-// exception this round is the polar factor of the mixing matrix in update() (moihgp.h:433-447), a
-// once-per-update O(M L^2) host routine (SURVEY 8f N4 schedules its device form).
+// Host side = parameter bookkeeping + kernel orchestration only.  Every arithmetic step of the reference path runs in a HIP
+// kernel (stationary*.hip, tick.hip, recursion*.hip, grad*.hip, gemm_mfma.hip, polar.hip, window.hip), including the polar
+// factor of the mixing matrix in update() (moihgp.h:433-447); the host draws the constructor's random matrix and moves bytes.
 #include "../../include/moihgp.h"
 #include "common.h"
 
