@@ -194,11 +194,11 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
     double acc = 0.0;
     unsigned nobs = 0;
     const bool scan_ok = __builtin_amdgcn_readfirstlane((int)(c[Lay::SCANOK] != T(0))) != 0;
-    // Two register plans.  PF (everything but fp64 with 9+ states): the scan powers and the response table are streamed in at
+    // Two register plans.  PF (everything but fp64 with 12 states): the scan powers and the response table are streamed in at
     // the start of every segment (L2-resident, coalesced, issued ahead of the phases that use them), which leaves room to
     // fetch the NEXT segment of the stream into registers during the replay.  !PF: no registers to spare for that, so the four
     // scan powers stay resident for the whole sweep instead and the stream is fetched at the segment start.
-    constexpr bool PF = !(sizeof(T) == 8 && D > 8);
+    constexpr bool PF = !(sizeof(T) == 8 && D > 9);
     // (scan powers held in registers: one fewer in the split kernels of the resident plan, which carry the slice bookkeeping
     // on top and must not overflow into AGPRs -- see tools/check_dpp_hazard.py)
     constexpr int NSL = Lay::LS / 16, NSG = Lay::GN / 16, NRES = (!PF && SPLIT) ? 3 : 4;
