@@ -6,8 +6,8 @@
 //   * the per-latent matrices are WAVE-UNIFORM, so they are never held one scalar per lane.  The scan and response tables
 //     live in "slabs": one register holds 16 table entries, the same 16 in each of the wave's four 16-lane rows, and the
 //     FMA reads entry e as a DPP broadcast operand (v_fmac_f64_dpp / v_fmac_f32_dpp row_newbcast:e) -- a uniform operand
-//     at no instruction cost, without going through the scalar register file.  A 12 x 12 matrix is 9 such registers, so the
-//     six scan powers of a latent stay resident for the whole kernel (54 slabs) and the scan phase issues no load at all;
+//     at no instruction cost, without going through the scalar register file.  A 12 x 12 matrix is 9 such registers; the scan
+//     powers of a segment are fetched at its start (coalesced, L2-resident), so the scan phase itself issues no load;
 //   * a segment is 64 lanes x 32 ticks.  z_j = sum_k g_k y_k (chunk response, g streamed in per segment), then a 6-level
 //     Kogge-Stone scan x_j = M x_{j-1} + z_j with the uniform powers M^(1,2,4,8,16,32) (lane shifts by ds_bpermute), then
 //     every lane replays its 32 ticks from its start state in innovation form,  v = y - HA x;  x <- A x + K v
@@ -194,14 +194,14 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
     double acc = 0.0;
     unsigned nobs = 0;
     const bool scan_ok = __builtin_amdgcn_readfirstlane((int)(c[Lay::SCANOK] != T(0))) != 0;
-    // Two register plans.  PF (everything but fp64 with 12 states): the scan powers and the response table are streamed in at
-    // the start of every segment (L2-resident, coalesced, issued ahead of the phases that use them), which leaves room to
-    // fetch the NEXT segment of the stream into registers during the replay.  !PF: no registers to spare for that, so the four
-    // scan powers stay resident for the whole sweep instead and the stream is fetched at the segment start.
-    constexpr bool PF = !(sizeof(T) == 8 && D > 9);
-    // (scan powers held in registers: one fewer in the split kernels of the resident plan, which carry the slice bookkeeping
-    // on top and must not overflow into AGPRs -- see tools/check_dpp_hazard.py)
-    constexpr int NSL = Lay::LS / 16, NSG = Lay::GN / 16, NRES = (!PF && SPLIT) ? 3 : 4;
+    // The scan powers and the response table are streamed in at the start of every segment (L2-resident, coalesced, issued ahead
+    // of the phases that use them) rather than held for the whole sweep: that leaves registers to fetch the NEXT segment of the
+    // stream during the replay, so a wave does not sit waiting for HBM at a segment boundary.  fp64 with 12 states has room for
+    // three quarters of a segment only (half in the split kernels); the rest is fetched at the segment start.
+    constexpr int NPF = (sizeof(T) == 8 && D > 9) ? (kChunkX / (16 / (int)sizeof(T))) * (SPLIT ? 2 : 3) / 4 : kChunkX / (16 / (int)sizeof(T));   // prefetched vectors per lane
+    // (the register budget must not overflow into AGPRs: a reload placed in front of a DPP FMA is a hazard the compiler does not
+    // see -- tools/check_dpp_hazard.py checks the built code)
+    constexpr int NSL = Lay::LS / 16, NSG = Lay::GN / 16, NRES = 4;
     T ha = c[Lay::HA16 + (lane & 15)], kk = c[Lay::K16 + (lane & 15)];
     const int nlev = __builtin_amdgcn_readfirstlane((int)c[Lay::NLEV]);
     // the ticks this wave sweeps: [t_start, t_end), of which [t_begin, t_end) count (everything, unless SPLIT)
@@ -225,19 +225,12 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
         last = (t_end == Tlen);
     }
     T sp[NRES][NSL];
-    if (!PF) {
-#pragma unroll
-        for (int lv = 0; lv < NRES; lv++) load_slabs<T, NSL>(c + Lay::SP + lv * Lay::LS, lane, sp[lv]);
-    }
-
-    // The stream of the NEXT segment is fetched into registers while the current one is replayed (the replay needs few
-    // registers and no memory), so a wave never sits waiting for HBM at a segment boundary.
-    V pre[CK / EPV];
+    V pre[NPF];
     auto fetch = [&](size_t t0, int n) {
         int lo = lane;
         asm volatile("" : "+v"(lo));       // recompute the lane addresses here: hoisted out of the loop they would be 32 live registers
 #pragma unroll
-        for (int r = 0; r < CK / EPV; r++) {
+        for (int r = 0; r < NPF; r++) {
             const int e = (r * 64 + lane) * EPV;
             V v{};                                                   // always (re)defined: dead between its use and the next fetch
             // (uniform base + 32-bit lane offset: 64-bit per-lane addresses for all the loads would cost 32 registers)
@@ -245,7 +238,7 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
             pre[r] = v;
         }
     };
-    if (PF && t_end > t_start) fetch(t_start, (int)(t_end - t_start < (size_t)SEG ? t_end - t_start : (size_t)SEG));
+    if (t_end > t_start) fetch(t_start, (int)(t_end - t_start < (size_t)SEG ? t_end - t_start : (size_t)SEG));
 
     for (size_t t0 = t_start; t0 < t_end; t0 += SEG) {
         const int n = (int)(t_end - t0 < (size_t)SEG ? t_end - t0 : (size_t)SEG);
@@ -256,7 +249,7 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
         constexpr int NSG0 = NSG / 2, NSG1 = NSG - NSG0;           // two halves: the second is fetched while the first is used
         T g0[NSG0], g1[NSG1];
         load_slabs<T, NSG0>(cu + Lay::G, lane, g0);
-        if constexpr (PF) load_slabs<T, NSG1>(cu + Lay::G + NSG0 * 16, lane, g1);
+        load_slabs<T, NSG1>(cu + Lay::G + NSG0 * 16, lane, g1);
         T ablk[J * DB * DB];
 #pragma unroll
         for (int i = 0; i < J * DB * DB; i++) ablk[i] = cu[Lay::AB + i];
@@ -265,19 +258,15 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
         for (int r = 0; r < CK / EPV; r++) {
             const int e = (r * 64 + lane) * EPV;
             T vals[EPV];
-            if constexpr (PF) unpack<T>(pre[r], vals);
+            if (r < NPF) unpack<T>(pre[r < NPF ? r : 0], vals);
             else if (e < n) unpack<T>(nt_load(reinterpret_cast<const V*>(row + t0 + e)), vals);
 #pragma unroll
             for (int q = 0; q < EPV; q++) if (e + q >= n) vals[q] = T(0);        // beyond the stream: inert zeros
             *reinterpret_cast<V*>(tile + (e / CK) * STRIDE + (e % CK)) = pack<T>(vals);
         }
-        if constexpr (PF) __builtin_amdgcn_sched_barrier(0);         // (the prefetch registers are free from here on)
-        if constexpr (PF) {
+        __builtin_amdgcn_sched_barrier(0);                           // (the prefetch registers are free from here on)
 #pragma unroll
-            for (int lv = 0; lv < NRES; lv++) load_slabs<T, NSL>(cu + Lay::SP + lv * Lay::LS, lane, sp[lv]);   // (M^16, M^32: on demand below)
-        } else {
-            load_slabs<T, NSG1>(cu + Lay::G + NSG0 * 16, lane, g1);
-        }
+        for (int lv = 0; lv < NRES; lv++) load_slabs<T, NSL>(cu + Lay::SP + lv * Lay::LS, lane, sp[lv]);   // (M^16, M^32: on demand below)
         wave_lds_fence();
         // ---- chunk response z = sum_k g_k y_k, and the missing-data test ----
         T z[D];
@@ -298,12 +287,13 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
                 });
             });
             // keep the scheduler from hoisting every LDS read of the chunk to the top (that alone would be 64 registers)
-            if constexpr (PF && kv % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+            if constexpr (kv % 4 == 3) __builtin_amdgcn_sched_barrier(0);
         });
         const size_t left = t0 + SEG < t_end ? t_end - (t0 + SEG) : 0;
         const int nnext = (int)(left < (size_t)SEG ? left : (size_t)SEG);
         if (!scan_ok || __builtin_amdgcn_ballot_w64(bad) != 0) {
-            if constexpr (PF) { fetch(t0 + SEG, nnext); __builtin_amdgcn_sched_barrier(0); }
+            fetch(t0 + SEG, nnext);
+            __builtin_amdgcn_sched_barrier(0);
             sequential<T, D, WRITE, NLL>(c, tile, STRIDE, n, head, lane, xc, acc, nobs);
         } else {
             // ---- carry-in on lane 0, then the 64-lane Kogge-Stone scan with uniform powers ----
@@ -333,11 +323,9 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
 #pragma unroll
                 for (int i = 0; i < D; i++) { const T m = bperm<T>(addr, z[i]); xs[i] = lane >= 1 ? m : xc[i]; }
             }
-            if constexpr (PF) {
-                __builtin_amdgcn_sched_barrier(0);
-                fetch(t0 + SEG, nnext);                              // next segment's stream, in flight during the replay
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(t0 + SEG, nnext);                                  // next segment's stream, in flight during the replay
+            __builtin_amdgcn_sched_barrier(0);
             if (n == SEG && head == 0) replay<T, DB, J, WRITE, NLL, false>(ablk, ha, kk, tile_lane, lane * CK, n, 0, xs, acc, nobs);
             else replay<T, DB, J, WRITE, NLL, true>(ablk, ha, kk, tile_lane, lane * CK, n, head, xs, acc, nobs);
             const int jl = (n - 1) / CK;                             // the lane that holds the last tick
@@ -348,14 +336,13 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
         if (WRITE) {
             wave_lds_fence();
             int lo = lane;
-            if constexpr (PF) asm volatile("" : "+v"(lo));
+            asm volatile("" : "+v"(lo));
 #pragma unroll
             for (int r = 0; r < CK / EPV; r++) {
                 const int e = (r * 64 + lane) * EPV;
                 if (e < n && e >= head) {                            // (head is a multiple of CK: whole vectors)
                     const V out = *reinterpret_cast<const V*>(tile + (e / CK) * STRIDE + (e % CK));
-                    if constexpr (PF) nt_store(out, reinterpret_cast<V*>(orow + t0) + (r * 64 + lo));
-                    else nt_store(out, reinterpret_cast<V*>(orow + t0 + e));
+                    nt_store(out, reinterpret_cast<V*>(orow + t0) + (r * 64 + lo));
                 }
             }
         }
