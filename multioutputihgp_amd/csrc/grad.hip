@@ -20,6 +20,7 @@
 // 16-byte vectors) recomputes it.  The reference never feeds a NaN to IHGP through MOIHGP (SURVEY 8a notes).
 #include "kernels_common.h"
 #include <cstdlib>
+#include <type_traits>
 
 #ifndef MOIHGP_GRAD_SPREG
 #define MOIHGP_GRAD_SPREG 1
@@ -32,11 +33,29 @@ namespace moihgp {
 namespace {
 
 constexpr int P = kNumIgpParam;
+// Parameters whose dF is identically zero: magnitude and noise; only the lengthscale moves F (matern32ss.h:54-55,
+// matern52ss.h:61-63).  For those the reference itself stores dA = 0, HdA = 0 and dAKHA = -dK HA (ihgp.h:141-143, :189-193), so
+// dAKHA_p x + dK_p y = dK_p (y - HA x) = dK_p v: the scan kernel uses that form (12 instead of 21 multiply-adds per tick).
+__device__ constexpr bool kDFzero[P] = {true, false, true};
 
 template <typename T, int D>
 struct GradConst {
     T a[D * D], k[D], akha[D * D], dakha[P][D * D], dk[P][D], hda[P][D];
 };
+
+// The per-latent constants are wave-uniform and would all be scalar registers: 66 of them at d = 3, more than the scalar
+// file can hold next to the scan tables, and the overflow comes back as v_readlane / v_writelane traffic in the tick loop.
+// The sensitivity blocks are therefore pinned in vector registers (there is room), the mean's A, K, AKHA stay scalar.
+#ifndef MOIHGP_GRAD_PINV
+#define MOIHGP_GRAD_PINV 1
+#endif
+template <typename T>
+__device__ inline T pin_vgpr(T v) {
+#if MOIHGP_GRAD_PINV
+    asm("" : "+v"(v));
+#endif
+    return v;
+}
 
 template <typename T, int D>
 __device__ inline void load_grad_const(GradConst<T, D>& c, const T* cb) {
@@ -48,9 +67,9 @@ __device__ inline void load_grad_const(GradConst<T, D>& c, const T* cb) {
 #pragma unroll
     for (int p = 0; p < P; p++) {
 #pragma unroll
-        for (int i = 0; i < D * D; i++) c.dakha[p][i] = cb[Lay::DAKHA + p * D * D + i];
+        for (int i = 0; i < D * D; i++) c.dakha[p][i] = pin_vgpr(cb[Lay::DAKHA + p * D * D + i]);
 #pragma unroll
-        for (int i = 0; i < D; i++) { c.dk[p][i] = cb[Lay::DK + p * D + i]; c.hda[p][i] = cb[Lay::HDA + p * D + i]; }
+        for (int i = 0; i < D; i++) { c.dk[p][i] = pin_vgpr(cb[Lay::DK + p * D + i]); c.hda[p][i] = pin_vgpr(cb[Lay::HDA + p * D + i]); }
     }
 }
 
@@ -86,7 +105,8 @@ grad_scan_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, con
     using V = typename VecOf<T>::type;
     using Lay = CB<D>;
     constexpr int EPV = 16 / sizeof(T), VPL = CK / EPV, SEG = 64 * CK, NVP = 64 * (VPL + 1);
-    constexpr int NTAB = CK * D + 4 * D * D;                     // g table + scan powers, per wave, in LDS
+    constexpr int NTAB = 2 * CK * D + 4 * D * D;                 // g table + scan powers + HA AKHA^k rows, per wave, in LDS
+    constexpr int HP = CK * D + 4 * D * D;                       // offset of the HA AKHA^k rows
     static_assert(CK % EPV == 0, "CK must be a multiple of 16 bytes");
     __shared__ V lds_all[kWavesPerBlock][NVP];
     __shared__ T tab_all[kWavesPerBlock][NTAB];
@@ -130,6 +150,21 @@ grad_scan_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, con
 #pragma unroll
             for (int i = 0; i < D * D; i++) if (lane == i) tab[CK * D + lv * D * D + i] = (T)pw[i];
             matmul<double, D>(pw, pw, pw);
+        }
+        {   // hp_k = HA AKHA^k, k < CK: what a start sensitivity contributes to HA dx at tick k of its chunk
+            double h[D];
+#pragma unroll
+            for (int i = 0; i < D; i++) h[i] = c64[Lay::HA + i];
+#pragma unroll
+            for (int k = 0; k < CK; k++) {
+#pragma unroll
+                for (int i = 0; i < D; i++) if (lane == i) tab[HP + k * D + i] = (T)h[i];
+                double hn[D];
+#pragma unroll
+                for (int j = 0; j < D; j++) { double t = 0; for (int i = 0; i < D; i++) t = fma(h[i], ak[i * D + j], t); hn[j] = t; }
+#pragma unroll
+                for (int j = 0; j < D; j++) h[j] = hn[j];
+            }
         }
         // pj = M^(r+1), r = lane & 15, by binary powering on the bits of r
         double acc[D * D], sq[D * D];
@@ -178,9 +213,10 @@ grad_scan_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, con
     bool has_nan = false;
 
     const size_t nfull = Tlen / SEG, nseg = (Tlen + SEG - 1) / SEG;
-    for (size_t seg = 0; seg < nseg && !has_nan; seg++) {
+    // one segment; the ragged last one is its own instantiation so that full segments carry no masking
+    auto segment = [&](const size_t seg, auto tail_c) {
+        constexpr bool tail = decltype(tail_c)::value;
         const size_t tbase = seg * SEG, t0 = tbase + (size_t)lane * CK;
-        const bool tail = seg >= nfull;
         // ---- coalesced loads -> LDS -> chunk-per-lane registers (padding past Tlen reads as zero) --------
 #pragma unroll
         for (int i = 0; i < VPL; i++) {
@@ -219,7 +255,7 @@ grad_scan_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, con
         bool bad = false;
 #pragma unroll
         for (int i = 0; i < D; i++) bad |= (z[i] != z[i]);
-        if (__any(bad)) { has_nan = true; break; }                 // missing ticks: hand the latent to grad_seq_kernel
+        if (__any(bad)) { has_nan = true; return; }                // missing ticks: hand the latent to grad_seq_kernel
         {
             T x0[D];
 #pragma unroll
@@ -231,101 +267,101 @@ grad_scan_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, con
 #pragma unroll
         for (int i = 0; i < D; i++) xs[i] = wave_shr1(z[i], xin[i]);
 
-        // ---- (b) replay 1: true mean trajectory -> zero-state chunk response of every sensitivity -------------
-        T dz[P][D];
+        // ---- (b) the one replay: true mean trajectory, zero-state response dz_p of every sensitivity over the chunk, and the
+        //      gradient sums in split form.  With dx_p(k) = dz_p(k) + AKHA^k dx_p(start) (linearity) the tick term is
+        //      v dv_p = v (-HdA_p x - HA dz_p) - v (HA AKHA^k) dx_p(start): the first part is summed here, the second as the row
+        //      vector w = sum_k v_k hp_k, contracted with the start state once the scan below has produced it.
+        T dz[P][D], w[D];
+        T pv2 = 0, pvdv[P] = {0, 0, 0};
         {
-            T xr[D];
-#pragma unroll
-            for (int i = 0; i < D; i++) xr[i] = xs[i];
 #pragma unroll
             for (int p = 0; p < P; p++)
 #pragma unroll
                 for (int i = 0; i < D; i++) dz[p][i] = T(0);
 #pragma unroll
+            for (int i = 0; i < D; i++) w[i] = T(0);
+#pragma unroll
             for (int k = 0; k < CK; k++) {
                 const bool valid = !tail || (t0 + k) < Tlen;
+                T xo[D], hx;
+#pragma unroll
+                for (int i = 0; i < D; i++) xo[i] = xs[i];
+                const T vr = tick_mean<T, D>(c, xs, y[k], hx);      // xs <- AKHA x + K y (ihgp.h:50), v = y - HA x
+                T v = vr;
+                if (tail) {
+                    v = valid ? v : T(0);
+                    nobs += valid ? 1u : 0u;
+#pragma unroll
+                    for (int i = 0; i < D; i++) xs[i] = valid ? xs[i] : xo[i];
+                }
+                T dv[P];
 #pragma unroll
                 for (int p = 0; p < P; p++) {
-                    T u[D];
+                    T a = 0, u[D];
 #pragma unroll
-                    for (int i = 0; i < D; i++) u[i] = c.dk[p][i] * y[k];
-                    matvec_acc<T, D>(c.dakha[p], xr, u);            // u = dAKHA_p x + dK_p y   (pre-step x, ihgp.h:54)
+                    for (int i = 0; i < D; i++) a = fma(c.a[i], dz[p][i], a);
+                    if (kDFzero[p]) {
+#pragma unroll
+                        for (int i = 0; i < D; i++) u[i] = c.dk[p][i] * vr;               // dAKHA_p x + dK_p y = dK_p v
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < D; i++) a = fma(c.hda[p][i], xo[i], a);
+#pragma unroll
+                        for (int i = 0; i < D; i++) u[i] = c.dk[p][i] * y[k];
+                        matvec_acc<T, D>(c.dakha[p], xo, u);        // u = dAKHA_p x + dK_p y   (pre-step x, ihgp.h:54)
+                    }
+                    dv[p] = a;                                      // -dv_p without the start-state part (ihgp.h:218)
                     matvec_acc<T, D>(c.akha, dz[p], u);             // + AKHA dz
 #pragma unroll
                     for (int i = 0; i < D; i++) dz[p][i] = valid ? u[i] : dz[p][i];
                 }
-                T xo[D], hx;
+                pv2 = fma(v, v, pv2);
 #pragma unroll
-                for (int i = 0; i < D; i++) xo[i] = xr[i];
-                tick_mean<T, D>(c, xr, y[k], hx);
-                if (tail) {
+                for (int p = 0; p < P; p++) pvdv[p] = fma(-v, dv[p], pvdv[p]);
 #pragma unroll
-                    for (int i = 0; i < D; i++) xr[i] = valid ? xr[i] : xo[i];
-                }
+                for (int i = 0; i < D; i++) w[i] = fma(v, tab[HP + k * D + i], w[i]);
+                y[k] = (WRITE == 2) ? hx : xs[0];
             }
         }
-        // ---- (c) scan the sensitivities with the same powers; lane 0 carries dx_in ---------------------------
-        T dxs[P][D];
+        if (!tail) nobs += CK;
+        // ---- (c) scan the sensitivities with the same powers; lane 0 carries dx_in; close the gradient sums --------
+        int jl = 63, nl = CK;                                       // lane and tick count of the last chunk with data
+        if (tail) { jl = (int)((Tlen - 1 - tbase) / CK); nl = (int)(Tlen - tbase - (size_t)jl * CK); }
+#pragma unroll
+        for (int i = 0; i < D; i++) xin[i] = read_lane(xs[i], jl);  // state after the last valid tick
 #pragma unroll
         for (int p = 0; p < P; p++) {
-            T d0[D];
+            T d0[D], dzl[D], ds[D];
 #pragma unroll
-            for (int i = 0; i < D; i++) d0[i] = (lane == 0) ? dxin[p][i] : T(0);
+            for (int i = 0; i < D; i++) { d0[i] = (lane == 0) ? dxin[p][i] : T(0); dzl[i] = dz[p][i]; }
             matvec_acc<T, D>(sp, d0, dz[p]);
             dpp_scan<T, D>(dz[p], sp, pj);
 #pragma unroll
-            for (int i = 0; i < D; i++) dxs[p][i] = wave_shr1(dz[p][i], dxin[p][i]);
+            for (int i = 0; i < D; i++) ds[i] = wave_shr1(dz[p][i], dxin[p][i]);       // dx_p at the start of this lane's chunk
+            T s = 0;
+#pragma unroll
+            for (int i = 0; i < D; i++) s = fma(w[i], ds[i], s);
+            pvdv[p] -= s;
+            if (!tail) {
+#pragma unroll
+                for (int i = 0; i < D; i++) dxin[p][i] = read_lane(dz[p][i], 63);      // inclusive scan value = end of the segment
+            } else {
+                // the last chunk holds nl <= CK ticks: its end state is dz (frozen there) + AKHA^nl dx(start)
+                for (int k = 0; k < nl; k++) {
+                    T t[D];
+#pragma unroll
+                    for (int i = 0; i < D; i++) t[i] = T(0);
+                    matvec_acc<T, D>(c.akha, ds, t);
+#pragma unroll
+                    for (int i = 0; i < D; i++) ds[i] = t[i];
+                }
+#pragma unroll
+                for (int i = 0; i < D; i++) dxin[p][i] = read_lane(dzl[i] + ds[i], jl);
+            }
         }
-        // ---- (d) replay 2 from the true start states: gradient terms, filtered means ----------------------------
-        T pv2 = 0, pvdv[P] = {0, 0, 0};
-#pragma unroll
-        for (int k = 0; k < CK; k++) {
-            const bool valid = !tail || (t0 + k) < Tlen;
-            T xo[D], hx;
-#pragma unroll
-            for (int i = 0; i < D; i++) xo[i] = xs[i];
-            T dxn[P][D];
-#pragma unroll
-            for (int p = 0; p < P; p++) {
-#pragma unroll
-                for (int i = 0; i < D; i++) dxn[p][i] = c.dk[p][i] * y[k];
-                matvec_acc<T, D>(c.dakha[p], xs, dxn[p]);
-                matvec_acc<T, D>(c.akha, dxs[p], dxn[p]);           // ihgp.h:54
-            }
-            T v = tick_mean<T, D>(c, xs, y[k], hx);                 // xs <- AKHA x + K y (ihgp.h:50), v = y - HA x
-            if (tail) v = valid ? v : T(0);
-            pv2 = fma(v, v, pv2);
-#pragma unroll
-            for (int p = 0; p < P; p++) {
-                T a = 0, b = 0;
-#pragma unroll
-                for (int i = 0; i < D; i++) { a = fma(c.hda[p][i], xo[i], a); b = fma(c.a[i], dxs[p][i], b); }
-                pvdv[p] = fma(v, -a - b, pvdv[p]);                  // v * dv_p, dv_p = -HdA_p x - HA dx_p (ihgp.h:218)
-            }
-            if (tail) {
-                nobs += valid ? 1u : 0u;
-#pragma unroll
-                for (int i = 0; i < D; i++) xs[i] = valid ? xs[i] : xo[i];
-            }
-#pragma unroll
-            for (int p = 0; p < P; p++)
-#pragma unroll
-                for (int i = 0; i < D; i++) dxs[p][i] = (tail && !valid) ? dxs[p][i] : dxn[p][i];
-            y[k] = (WRITE == 2) ? hx : xs[0];
-        }
-        if (!tail) nobs += CK;
         sv2 += (double)pv2;
 #pragma unroll
         for (int p = 0; p < P; p++) svdv[p] += (double)pvdv[p];
-        // state after the last valid tick
-        int jl = 63;
-        if (tail) jl = (int)((Tlen - 1 - tbase) / CK);
-#pragma unroll
-        for (int i = 0; i < D; i++) xin[i] = read_lane(xs[i], jl);
-#pragma unroll
-        for (int p = 0; p < P; p++)
-#pragma unroll
-            for (int i = 0; i < D; i++) dxin[p][i] = read_lane(dxs[p][i], jl);
 
         if (WRITE) {
 #pragma unroll
@@ -339,7 +375,9 @@ grad_scan_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, con
             }
         }
         wave_lds_fence();
-    }
+    };
+    for (size_t seg = 0; seg < nfull && !has_nan; seg++) segment(seg, std::false_type{});
+    if (nseg > nfull && !has_nan) segment(nfull, std::true_type{});
 
     if (has_nan) {                                                  // nothing has been written for this latent's state yet
         if (lane == 0) fallback[l] = 1;
