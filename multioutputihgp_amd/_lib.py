@@ -30,8 +30,9 @@ class MoihgpError(RuntimeError):
 
 
 def library_path() -> str:
-    # same relative location the reference loads from (pywrapper.py:22)
-    return os.path.join(_HERE, "lib", "libmoihgp.so")
+    # same relative location the reference loads from (pywrapper.py:22); MOIHGP_LIB points at another build of the same
+    # library (kernel tuning experiments), never at a different implementation
+    return os.environ.get("MOIHGP_LIB") or os.path.join(_HERE, "lib", "libmoihgp.so")
 
 
 def load_library():

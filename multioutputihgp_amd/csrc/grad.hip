@@ -8,11 +8,14 @@
 // grad_scan_kernel: one wavefront owns one latent, lanes are consecutive time chunks of CK ticks, as in
 // recursion.hip.  The mean x is solved per segment by the chunk response + DPP scan of the filter.  Each
 // sensitivity dx_p obeys the SAME linear time-invariant recursion (transition AKHA) driven by the input
-// u_t = dAKHA_p x_t + dK_p y_t, which is known once the true x trajectory of the chunk is replayed; so its chunk
-// response is accumulated during a first replay, the three dx_p are scanned with the very same powers of
-// M = AKHA^CK, and a second replay from the true (x, dx) start states emits the gradient terms.  Sums over ticks:
-//     grad_p = (sum v dv_p)/S - 1/2 (sum v^2 / S - n) dS_p / S
-// VALU-bound (about 200 vector ops per tick at d = 3, P = 3 against 4-8 bytes of stream): its roofline is the
+// u_t = dAKHA_p x_t + dK_p y_t, which is known once the true x trajectory of the chunk is replayed.  One replay per
+// segment does everything: it walks the true x, accumulates the zero-state response dz_p of every sensitivity, and sums
+// the gradient terms in split form -- by linearity dx_p(k) = dz_p(k) + AKHA^k dx_p(start), so
+//     sum_k v_k dv_pk = sum_k v_k (-HdA_p x_k - HA dz_p(k))  -  (sum_k v_k HA AKHA^k) dx_p(start)
+// with the row vector w = sum_k v_k HA AKHA^k accumulated beside it; the three dz_p are then scanned with the very same
+// powers of M = AKHA^CK, which yields every chunk's dx_p(start) (to close the sums) and the segment's end state.
+// Sums over ticks:   grad_p = (sum v dv_p)/S - 1/2 (sum v^2 / S - n) dS_p / S
+// VALU-bound (about 115 vector ops per tick at d = 3, P = 3 against 4-8 bytes of stream): its roofline is the
 // vector ALU, not HBM.
 //
 // Streams with missing ticks (NaN; ihgp.h:39-47 swaps AKHA, dAKHA, dK for A, dA, 0) break the uniform chunk maps:
@@ -233,9 +236,15 @@ grad_scan_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, con
             lds[q + q / VPL] = pack<T>(e);
         }
         wave_lds_fence();
+        // Full segments hold the chunk in registers and unroll the tick loops.  The ragged last segment runs once per latent
+        // but would set the kernel's register allocation (masks keep old and new values alive): it keeps its chunk in LDS and
+        // walks it with rolled loops instead.
         T y[CK];
+        T* yl = reinterpret_cast<T*>(lds + lane * (VPL + 1));
+        if constexpr (!tail) {
 #pragma unroll
-        for (int k = 0; k < VPL; k++) unpack<T>(lds[lane * (VPL + 1) + k], &y[k * EPV]);
+            for (int k = 0; k < VPL; k++) unpack<T>(lds[lane * (VPL + 1) + k], &y[k * EPV]);
+        }
 
         // ---- (a) mean: chunk response + scan -------------------------------------------------------------
 #if MOIHGP_GRAD_SPREG
@@ -248,10 +257,19 @@ grad_scan_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, con
         T z[D];
 #pragma unroll
         for (int i = 0; i < D; i++) z[i] = T(0);
+        if constexpr (tail) {
+#pragma unroll 1
+            for (int k = 0; k < CK; k++) {
+                const T yk = yl[k];
 #pragma unroll
-        for (int k = 0; k < CK; k++)
+                for (int i = 0; i < D; i++) z[i] = fma(tab[k * D + i], yk, z[i]);
+            }
+        } else {
 #pragma unroll
-            for (int i = 0; i < D; i++) z[i] = fma(tab[k * D + i], y[k], z[i]);
+            for (int k = 0; k < CK; k++)
+#pragma unroll
+                for (int i = 0; i < D; i++) z[i] = fma(tab[k * D + i], y[k], z[i]);
+        }
         bool bad = false;
 #pragma unroll
         for (int i = 0; i < D; i++) bad |= (z[i] != z[i]);
@@ -280,13 +298,12 @@ grad_scan_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, con
                 for (int i = 0; i < D; i++) dz[p][i] = T(0);
 #pragma unroll
             for (int i = 0; i < D; i++) w[i] = T(0);
-#pragma unroll
-            for (int k = 0; k < CK; k++) {
+            auto tick = [&](const int k, const T yk) -> T {
                 const bool valid = !tail || (t0 + k) < Tlen;
                 T xo[D], hx;
 #pragma unroll
                 for (int i = 0; i < D; i++) xo[i] = xs[i];
-                const T vr = tick_mean<T, D>(c, xs, y[k], hx);      // xs <- AKHA x + K y (ihgp.h:50), v = y - HA x
+                const T vr = tick_mean<T, D>(c, xs, yk, hx);      // xs <- AKHA x + K y (ihgp.h:50), v = y - HA x
                 T v = vr;
                 if (tail) {
                     v = valid ? v : T(0);
@@ -307,7 +324,7 @@ grad_scan_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, con
 #pragma unroll
                         for (int i = 0; i < D; i++) a = fma(c.hda[p][i], xo[i], a);
 #pragma unroll
-                        for (int i = 0; i < D; i++) u[i] = c.dk[p][i] * y[k];
+                        for (int i = 0; i < D; i++) u[i] = c.dk[p][i] * yk;
                         matvec_acc<T, D>(c.dakha[p], xo, u);        // u = dAKHA_p x + dK_p y   (pre-step x, ihgp.h:54)
                     }
                     dv[p] = a;                                      // -dv_p without the start-state part (ihgp.h:218)
@@ -320,7 +337,17 @@ grad_scan_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, con
                 for (int p = 0; p < P; p++) pvdv[p] = fma(-v, dv[p], pvdv[p]);
 #pragma unroll
                 for (int i = 0; i < D; i++) w[i] = fma(v, tab[HP + k * D + i], w[i]);
-                y[k] = (WRITE == 2) ? hx : xs[0];
+                return (WRITE == 2) ? hx : xs[0];
+            };
+            if constexpr (tail) {
+#pragma unroll 1
+                for (int k = 0; k < CK; k++) {
+                    const T o = tick(k, yl[k]);
+                    if (WRITE) yl[k] = o;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < CK; k++) y[k] = tick(k, y[k]);
             }
         }
         if (!tail) nobs += CK;
@@ -364,8 +391,10 @@ grad_scan_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, con
         for (int p = 0; p < P; p++) svdv[p] += (double)pvdv[p];
 
         if (WRITE) {
+            if constexpr (!tail) {
 #pragma unroll
-            for (int k = 0; k < VPL; k++) lds[lane * (VPL + 1) + k] = pack<T>(&y[k * EPV]);
+                for (int k = 0; k < VPL; k++) lds[lane * (VPL + 1) + k] = pack<T>(&y[k * EPV]);
+            }
             wave_lds_fence();
 #pragma unroll
             for (int i = 0; i < VPL; i++) {
@@ -510,7 +539,7 @@ int launch_grad_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, si
                        hipStream_t stream, int out_mode) {
     if (L == 0) return 0;
     // short windows (the online learner's W <= 128 ticks, moihgp_online.h:61-70) use 16-byte chunks so that a
-    // window still spreads over the lanes of the wave; long streams use 8-tick chunks (tuning hook: MOIHGP_GRAD_CK)
+    // window still spreads over the lanes of the wave; long streams use 16-tick (fp32) / 8-tick (fp64) chunks (tuning hook: MOIHGP_GRAD_CK)
     const bool shortw = T <= (dtype == 0 ? 256 : 512);
     static const int ck_override = [] { const char* e = std::getenv("MOIHGP_GRAD_CK"); return e ? std::atoi(e) : 0; }();
 #define MOIHGP_GRAD_CASE(TT, DD, CKK, CB) \
@@ -519,12 +548,14 @@ int launch_grad_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, si
         if (d == 2) { if (shortw) MOIHGP_GRAD_CASE(double, 2, 2, cb64); MOIHGP_GRAD_CASE(double, 2, 8, cb64); }
         if (shortw || ck_override == 2) MOIHGP_GRAD_CASE(double, 3, 2, cb64);
         if (ck_override == 4) MOIHGP_GRAD_CASE(double, 3, 4, cb64);
+        if (ck_override == 16) MOIHGP_GRAD_CASE(double, 3, 16, cb64);
         MOIHGP_GRAD_CASE(double, 3, 8, cb64);
     }
     if (d == 2) { if (shortw) MOIHGP_GRAD_CASE(float, 2, 4, cb32); MOIHGP_GRAD_CASE(float, 2, 16, cb32); }
     if (shortw || ck_override == 4) MOIHGP_GRAD_CASE(float, 3, 4, cb32);
-    if (ck_override == 16) MOIHGP_GRAD_CASE(float, 3, 16, cb32);
-    MOIHGP_GRAD_CASE(float, 3, 8, cb32);            // measured: 8-tick chunks (165 VGPRs) beat 16-tick chunks (256 VGPRs) by 17 %
+    if (ck_override == 8) MOIHGP_GRAD_CASE(float, 3, 8, cb32);
+    if (ck_override == 32) MOIHGP_GRAD_CASE(float, 3, 32, cb32);
+    MOIHGP_GRAD_CASE(float, 3, 16, cb32);           // measured: 16-tick chunks (236 VGPRs) 0.178 ms, 8-tick chunks (172) 0.228 ms at 4096 x 1e4
 #undef MOIHGP_GRAD_CASE
 }
 
