@@ -88,10 +88,19 @@ __device__ inline void matvec_bc(const T (&m)[NS], const T (&v)[D], T (&out)[D])
     });
 }
 
-template <typename T, int DB, int J, bool WRITE, bool NLL, bool TAIL>
-__device__ inline void replay(const T (&a)[J * DB * DB], const T& ha, const T& kk, T* tile_lane, int first_tick, int n, int head,
-                              T (&xs)[DB * J], double& acc, unsigned& nobs) {
+// One instantiation serves full, ragged and warm-up segments alike (a second, masked one took part in the kernel's register
+// allocation and cost the full segments 10 %), and the tick loop carries no per-lane masking: every lane walks its whole chunk,
+// lanes past the end compute on zero padding nobody reads.  What a ragged end needs is taken at the one tick where the stream
+// ends -- tick klast of lane jl, a wave-uniform test: that lane parks its state in LDS (the carry-out) and adds its running sum
+// of squared innovations to the total there.  head (warm-up ticks of a time slice, not counted) is a multiple of the chunk length, so a
+// lane's chunk counts as a whole or not at all.
+template <typename T, int DB, int J, bool WRITE, bool NLL>
+__device__ inline void replay(const T (&a)[J * DB * DB], const T& ha, const T& kk, T* tile_lane, T* carry, int lane, int n, int head,
+                              T (&xs)[DB * J], T (&xc)[DB * J], double& acc, unsigned& nobs) {
     constexpr int D = DB * J;
+    const int jl = (n - 1) / kChunkX, klast = (n - 1) % kChunkX;      // lane and tick of the last tick of the segment
+    double part = 0.0;
+    const bool counted = lane * kChunkX >= head;
 #pragma unroll 1
     for (int k = 0; k < kChunkX; k++) {
         const T y = tile_lane[k];
@@ -101,11 +110,9 @@ __device__ inline void replay(const T (&a)[J * DB * DB], const T& ha, const T& k
             fmac_bc<i>(i % 3 == 0 ? h0 : (i % 3 == 1 ? h1 : h2), ha, xs[i]);
         });
         const T v = y - ((h0 + h1) + h2);
-        const bool valid = !TAIL || (first_tick + k < n);
-        if (NLL && valid && (!TAIL || first_tick + k >= head)) {       // (head: warm-up ticks of a time slice are not counted)
+        if (NLL) {
             const double vd = (double)v;
-            acc = fma(vd, vd, acc);                                 // ihgp.h:206-207, pre-step state
-            nobs++;
+            part = fma(vd, vd, part);                               // ihgp.h:206-207, pre-step state
         }
         T xn[D];
 #pragma unroll
@@ -119,22 +126,36 @@ __device__ inline void replay(const T (&a)[J * DB * DB], const T& ha, const T& k
             }
         static_for<D>([&](auto ii) { fmac_bc<decltype(ii)::value>(xn[decltype(ii)::value], kk, v); });   // ihgp.h:90 as A x + K (y - HA x)
 #pragma unroll
-        for (int i = 0; i < D; i++) xs[i] = valid ? xn[i] : xs[i];
+        for (int i = 0; i < D; i++) xs[i] = xn[i];
         if (WRITE) tile_lane[k] = xn[0];                            // ihgp.h:91 `yhat = xnew(0, 0)`, literally
+        if (k == klast) {                                           // wave-uniform
+            if (lane == jl) {
+                if (NLL && counted) acc += part;
+#pragma unroll
+                for (int i = 0; i < D; i++) carry[i] = xn[i];
+            }
+        }
     }
+    if (NLL) {
+        acc += (counted && lane < jl) ? part : 0.0;
+        nobs += counted ? (lane < jl ? (unsigned)kChunkX : (lane == jl ? (unsigned)(klast + 1) : 0u)) : 0u;
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int i = 0; i < D; i++) xc[i] = carry[i];                    // one broadcast read per entry
+    wave_lds_fence();
 }
 
-// n ticks of the tile, one after the other: lane i < D owns row i of AKHA (and of A for missing ticks), lane D owns HA.
+// n ticks of the tile, one after the other, in innovation form: lane i < D owns row i of A, lane D owns HA; per tick every lane
+// forms its row's product with the state, lane D's result is HA x, and an observed tick adds K (y - HA x) (ihgp.h:90 as
+// A x + K (y - HA x); a missing tick is ihgp.h:83-87, x <- A x).  One row per lane: this path must not set the kernel's registers.
 template <typename T, int D, bool WRITE, bool NLL>
 __device__ inline void sequential(const T* __restrict__ c, T* tile, int stride, int n, int head, int lane, T (&xc)[D], double& acc, unsigned& nobs) {
     using Lay = XC<D>;
-    T rowF[D], rowP[D], kk = 0, xv = 0;
+    T row[D], kk = 0, xv = 0;
     const int r = lane < D ? lane : 0;
 #pragma unroll
-    for (int j = 0; j < D; j++) {
-        rowF[j] = lane < D ? c[Lay::AKHA + r * D + j] : (lane == D ? c[Lay::HA + j] : T(0));
-        rowP[j] = lane < D ? c[Lay::A + r * D + j] : T(0);
-    }
+    for (int j = 0; j < D; j++) row[j] = lane < D ? c[Lay::A + r * D + j] : (lane == D ? c[Lay::HA + j] : T(0));
     if (lane < D) kk = c[Lay::K + r];
 #pragma unroll
     for (int i = 0; i < D; i++) if (lane == i) xv = xc[i];
@@ -142,19 +163,13 @@ __device__ inline void sequential(const T* __restrict__ c, T* tile, int stride, 
     for (int t = 0; t < n; t++) {
         T* slot = tile + (t / kChunkX) * stride + (t % kChunkX);
         const T y = *slot;                                           // same address in every lane: one broadcast read
-        const bool miss = (y != y);
         T s = 0;
-        if (miss) {                                                  // ihgp.h:83-87: x <- A x, no likelihood term
 #pragma unroll
-            for (int j = 0; j < D; j++) s = fma(rowP[j], read_lane(xv, j), s);
-        } else {
-#pragma unroll
-            for (int j = 0; j < D; j++) s = fma(rowF[j], read_lane(xv, j), s);
-            s = fma(kk, y, s);
-            if (NLL) {
-                const double v = (double)(y - read_lane(s, D));      // lane D computed HA x
-                if (lane == 0 && t >= head) { acc = fma(v, v, acc); nobs++; }
-            }
+        for (int j = 0; j < D; j++) s = fma(row[j], read_lane(xv, j), s);
+        if (!(y != y)) {
+            const T v = y - read_lane(s, D);                         // lane D computed HA x
+            s = fma(kk, v, s);
+            if (NLL && lane == 0 && t >= head) { const double vd = (double)v; acc = fma(vd, vd, acc); nobs++; }
         }
         xv = s;
         if (WRITE) { const T yh = read_lane(s, 0); if (lane == 0) *slot = yh; }
@@ -178,6 +193,7 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
     using Lay = XC<D>;
     constexpr int CK = kChunkX, EPV = 16 / sizeof(T), STRIDE = CK + EPV, SEG = 64 * CK;
     __shared__ __attribute__((aligned(16))) T tiles[WPB][64 * STRIDE];
+    __shared__ T carries[WPB][D];                                    // carry-out of a segment (written by the lane that holds its last tick)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t l = SPLIT ? (size_t)blockIdx.x : (size_t)blockIdx.x * WPB + wave;   // SPLIT: grid = (latents, slices)
@@ -326,11 +342,7 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
             __builtin_amdgcn_sched_barrier(0);
             fetch(t0 + SEG, nnext);                                  // next segment's stream, in flight during the replay
             __builtin_amdgcn_sched_barrier(0);
-            if (n == SEG && head == 0) replay<T, DB, J, WRITE, NLL, false>(ablk, ha, kk, tile_lane, lane * CK, n, 0, xs, acc, nobs);
-            else replay<T, DB, J, WRITE, NLL, true>(ablk, ha, kk, tile_lane, lane * CK, n, head, xs, acc, nobs);
-            const int jl = (n - 1) / CK;                             // the lane that holds the last tick
-#pragma unroll
-            for (int i = 0; i < D; i++) xc[i] = read_lane(xs[i], jl);
+            replay<T, DB, J, WRITE, NLL>(ablk, ha, kk, tile_lane, carries[wave], lane, n, head, xs, xc, acc, nobs);
         }
         // ---- stage out ----
         if (WRITE) {
