@@ -175,6 +175,15 @@ def run_c1(args, rank, world):
     print(json.dumps(out), flush=True)
 
 
+def valu_side(d, dtype, steps_per_s):
+    """Vector-ALU side of the roofline: SURVEY 8(d)'s flop count for the filter (2 d^2 + 2 d per Kalman step) over the
+    dense vector peak of the dtype (MI355X_MICROARCH.md: 157.3 TFLOP/s fp32, 78.6 fp64)."""
+    flops = 2 * d * d + 2 * d
+    peak = 157.3 if dtype == torch.float32 else 78.6
+    tf = steps_per_s * flops / 1e12
+    return {"flops_per_step": flops, "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -310,7 +319,9 @@ def main():
                        "layout": "series-major [L][ld], HBM-resident", "sharding": f"latents x{world}, NLL scalar all-reduce per pass" + ("" if world == 1 else (" (stream-ordered)" if args.sync_allreduce else " (overlapped with the next pass)"))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "kernel": "filter_x_kernel" if bank.stacked else "filter_scan_kernel", "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes, "frac_of_measured_copy_peak": achieved / HBM_COPY_GBPS},
+                         "algorithmic_bytes_per_launch": alg_bytes, "frac_of_measured_copy_peak": achieved / HBM_COPY_GBPS,
+                         # the other wall (mode F is 2 d^2 + 2 d flop per step; the d = 12 fp64 configuration sits on this one)
+                         "vector_alu": valu_side(bank.d, dtype, Lg_per * T / (kern_ms * 1e-3))},
             "nll_total": float(total.item()),
         }
         if rehearsal:

@@ -41,6 +41,46 @@ constexpr int P = kNumIgpParam;
 // dAKHA_p x + dK_p y = dK_p (y - HA x) = dK_p v: the scan kernel uses that form (12 instead of 21 multiply-adds per tick).
 __device__ constexpr bool kDFzero[P] = {true, false, true};
 
+// Two sensitivities side by side: magnitude and noise (the dF = 0 parameters) obey the same recursion with the same matrices and
+// differ only in their dK, so they travel as one 2-vector per state entry; in fp32 every multiply-add on the pair is ONE packed
+// v_pk_fma_f32 with the matrix entry broadcast.  fp64 has no packed form and keeps the one-parameter-at-a-time code.
+template <typename T> struct PairOf { typedef T type __attribute__((ext_vector_type(2))); };
+template <typename T, int D>
+__device__ inline void matvec_acc2(const T* m, const typename PairOf<T>::type* v, typename PairOf<T>::type* out) {
+#pragma unroll
+    for (int i = 0; i < D; i++)
+#pragma unroll
+        for (int j = 0; j < D; j++) out[i] = m[i * D + j] * v[j] + out[i];
+}
+template <int CTRL, int ROW_MASK, typename T2>
+__device__ inline T2 dpp0_2(T2 v) { T2 r; r.x = dpp0<CTRL, ROW_MASK>(v.x); r.y = dpp0<CTRL, ROW_MASK>(v.y); return r; }
+template <typename T, int D>
+__device__ inline void dpp_scan2(typename PairOf<T>::type* z, const T* sp, const T* pj) {
+    typename PairOf<T>::type t[D];
+#pragma unroll
+    for (int i = 0; i < D; i++) t[i] = dpp0_2<DPP_ROW_SHR + 1, 0xF>(z[i]);
+    matvec_acc2<T, D>(sp + 0 * D * D, t, z);
+#pragma unroll
+    for (int i = 0; i < D; i++) t[i] = dpp0_2<DPP_ROW_SHR + 2, 0xF>(z[i]);
+    matvec_acc2<T, D>(sp + 1 * D * D, t, z);
+#pragma unroll
+    for (int i = 0; i < D; i++) t[i] = dpp0_2<DPP_ROW_SHR + 4, 0xF>(z[i]);
+    matvec_acc2<T, D>(sp + 2 * D * D, t, z);
+#pragma unroll
+    for (int i = 0; i < D; i++) t[i] = dpp0_2<DPP_ROW_SHR + 8, 0xF>(z[i]);
+    matvec_acc2<T, D>(sp + 3 * D * D, t, z);
+#pragma unroll
+    for (int i = 0; i < D; i++) t[i] = dpp0_2<DPP_ROW_BCAST15, 0x2>(z[i]);
+    matvec_acc2<T, D>(pj, t, z);
+#pragma unroll
+    for (int i = 0; i < D; i++) t[i] = dpp0_2<DPP_ROW_BCAST15, 0x4>(z[i]);
+    matvec_acc2<T, D>(pj, t, z);
+#pragma unroll
+    for (int i = 0; i < D; i++) t[i] = dpp0_2<DPP_ROW_BCAST15, 0x8>(z[i]);
+    matvec_acc2<T, D>(pj, t, z);
+}
+static_assert(P == 3 && kDFzero[0] && !kDFzero[1] && kDFzero[2], "the scan kernel pairs parameters 0 and 2 and treats 1 in full");
+
 template <typename T, int D>
 struct GradConst {
     T a[D * D], k[D], akha[D * D], dakha[P][D * D], dk[P][D], hda[P][D];
@@ -289,101 +329,231 @@ grad_scan_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, con
         //      gradient sums in split form.  With dx_p(k) = dz_p(k) + AKHA^k dx_p(start) (linearity) the tick term is
         //      v dv_p = v (-HdA_p x - HA dz_p) - v (HA AKHA^k) dx_p(start): the first part is summed here, the second as the row
         //      vector w = sum_k v_k hp_k, contracted with the start state once the scan below has produced it.
-        T dz[P][D], w[D];
-        T pv2 = 0, pvdv[P] = {0, 0, 0};
-        {
-#pragma unroll
-            for (int p = 0; p < P; p++)
-#pragma unroll
-                for (int i = 0; i < D; i++) dz[p][i] = T(0);
-#pragma unroll
-            for (int i = 0; i < D; i++) w[i] = T(0);
-            auto tick = [&](const int k, const T yk) -> T {
-                const bool valid = !tail || (t0 + k) < Tlen;
-                T xo[D], hx;
-#pragma unroll
-                for (int i = 0; i < D; i++) xo[i] = xs[i];
-                const T vr = tick_mean<T, D>(c, xs, yk, hx);      // xs <- AKHA x + K y (ihgp.h:50), v = y - HA x
-                T v = vr;
-                if (tail) {
-                    v = valid ? v : T(0);
-                    nobs += valid ? 1u : 0u;
-#pragma unroll
-                    for (int i = 0; i < D; i++) xs[i] = valid ? xs[i] : xo[i];
-                }
-                T dv[P];
-#pragma unroll
-                for (int p = 0; p < P; p++) {
-                    T a = 0, u[D];
-#pragma unroll
-                    for (int i = 0; i < D; i++) a = fma(c.a[i], dz[p][i], a);
-                    if (kDFzero[p]) {
-#pragma unroll
-                        for (int i = 0; i < D; i++) u[i] = c.dk[p][i] * vr;               // dAKHA_p x + dK_p y = dK_p v
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < D; i++) a = fma(c.hda[p][i], xo[i], a);
-#pragma unroll
-                        for (int i = 0; i < D; i++) u[i] = c.dk[p][i] * yk;
-                        matvec_acc<T, D>(c.dakha[p], xo, u);        // u = dAKHA_p x + dK_p y   (pre-step x, ihgp.h:54)
-                    }
-                    dv[p] = a;                                      // -dv_p without the start-state part (ihgp.h:218)
-                    matvec_acc<T, D>(c.akha, dz[p], u);             // + AKHA dz
-#pragma unroll
-                    for (int i = 0; i < D; i++) dz[p][i] = valid ? u[i] : dz[p][i];
-                }
-                pv2 = fma(v, v, pv2);
-#pragma unroll
-                for (int p = 0; p < P; p++) pvdv[p] = fma(-v, dv[p], pvdv[p]);
-#pragma unroll
-                for (int i = 0; i < D; i++) w[i] = fma(v, tab[HP + k * D + i], w[i]);
-                return (WRITE == 2) ? hx : xs[0];
-            };
-            if constexpr (tail) {
-#pragma unroll 1
-                for (int k = 0; k < CK; k++) {
-                    const T o = tick(k, yl[k]);
-                    if (WRITE) yl[k] = o;
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < CK; k++) y[k] = tick(k, y[k]);
-            }
-        }
-        if (!tail) nobs += CK;
-        // ---- (c) scan the sensitivities with the same powers; lane 0 carries dx_in; close the gradient sums --------
+        T pv2 = 0, pvdv[P];
         int jl = 63, nl = CK;                                       // lane and tick count of the last chunk with data
         if (tail) { jl = (int)((Tlen - 1 - tbase) / CK); nl = (int)(Tlen - tbase - (size_t)jl * CK); }
+        if constexpr (sizeof(T) == 4) {
+            using T2 = typename PairOf<T>::type;
+            T dz1[D], w[D];
+            T2 dz02[D], dk02[D];
+            T pv1 = 0;
+            T2 pv02 = {T(0), T(0)};
 #pragma unroll
-        for (int i = 0; i < D; i++) xin[i] = read_lane(xs[i], jl);  // state after the last valid tick
+            for (int i = 0; i < D; i++) { dk02[i].x = c.dk[0][i]; dk02[i].y = c.dk[2][i]; }
+            {
 #pragma unroll
-        for (int p = 0; p < P; p++) {
-            T d0[D], dzl[D], ds[D];
+                for (int i = 0; i < D; i++) { dz1[i] = T(0); dz02[i] = T2{T(0), T(0)}; w[i] = T(0); }
+                auto tick = [&](const int k, const T yk) -> T {
+                    const bool valid = !tail || (t0 + k) < Tlen;
+                    T xo[D], hx;
 #pragma unroll
-            for (int i = 0; i < D; i++) { d0[i] = (lane == 0) ? dxin[p][i] : T(0); dzl[i] = dz[p][i]; }
-            matvec_acc<T, D>(sp, d0, dz[p]);
-            dpp_scan<T, D>(dz[p], sp, pj);
+                    for (int i = 0; i < D; i++) xo[i] = xs[i];
+                    const T vr = tick_mean<T, D>(c, xs, yk, hx);        // xs <- AKHA x + K y (ihgp.h:50), v = y - HA x
+                    T v = vr;
+                    if (tail) {
+                        v = valid ? v : T(0);
+                        nobs += valid ? 1u : 0u;
 #pragma unroll
-            for (int i = 0; i < D; i++) ds[i] = wave_shr1(dz[p][i], dxin[p][i]);       // dx_p at the start of this lane's chunk
-            T s = 0;
+                        for (int i = 0; i < D; i++) xs[i] = valid ? xs[i] : xo[i];
+                    }
+                    // lengthscale (dF != 0): -dv without the start-state part (ihgp.h:218), u = dAKHA x + dK y + AKHA dz (ihgp.h:54)
+                    T a1 = 0, u1[D];
 #pragma unroll
-            for (int i = 0; i < D; i++) s = fma(w[i], ds[i], s);
-            pvdv[p] -= s;
-            if (!tail) {
+                    for (int i = 0; i < D; i++) a1 = fma(c.a[i], dz1[i], a1);
 #pragma unroll
-                for (int i = 0; i < D; i++) dxin[p][i] = read_lane(dz[p][i], 63);      // inclusive scan value = end of the segment
-            } else {
-                // the last chunk holds nl <= CK ticks: its end state is dz (frozen there) + AKHA^nl dx(start)
-                for (int k = 0; k < nl; k++) {
-                    T t[D];
+                    for (int i = 0; i < D; i++) a1 = fma(c.hda[1][i], xo[i], a1);
 #pragma unroll
-                    for (int i = 0; i < D; i++) t[i] = T(0);
-                    matvec_acc<T, D>(c.akha, ds, t);
+                    for (int i = 0; i < D; i++) u1[i] = c.dk[1][i] * yk;
+                    matvec_acc<T, D>(c.dakha[1], xo, u1);
+                    matvec_acc<T, D>(c.akha, dz1, u1);
+                    // magnitude and noise as a pair: dAKHA_p x + dK_p y = dK_p v
+                    T2 a02 = {T(0), T(0)}, u02[D];
 #pragma unroll
-                    for (int i = 0; i < D; i++) ds[i] = t[i];
+                    for (int i = 0; i < D; i++) a02 = c.a[i] * dz02[i] + a02;
+#pragma unroll
+                    for (int i = 0; i < D; i++) u02[i] = dk02[i] * vr;
+                    matvec_acc2<T, D>(c.akha, dz02, u02);
+#pragma unroll
+                    for (int i = 0; i < D; i++) { dz1[i] = valid ? u1[i] : dz1[i]; dz02[i] = valid ? u02[i] : dz02[i]; }
+                    pv2 = fma(v, v, pv2);
+                    pv1 = fma(-v, a1, pv1);
+                    pv02 = (-v) * a02 + pv02;
+#pragma unroll
+                    for (int i = 0; i < D; i++) w[i] = fma(v, tab[HP + k * D + i], w[i]);
+                    return (WRITE == 2) ? hx : xs[0];
+                };
+                if constexpr (tail) {
+#pragma unroll 1
+                    for (int k = 0; k < CK; k++) {
+                        const T o = tick(k, yl[k]);
+                        if (WRITE) yl[k] = o;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < CK; k++) y[k] = tick(k, y[k]);
                 }
+            }
+            if (!tail) nobs += CK;
+            // ---- (c) scan the sensitivities with the same powers; lane 0 carries dx_in; close the gradient sums --------
 #pragma unroll
-                for (int i = 0; i < D; i++) dxin[p][i] = read_lane(dzl[i] + ds[i], jl);
+            for (int i = 0; i < D; i++) xin[i] = read_lane(xs[i], jl);  // state after the last valid tick
+            {   // the lengthscale
+                T d0[D], dzl[D], ds[D];
+#pragma unroll
+                for (int i = 0; i < D; i++) { d0[i] = (lane == 0) ? dxin[1][i] : T(0); dzl[i] = dz1[i]; }
+                matvec_acc<T, D>(sp, d0, dz1);
+                dpp_scan<T, D>(dz1, sp, pj);
+#pragma unroll
+                for (int i = 0; i < D; i++) ds[i] = wave_shr1(dz1[i], dxin[1][i]);         // dx_p at the start of this lane's chunk
+                T sw = 0;
+#pragma unroll
+                for (int i = 0; i < D; i++) sw = fma(w[i], ds[i], sw);
+                pvdv[1] = pv1 - sw;
+                if (!tail) {
+#pragma unroll
+                    for (int i = 0; i < D; i++) dxin[1][i] = read_lane(dz1[i], 63);        // inclusive scan value = end of the segment
+                } else {
+                    // the last chunk holds nl <= CK ticks: its end state is dz (frozen there) + AKHA^nl dx(start)
+                    for (int k = 0; k < nl; k++) {
+                        T t[D];
+#pragma unroll
+                        for (int i = 0; i < D; i++) t[i] = T(0);
+                        matvec_acc<T, D>(c.akha, ds, t);
+#pragma unroll
+                        for (int i = 0; i < D; i++) ds[i] = t[i];
+                    }
+#pragma unroll
+                    for (int i = 0; i < D; i++) dxin[1][i] = read_lane(dzl[i] + ds[i], jl);
+                }
+            }
+            {   // magnitude and noise
+                T2 d0[D], dzl[D], ds[D];
+#pragma unroll
+                for (int i = 0; i < D; i++) {
+                    d0[i].x = (lane == 0) ? dxin[0][i] : T(0); d0[i].y = (lane == 0) ? dxin[2][i] : T(0);
+                    dzl[i] = dz02[i];
+                }
+                matvec_acc2<T, D>(sp, d0, dz02);
+                dpp_scan2<T, D>(dz02, sp, pj);
+#pragma unroll
+                for (int i = 0; i < D; i++) { ds[i].x = wave_shr1(dz02[i].x, dxin[0][i]); ds[i].y = wave_shr1(dz02[i].y, dxin[2][i]); }
+                T2 sw = {T(0), T(0)};
+#pragma unroll
+                for (int i = 0; i < D; i++) sw = w[i] * ds[i] + sw;
+                pvdv[0] = pv02.x - sw.x; pvdv[2] = pv02.y - sw.y;
+                if (!tail) {
+#pragma unroll
+                    for (int i = 0; i < D; i++) { dxin[0][i] = read_lane(dz02[i].x, 63); dxin[2][i] = read_lane(dz02[i].y, 63); }
+                } else {
+                    for (int k = 0; k < nl; k++) {
+                        T2 t[D];
+#pragma unroll
+                        for (int i = 0; i < D; i++) t[i] = T2{T(0), T(0)};
+                        matvec_acc2<T, D>(c.akha, ds, t);
+#pragma unroll
+                        for (int i = 0; i < D; i++) ds[i] = t[i];
+                    }
+#pragma unroll
+                    for (int i = 0; i < D; i++) { dxin[0][i] = read_lane(dzl[i].x + ds[i].x, jl); dxin[2][i] = read_lane(dzl[i].y + ds[i].y, jl); }
+                }
+            }
+        } else {
+            // fp64: no packed form; one parameter after the other keeps fewer values alive (240 against 284 VGPRs)
+            T dz[P][D], w[D];
+#pragma unroll
+            for (int p = 0; p < P; p++) pvdv[p] = T(0);
+            {
+#pragma unroll
+                for (int p = 0; p < P; p++)
+#pragma unroll
+                    for (int i = 0; i < D; i++) dz[p][i] = T(0);
+#pragma unroll
+                for (int i = 0; i < D; i++) w[i] = T(0);
+                auto tick = [&](const int k, const T yk) -> T {
+                    const bool valid = !tail || (t0 + k) < Tlen;
+                    T xo[D], hx;
+#pragma unroll
+                    for (int i = 0; i < D; i++) xo[i] = xs[i];
+                    const T vr = tick_mean<T, D>(c, xs, yk, hx);      // xs <- AKHA x + K y (ihgp.h:50), v = y - HA x
+                    T v = vr;
+                    if (tail) {
+                        v = valid ? v : T(0);
+                        nobs += valid ? 1u : 0u;
+#pragma unroll
+                        for (int i = 0; i < D; i++) xs[i] = valid ? xs[i] : xo[i];
+                    }
+                    T dv[P];
+#pragma unroll
+                    for (int p = 0; p < P; p++) {
+                        T a = 0, u[D];
+#pragma unroll
+                        for (int i = 0; i < D; i++) a = fma(c.a[i], dz[p][i], a);
+                        if (kDFzero[p]) {
+#pragma unroll
+                            for (int i = 0; i < D; i++) u[i] = c.dk[p][i] * vr;               // dAKHA_p x + dK_p y = dK_p v
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < D; i++) a = fma(c.hda[p][i], xo[i], a);
+#pragma unroll
+                            for (int i = 0; i < D; i++) u[i] = c.dk[p][i] * yk;
+                            matvec_acc<T, D>(c.dakha[p], xo, u);        // u = dAKHA_p x + dK_p y   (pre-step x, ihgp.h:54)
+                        }
+                        dv[p] = a;                                      // -dv_p without the start-state part (ihgp.h:218)
+                        matvec_acc<T, D>(c.akha, dz[p], u);             // + AKHA dz
+#pragma unroll
+                        for (int i = 0; i < D; i++) dz[p][i] = valid ? u[i] : dz[p][i];
+                    }
+                    pv2 = fma(v, v, pv2);
+#pragma unroll
+                    for (int p = 0; p < P; p++) pvdv[p] = fma(-v, dv[p], pvdv[p]);
+#pragma unroll
+                    for (int i = 0; i < D; i++) w[i] = fma(v, tab[HP + k * D + i], w[i]);
+                    return (WRITE == 2) ? hx : xs[0];
+                };
+                if constexpr (tail) {
+#pragma unroll 1
+                    for (int k = 0; k < CK; k++) {
+                        const T o = tick(k, yl[k]);
+                        if (WRITE) yl[k] = o;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < CK; k++) y[k] = tick(k, y[k]);
+                }
+            }
+            if (!tail) nobs += CK;
+            // ---- (c) scan the sensitivities with the same powers; lane 0 carries dx_in; close the gradient sums --------
+#pragma unroll
+            for (int i = 0; i < D; i++) xin[i] = read_lane(xs[i], jl);  // state after the last valid tick
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                T d0[D], dzl[D], ds[D];
+#pragma unroll
+                for (int i = 0; i < D; i++) { d0[i] = (lane == 0) ? dxin[p][i] : T(0); dzl[i] = dz[p][i]; }
+                matvec_acc<T, D>(sp, d0, dz[p]);
+                dpp_scan<T, D>(dz[p], sp, pj);
+#pragma unroll
+                for (int i = 0; i < D; i++) ds[i] = wave_shr1(dz[p][i], dxin[p][i]);       // dx_p at the start of this lane's chunk
+                T s = 0;
+#pragma unroll
+                for (int i = 0; i < D; i++) s = fma(w[i], ds[i], s);
+                pvdv[p] -= s;
+                if (!tail) {
+#pragma unroll
+                    for (int i = 0; i < D; i++) dxin[p][i] = read_lane(dz[p][i], 63);      // inclusive scan value = end of the segment
+                } else {
+                    // the last chunk holds nl <= CK ticks: its end state is dz (frozen there) + AKHA^nl dx(start)
+                    for (int k = 0; k < nl; k++) {
+                        T t[D];
+#pragma unroll
+                        for (int i = 0; i < D; i++) t[i] = T(0);
+                        matvec_acc<T, D>(c.akha, ds, t);
+#pragma unroll
+                        for (int i = 0; i < D; i++) ds[i] = t[i];
+                    }
+#pragma unroll
+                    for (int i = 0; i < D; i++) dxin[p][i] = read_lane(dzl[i] + ds[i], jl);
+                }
             }
         }
         sv2 += (double)pv2;
