@@ -321,7 +321,7 @@ def main():
                          "traffic": traffic, "kernel": "filter_x_kernel" if bank.stacked else "filter_scan_kernel", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": alg_bytes, "frac_of_measured_copy_peak": achieved / HBM_COPY_GBPS,
                          # the other wall (mode F is 2 d^2 + 2 d flop per step; the d = 12 fp64 configuration sits on this one)
-                         "vector_alu": valu_side(bank.d, dtype, Lg_per * T / (kern_ms * 1e-3))},
+                         "vector_alu": valu_side(bank.d, dtype, L * min(slab, T) / (kern_ms * 1e-3))},
             "nll_total": float(total.item()),
         }
         if rehearsal:

@@ -310,7 +310,24 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
         if (!scan_ok || __builtin_amdgcn_ballot_w64(bad) != 0) {
             fetch(t0 + SEG, nnext);
             __builtin_amdgcn_sched_barrier(0);
-            sequential<T, D, WRITE, NLL>(c, tile, STRIDE, n, head, lane, xc, acc, nobs);
+            // An unstable latent whose state has left the format (inf / NaN) has nothing finite ahead of it: the rest of its
+            // stream is filled with NaN instead of being walked tick by tick (that walk is 10 x slower than the segment solve, and
+            // one such latent would hold the whole launch back; the reference's own values there are inf / NaN as well).
+            bool any_lost = false;
+#pragma unroll
+            for (int i = 0; i < D; i++) any_lost = any_lost || !((xc[i] - xc[i]) == T(0));
+            if (!scan_ok && any_lost) {
+                const T qnan = __builtin_nan("");
+                if (WRITE) {
+#pragma unroll 4
+                    for (int k = 0; k < CK; k++) tile_lane[k] = qnan;
+                }
+#pragma unroll
+                for (int i = 0; i < D; i++) xc[i] = qnan;
+                if (NLL) acc = __builtin_nan("");
+            } else {
+                sequential<T, D, WRITE, NLL>(c, tile, STRIDE, n, head, lane, xc, acc, nobs);
+            }
         } else {
             // ---- carry-in on lane 0, then the 64-lane Kogge-Stone scan with uniform powers ----
             T t[D];

@@ -605,6 +605,32 @@ def test_stacked_ragged_shapes_vs_oracle(env, kern, dtype, L, T):
     assert same(nll2, nll) and same(x2, xT) and same(x3, xT) and same(x4, xT) and same(yh3[:, :T], yhat[:, :T])
 
 
+def test_stacked_mildly_unstable_latents_stay_on_the_scan_path(env):
+    """The literal DARE (dare.h:23) leaves some stacked Matern-3/2 latents with rho(AKHA) slightly above 1 (these parameter
+    sets come from the bench's own draw).  Their trajectories grow like rho^t but stay far inside fp64's range, and the
+    segment solve must follow them tick for tick (error measured against the trajectory's running magnitude)."""
+    prm = np.array([[1.42962333, 1.59788413, 1.91620496, 1.66245887, 0.05233625],
+                    [0.7227578, 1.71853154, 1.59357212, 1.81934245, 0.05206774],
+                    [0.85943105, 1.84330571, 1.96285317, 1.72411971, 0.0601299],
+                    [1.0, 1.0, 1.0, 1.0, 0.1]])
+    kern, T = "Matern32x2", 4500
+    rng = np.random.default_rng(5)
+    bank = env["streams"].LatentBank(0.1, prm, kernel=kern)
+    igps = env["cref"].ihgp_array(kern, 0.1, prm)
+    rho = [np.max(np.abs(np.linalg.eigvals(g.mat("AKHA")))) for g in igps]
+    assert max(rho[:3]) > 1.0 and min(rho[:3]) > 1.0 and rho[3] < 1.0, rho
+    Ty = synth(4, T, rng)
+    o = env["cref"].filter_stream(igps, Ty, nthreads=2)
+    yhat, xT, nll = bank.filter(to_dev(Ty, torch.float64), T=T)
+    torch.cuda.synchronize()
+    got = yhat[:, :T].cpu().numpy()
+    assert np.isfinite(got).all() and np.abs(o["yhat"][:3]).max() > 1e20           # they did grow
+    running = np.maximum.accumulate(np.abs(o["yhat"]), axis=1) + 1e-300
+    assert (np.abs(got - o["yhat"]) / running).max() < 1e-8
+    assert rel_err(nll.cpu().numpy(), o["nll_per_latent"]) < 1e-8
+    assert rel_err(xT.cpu().numpy(), o["x"]) < 1e-8
+
+
 @pytest.mark.parametrize("kern", ["Matern52x2", "Matern52x4"])
 def test_stacked_missing_data_and_slabs(env, kern):
     J = int(kern[-1])
