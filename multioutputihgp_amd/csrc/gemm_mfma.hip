@@ -131,6 +131,12 @@ gemm_mfma_kernel(size_t Mi, size_t Nj, size_t Kk, const TA* __restrict__ A, size
                         ra[h][e] = (gk < Kk && gi < Mi) ? (TC)A[gk * lda + gi] : TC(0);
                     }
                 }
+                // the k scale goes onto whichever operand a thread holds for ONE k (one load, 8 multiplies): here that is A
+                if (ks_mode == 1 && gk < Kk) {
+                    const TC sc = (TC)ks[gk];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) ra[h][e] *= sc;
+                }
             } else {              // A(i,k) = A[i*lda + k]: thread -> (i = tid / 2, 8 consecutive k)
                 const int ii = tid >> 1, kk = (tid & 1) * 8;
                 const size_t gi = i0 + ii;
@@ -154,7 +160,7 @@ gemm_mfma_kernel(size_t Mi, size_t Nj, size_t Kk, const TA* __restrict__ A, size
                         rb[h][e] = (gk < Kk && gj < Nj) ? (TC)B[gj * ldb + gk] : TC(0);
                     }
                 }
-                if (ks_mode == 1) {
+                if (ks_mode == 1 && !A_ICONTIG) {       // both operands k-contiguous: eight scales per thread
 #pragma unroll
                     for (int e = 0; e < 8; e++) { const size_t gk = k0 + kk + e; if (gk < Kk) rb[h][e] *= (TC)ks[gk]; }
                 }
@@ -169,7 +175,7 @@ gemm_mfma_kernel(size_t Mi, size_t Nj, size_t Kk, const TA* __restrict__ A, size
                         rb[h][e] = (gk < Kk && gj < Nj) ? (TC)B[gk * ldb + gj] : TC(0);
                     }
                 }
-                if (ks_mode == 1 && gk < Kk) {
+                if (ks_mode == 1 && !A_ICONTIG && gk < Kk) {
                     const TC sc = (TC)ks[gk];
 #pragma unroll
                     for (int e = 0; e < 8; e++) rb[h][e] *= sc;
