@@ -57,6 +57,8 @@ struct moihgp_gp {
     double sigma = 1e-2;
     // device state
     hipStream_t stream = nullptr;
+    float* dU32 = nullptr;     // fp32 image of dU for the fp32 stream products, rebuilt on first use after U changed
+    bool u32_valid = false;
     double *dU = nullptr, *dS = nullptr, *dsqrtS = nullptr, *dinvsqrtS = nullptr, *dsigma = nullptr, *dparams = nullptr, *cb64 = nullptr;
     float* cb32 = nullptr;
     // per-tick staging
@@ -91,7 +93,7 @@ struct moihgp_gp {
 
 static void gp_free(moihgp_gp* g) {
     if (!g) return;
-    void* ptrs[] = {g->dU, g->dS, g->dsqrtS, g->dinvsqrtS, g->dsigma, g->dparams, g->cb64, g->cb32, g->dx, g->dpart, g->dTy, g->dUty, g->dTyhat, g->dloss, g->dgrad, g->dscratch, g->dwork, g->dpolar, g->dfallback, g->dwin, g->dunstable, g->dxscratch, g->cbd64};
+    void* ptrs[] = {g->dU, g->dS, g->dsqrtS, g->dinvsqrtS, g->dsigma, g->dparams, g->cb64, g->cb32, g->dx, g->dpart, g->dTy, g->dUty, g->dTyhat, g->dloss, g->dgrad, g->dscratch, g->dwork, g->dpolar, g->dfallback, g->dwin, g->dunstable, g->dxscratch, g->cbd64, g->dU32};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (void* p : g->pinned) (void)hipHostUnregister(p);
@@ -106,6 +108,7 @@ static void gp_free(moihgp_gp* g) {
 
 static void upload_mixing(moihgp_gp* g) {
     if (g->latents_only) return;
+    g->u32_valid = false;
     if (!g->U_host_stale)    // otherwise the device copy is the current one (device polar factor)
         MOIHGP_HIP_FATAL(hipMemcpyAsync(g->dU, g->U.data(), sizeof(double) * g->M * g->L, hipMemcpyHostToDevice, g->stream));
     MOIHGP_HIP_FATAL(hipMemcpyAsync(g->dS, g->S.data(), sizeof(double) * g->L, hipMemcpyHostToDevice, g->stream));
@@ -326,6 +329,7 @@ static bool compute_polar(moihgp_gp* g, const double* Uparam) {
     const size_t M = g->M, L = g->L;
     bool small = polar_small_fits(M, L);
     if (const char* e = std::getenv("MOIHGP_POLAR")) { if (e[0] == 'g') small = false; }
+    g->u32_valid = false;
     MOIHGP_HIP_FATAL(hipMemcpyAsync(g->dU, Uparam, sizeof(double) * M * L, hipMemcpyHostToDevice, g->stream));
     int its = 0;
     if (small) {
@@ -595,16 +599,26 @@ int moihgp_grad_stream(moihgp_gp* gp, int dtype, const void* Ty, size_t T, size_
     return launch_grad_stream(gp->d, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cb32, x, dx, yhat, nll, grad, gp->dfallback, (hipStream_t)stream);
 }
 
+// fp32 image of the mixing matrix, (re)built on the caller's stream the first time an fp32 stream product needs it after U changed
+// (update() has synchronised its own stream by then)
+static const float* mixing_f32(moihgp_gp* gp, hipStream_t stream) {
+    if (!gp->dU32) gp->dU32 = dev_alloc<float>(gp->M * gp->L);
+    if (!gp->u32_valid) { launch_narrow(gp->dU, gp->M * gp->L, gp->dU32, stream); gp->u32_valid = true; }
+    return gp->dU32;
+}
+
 int moihgp_project_stream(moihgp_gp* gp, int dtype, const void* Y, size_t T, void* Ty, size_t ld, void* stream) {
     if (!gp || gp->latents_only) { set_last_error("project_stream needs a full MOIHGP object"); return 1; }
     if (ld < T) { set_last_error("ld < T"); return 1; }
-    return launch_project_stream(dtype, Y, T, gp->M, gp->L, gp->dU, gp->dinvsqrtS, Ty, ld, (hipStream_t)stream);
+    return launch_project_stream(dtype, Y, T, gp->M, gp->L, gp->dU, dtype == MOIHGP_F64 ? nullptr : mixing_f32(gp, (hipStream_t)stream), gp->dinvsqrtS, Ty, ld,
+                                 (hipStream_t)stream);
 }
 
 int moihgp_unproject_stream(moihgp_gp* gp, int dtype, const void* Tyhat, size_t T, size_t ld, void* Yhat, void* stream) {
     if (!gp || gp->latents_only) { set_last_error("unproject_stream needs a full MOIHGP object"); return 1; }
     if (ld < T) { set_last_error("ld < T"); return 1; }
-    return launch_unproject_stream(dtype, Tyhat, T, ld, gp->M, gp->L, gp->dU, gp->dsqrtS, Yhat, (hipStream_t)stream);
+    return launch_unproject_stream(dtype, Tyhat, T, ld, gp->M, gp->L, gp->dU, dtype == MOIHGP_F64 ? nullptr : mixing_f32(gp, (hipStream_t)stream), gp->dsqrtS, Yhat,
+                                   (hipStream_t)stream);
 }
 
 int moihgp_window_set(moihgp_gp* gp, const double* Y, size_t W) {

@@ -167,9 +167,10 @@ void launch_nll_tick(const TickArgs& a, const double* x, const double* y, const 
 // gemm_mfma.hip: MFMA GEMMs (whole-stream projection, Gram / update products of the polar factor).
 // invsqrtS / sqrtS: the device vectors S^-1/2 and S^1/2 (launch_scales)
 void launch_scales(const double* S, size_t L, double* sqrtS, double* invsqrtS, hipStream_t s);
-int launch_project_stream(int dtype, const void* Y, size_t T, size_t M, size_t L, const double* U, const double* invsqrtS,
+void launch_narrow(const double* src, size_t n, float* dst, hipStream_t s);       // dst = (float) src
+int launch_project_stream(int dtype, const void* Y, size_t T, size_t M, size_t L, const double* U, const float* U32 /* optional fp32 image of U */, const double* invsqrtS,
                           void* Ty, size_t ld, hipStream_t s);
-int launch_unproject_stream(int dtype, const void* Tyhat, size_t T, size_t ld, size_t M, size_t L, const double* U,
+int launch_unproject_stream(int dtype, const void* Tyhat, size_t T, size_t ld, size_t M, size_t L, const double* U, const float* U32,
                             const double* sqrtS, void* Yhat, hipStream_t s);
 // gradU[r][c] = sum_t Y[t][r] Z[c][t]   (Y tick-major [W][M], Z series-major [L][ldz])
 int launch_ugrad_gemm(const double* Y, size_t W, size_t M, const double* Z, size_t ldz, size_t L, double* gradU, hipStream_t s);

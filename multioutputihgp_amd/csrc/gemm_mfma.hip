@@ -293,17 +293,28 @@ __global__ void scales_kernel(const double* __restrict__ S, size_t L, double* __
 void launch_scales(const double* S, size_t L, double* sqrtS, double* invsqrtS, hipStream_t s) {
     hipLaunchKernelGGL(scales_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, s, S, L, sqrtS, invsqrtS);
 }
+__global__ void narrow_kernel(const double* __restrict__ src, size_t n, float* __restrict__ dst) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (float)src[i];
+}
+// fp32 image of the mixing matrix for the fp32 stream products: the kernels convert U to the compute type anyway, and at
+// 128 x 128 tiles the operand traffic (L2) is what bounds them -- 4-byte U elements cut it by a third
+void launch_narrow(const double* src, size_t n, float* dst, hipStream_t s) {
+    hipLaunchKernelGGL(narrow_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, n, dst);
+}
 // Ty[l][t] = S_l^-1/2 * sum_m U[m][l] Y[t][m]:  i = l, j = t, k = m;  A = U (i-contiguous, lda = L);  B = Y (k-contiguous, ldb = M)
-int launch_project_stream(int dtype, const void* Y, size_t T, size_t M, size_t L, const double* U, const double* S /* invsqrtS */, void* Ty, size_t ld,
-                          hipStream_t s) {
+int launch_project_stream(int dtype, const void* Y, size_t T, size_t M, size_t L, const double* U, const float* U32, const double* S /* invsqrtS */,
+                          void* Ty, size_t ld, hipStream_t s) {
     if (dtype == 0) return launch<double, double, double, true, true>(L, T, M, U, L, (const double*)Y, M, (double*)Ty, ld, S, 1, nullptr, 0, s);
+    if (U32) return launch<float, float, float, true, true>(L, T, M, U32, L, (const float*)Y, M, (float*)Ty, ld, S, 1, nullptr, 0, s);
     return launch<float, double, float, true, true>(L, T, M, U, L, (const float*)Y, M, (float*)Ty, ld, S, 1, nullptr, 0, s);
 }
 
 // Yhat[t][m] = sum_l Tyhat[l][t] * sqrt(S_l) * U[m][l]:  i = t, j = m, k = l;  A = Tyhat (i-contiguous, lda = ld);  B = U (k-contiguous, ldb = L)
-int launch_unproject_stream(int dtype, const void* Tyhat, size_t T, size_t ld, size_t M, size_t L, const double* U, const double* S /* sqrtS */,
-                            void* Yhat, hipStream_t s) {
+int launch_unproject_stream(int dtype, const void* Tyhat, size_t T, size_t ld, size_t M, size_t L, const double* U, const float* U32,
+                            const double* S /* sqrtS */, void* Yhat, hipStream_t s) {
     if (dtype == 0) return launch<double, double, double, true, true>(T, M, L, (const double*)Tyhat, ld, U, L, (double*)Yhat, M, nullptr, 0, S, 1, s);
+    if (U32) return launch<float, float, float, true, true>(T, M, L, (const float*)Tyhat, ld, U32, L, (float*)Yhat, M, nullptr, 0, S, 1, s);
     return launch<float, float, double, true, true>(T, M, L, (const float*)Tyhat, ld, U, L, (float*)Yhat, M, nullptr, 0, S, 1, s);
 }
 

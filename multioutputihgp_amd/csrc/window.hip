@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(256) window_finalize_kernel(size_t M, size_t L
 int launch_window_objective(const TickArgs& a, const double* cb64, const float* cb32, const WindowBufs& w, int* fallback, double* loss,
                             double* grad, hipStream_t s) {
     int rc;
-    if ((rc = launch_project_stream(0, w.Y, w.W, a.M, a.L, a.U, a.invsqrtS, w.Ty, w.ldw, s))) return rc;
+    if ((rc = launch_project_stream(0, w.Y, w.W, a.M, a.L, a.U, nullptr, a.invsqrtS, w.Ty, w.ldw, s))) return rc;
     if ((rc = launch_grad_stream(a.d, 0, w.Ty, w.W, w.ldw, a.L, cb64, cb32, w.x, w.dx, w.hx, w.nll, w.gl, fallback, s, /*out_mode=*/2))) return rc;
     dim3 b256(256);
     if (a.d == 2)
@@ -109,7 +109,7 @@ int launch_window_objective(const TickArgs& a, const double* cb64, const float* 
     else
         hipLaunchKernelGGL(window_z_kernel<3>, dim3((unsigned)((a.L + 3) / 4)), b256, 0, s, a.M, a.L, w.W, w.ldw, cb64, a.S, a.sigma, w.Y, w.Ty, w.hx, w.Z, w.spu);
     if ((rc = launch_ugrad_gemm(w.Y, w.W, a.M, w.Z, w.ldw, a.L, grad, s))) return rc;                         // grad[0 .. M*L) = U-gradient
-    if ((rc = launch_unproject_stream(0, w.Ty, w.W, w.ldw, a.M, a.L, a.U, a.sqrtS, w.UU, s))) return rc;           // U (U^T y_t)
+    if ((rc = launch_unproject_stream(0, w.Ty, w.W, w.ldw, a.M, a.L, a.U, nullptr, a.sqrtS, w.UU, s))) return rc;           // U (U^T y_t)
     hipLaunchKernelGGL(window_resid_kernel, dim3((unsigned)((w.W + 3) / 4)), b256, 0, s, a.M, w.W, w.Y, w.UU, w.rt);
     hipLaunchKernelGGL(window_finalize_kernel, dim3(1), b256, 0, s, a.M, a.L, w.W, a.S, a.sigma, w.rt, w.spu, w.nll, w.gl, loss, grad);
     hipError_t e = hipGetLastError();
