@@ -718,13 +718,11 @@ int launch_grad_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, si
         if (d == 2) { if (shortw) MOIHGP_GRAD_CASE(double, 2, 2, cb64); MOIHGP_GRAD_CASE(double, 2, 8, cb64); }
         if (shortw || ck_override == 2) MOIHGP_GRAD_CASE(double, 3, 2, cb64);
         if (ck_override == 4) MOIHGP_GRAD_CASE(double, 3, 4, cb64);
-        if (ck_override == 16) MOIHGP_GRAD_CASE(double, 3, 16, cb64);
         MOIHGP_GRAD_CASE(double, 3, 8, cb64);
     }
     if (d == 2) { if (shortw) MOIHGP_GRAD_CASE(float, 2, 4, cb32); MOIHGP_GRAD_CASE(float, 2, 16, cb32); }
     if (shortw || ck_override == 4) MOIHGP_GRAD_CASE(float, 3, 4, cb32);
     if (ck_override == 8) MOIHGP_GRAD_CASE(float, 3, 8, cb32);
-    if (ck_override == 32) MOIHGP_GRAD_CASE(float, 3, 32, cb32);
     MOIHGP_GRAD_CASE(float, 3, 16, cb32);           // measured: 16-tick chunks (236 VGPRs) 0.178 ms, 8-tick chunks (172) 0.228 ms at 4096 x 1e4
 #undef MOIHGP_GRAD_CASE
 }
