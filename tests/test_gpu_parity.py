@@ -405,8 +405,33 @@ def test_gradstream_vs_oracle(env, dtype, kern, L, T, nan):
     assert torch.equal(r2["grad"], r["grad"]) and torch.equal(r2["nll"], r["nll"])
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("kern", ["Matern32", "Matern52"])
+@pytest.mark.parametrize("T", [513, 1023, 1024, 1025, 2048, 2049, 3071])
+def test_gradstream_segment_boundaries_of_the_long_stream_kernels(env, dtype, kern, T):
+    """Streams one tick short of, exactly at and one tick past whole segments of the long-stream instantiations (512 ticks in fp64,
+    1024 in fp32): full segments run the unrolled single replay, the ragged rest the rolled one, and the carried (x, dx) and the
+    split gradient sums must join seamlessly."""
+    L = 3
+    rng = np.random.default_rng(T * 7 + (1 if kern == "Matern52" else 0))
+    prm = synth_params(L, rng)
+    bank = env["streams"].LatentBank(0.1, prm, kernel=KMAP[kern])
+    d = bank.d
+    Ty = synth(L, T, rng)
+    x0 = 0.2 * rng.standard_normal((L, d)); dx0 = 0.05 * rng.standard_normal((L, 3, d))
+    o = env["cref"].grad_stream(env["cref"].ihgp_array(kern, 0.1, prm), Ty, x0=x0, dx0=dx0)
+    r = bank.grad(to_dev(Ty, dtype), T=T, x=torch.from_numpy(x0).to(dtype).cuda(), dx=torch.from_numpy(dx0).to(dtype).cuda(), want_yhat=True)
+    torch.cuda.synchronize()
+    tol = 1e-9 if dtype == torch.float64 else FP32_TOL
+    assert rel_err(r["yhat"][:, :T].cpu().numpy(), o["yhat"]) < tol
+    assert rel_err(r["x"].cpu().numpy(), o["x"]) < tol and rel_err(r["dx"].cpu().numpy(), o["dx"]) < tol * 10
+    assert rel_err(r["nll"].cpu().numpy(), o["nll_per_latent"]) < tol
+    assert rel_err(r["grad"].cpu().numpy(), o["grad"]) < tol * 10
+
+
 # ------------------------------------------------------------------------------------------ windowed objective in one call
-@pytest.mark.parametrize("kern,M,L,W", [("Matern32", 6, 3, 5), ("Matern52", 8, 8, 16), ("Matern52", 70, 33, 128), ("Matern32", 300, 200, 40)])
+@pytest.mark.parametrize("kern,M,L,W", [("Matern32", 6, 3, 5), ("Matern52", 8, 8, 16), ("Matern52", 70, 33, 128), ("Matern32", 300, 200, 40),
+                                        ("Matern52", 6, 4, 1100)])     # the last one: predicted means out of full 512-tick segments
 def test_window_objective_vs_oracle_loop(env, kern, M, L, W):
     """moihgp_window_set/eval == the learners' loop (moihgp_online.h:61-70): step with sensitivities, NLL + gradient on the
     pre-step state, summed over the window; checked against the oracle's per-tick calls and against our own per-tick ABI."""
