@@ -630,6 +630,33 @@ def test_stacked_ragged_shapes_vs_oracle(env, kern, dtype, L, T):
     assert same(nll2, nll) and same(x2, xT) and same(x3, xT) and same(x4, xT) and same(yh3[:, :T], yhat[:, :T])
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("kern,L,T", [("Matern52x2", 3, 2047), ("Matern52x2", 3, 2048), ("Matern52x4", 2, 2049), ("Matern32x3", 3, 4096), ("Matern52x3", 2, 4097),
+                                      ("Matern52x4", 1024, 2048), ("Matern32x2", 1024, 4097), ("Matern52x2", 1030, 6144)])
+def test_stacked_segment_boundaries(env, kern, dtype, L, T):
+    """Streams ending exactly at, one tick short of and one tick past a 2048-tick segment, in the time-split kernels (few latents)
+    and in the four-waves-per-block kernels (L >= 1024): the single replay takes its carry-out at the tick where the stream ends."""
+    J = int(kern[-1])
+    rng = np.random.default_rng(13 * L + T + J)
+    prm = synth_params_stacked(L, J, rng)
+    bank = env["streams"].LatentBank(0.1, prm, kernel=kern)
+    x0 = 0.2 * rng.standard_normal((L, bank.d))
+    igps = env["cref"].ihgp_array(kern, 0.1, prm)
+    Ty = synth(L, T, rng)
+    o = env["cref"].filter_stream(igps, Ty, x0=x0, nthreads=8)
+    yhat, xT, nll = bank.filter(to_dev(Ty, dtype), T=T, x=torch.from_numpy(x0).to(dtype).cuda())
+    torch.cuda.synchronize()
+    tol = (FP64_TIGHT if dtype == torch.float64 else FP32_TOL) * 10
+    got, gx, gn = yhat[:, :T].cpu().numpy(), xT.cpu().numpy(), nll.cpu().numpy()
+    lim = 1e120 if dtype == torch.float64 else 1e15
+    ok = np.isfinite(o["nll_per_latent"]) & (np.abs(o["yhat"]).max(axis=1) < lim)      # latents the literal DARE leaves unstable: elsewhere
+    assert ok.sum() >= max(1, L // 2)
+    scale = np.abs(o["yhat"][ok]).max(axis=1, keepdims=True)
+    assert (np.abs(got[ok] - o["yhat"][ok]) / scale).max() < tol
+    assert rel_err(gn[ok], o["nll_per_latent"][ok]) < tol
+    assert (np.abs(gx[ok] - o["x"][ok]).max(axis=1) / np.maximum(np.abs(o["x"][ok]).max(axis=1), 1e-3 * scale[:, 0])).max() < tol * 10
+
+
 def test_stacked_mildly_unstable_latents_stay_on_the_scan_path(env):
     """The literal DARE (dare.h:23) leaves some stacked Matern-3/2 latents with rho(AKHA) slightly above 1 (these parameter
     sets come from the bench's own draw).  Their trajectories grow like rho^t but stay far inside fp64's range, and the
