@@ -190,8 +190,11 @@ int moihgp_window_eval(moihgp_gp* gp, const double* x, const double* dx, double*
  * moihgp_profile_enable(gp, n) the next n launches on this handle are bracketed by a HIP event pair
  * attached to the dispatch itself (hipExtLaunchKernel), not to the stream.  moihgp_profile_read waits
  * for them, writes the per-launch durations in milliseconds, rearms the slots and returns the count.
- * moihgp_profile_enable(gp, 0) turns it off. */
+ * moihgp_profile_enable(gp, 0) turns it off.  An event pair makes the dispatch it brackets wait for its predecessor and costs
+ * 3-6 us of launch overlap; moihgp_profile_stride(gp, k) attaches pairs to every k-th launch only (default 1), so a timed loop
+ * can sample its kernel durations without slowing every pass. */
 int moihgp_profile_enable(moihgp_gp* gp, int max_launches);
+int moihgp_profile_stride(moihgp_gp* gp, int stride);
 int moihgp_profile_read(moihgp_gp* gp, float* ms, int n);
 
 /* Page-lock a caller-owned HOST buffer that is passed again and again to the reference ABI (the params / grad staging arrays

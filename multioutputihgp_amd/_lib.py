@@ -21,7 +21,7 @@ ADDITIVE_SYMBOLS = [
     "moihgp_num_output", "moihgp_num_latent", "moihgp_reseed_U", "moihgp_new_latents",
     "moihgp_update_latents", "moihgp_set_mixing", "moihgp_get_latent", "moihgp_filter_stream", "moihgp_filter_stream_io", "moihgp_grad_stream",
     "moihgp_project_stream", "moihgp_unproject_stream", "moihgp_stream_sync",
-    "moihgp_profile_enable", "moihgp_profile_read", "moihgp_window_set", "moihgp_window_eval", "moihgp_pin_host_buffer",
+    "moihgp_profile_enable", "moihgp_profile_stride", "moihgp_profile_read", "moihgp_window_set", "moihgp_window_eval", "moihgp_pin_host_buffer",
 ]
 
 
@@ -93,6 +93,8 @@ def load_library():
     lib.moihgp_unproject_stream.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
     lib.moihgp_profile_enable.restype = C.c_int
     lib.moihgp_profile_enable.argtypes = [C.c_void_p, C.c_int]
+    lib.moihgp_profile_stride.restype = C.c_int
+    lib.moihgp_profile_stride.argtypes = [C.c_void_p, C.c_int]
     lib.moihgp_profile_read.restype = C.c_int
     lib.moihgp_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
     lib.moihgp_window_set.restype = C.c_int

@@ -85,6 +85,7 @@ struct moihgp_gp {
     double* dwin = nullptr;
     size_t win_cap = 0;
     // optional kernel-exact timing of filter launches (moihgp_profile_enable)
+    unsigned prof_stride = 1, prof_seen = 0;     // every prof_stride-th launch carries an event pair (moihgp_profile_stride)
     std::vector<hipEvent_t> prof_ev;
     int prof_n = 0;
 
@@ -534,7 +535,7 @@ int moihgp_filter_stream_io(moihgp_gp* gp, int dtype, const void* Ty, size_t T, 
     const char* ve = std::getenv("MOIHGP_FILTER_VARIANT");   // tuning hook: kernel tiling variant
     const int variant = ve ? std::atoi(ve) : 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (!gp->prof_ev.empty() && 2 * (size_t)(gp->prof_n + 1) <= gp->prof_ev.size()) {
+    if (!gp->prof_ev.empty() && 2 * (size_t)(gp->prof_n + 1) <= gp->prof_ev.size() && (gp->prof_seen++ % gp->prof_stride) == 0) {
         e0 = gp->prof_ev[2 * gp->prof_n];
         e1 = gp->prof_ev[2 * gp->prof_n + 1];
         gp->prof_n++;
@@ -570,11 +571,19 @@ int moihgp_profile_enable(moihgp_gp* gp, int max_launches) {
     for (hipEvent_t e : gp->prof_ev) (void)hipEventDestroy(e);
     gp->prof_ev.clear();
     gp->prof_n = 0;
+    gp->prof_seen = 0;
     for (int i = 0; i < 2 * max_launches; i++) {
         hipEvent_t e;
         MOIHGP_HIP_FATAL(hipEventCreate(&e));
         gp->prof_ev.push_back(e);
     }
+    return 0;
+}
+
+int moihgp_profile_stride(moihgp_gp* gp, int stride) {
+    if (!gp || stride < 1) { set_last_error("profile_stride: null handle or stride < 1"); return 1; }
+    gp->prof_stride = (unsigned)stride;
+    gp->prof_seen = 0;
     return 0;
 }
 
@@ -586,6 +595,7 @@ int moihgp_profile_read(moihgp_gp* gp, float* ms, int n) {
         MOIHGP_HIP_FATAL(hipEventElapsedTime(&ms[i], gp->prof_ev[2 * i], gp->prof_ev[2 * i + 1]));
     }
     gp->prof_n = 0;
+    gp->prof_seen = 0;
     return cnt;
 }
 

@@ -104,9 +104,11 @@ class LatentBank:
         out["iters"] = list(iters)
         return out
 
-    def profile_enable(self, max_launches: int):
-        """Attach HIP event pairs to the next `max_launches` filter dispatches (kernel-exact timing)."""
+    def profile_enable(self, max_launches: int, stride: int = 1):
+        """Attach HIP event pairs to filter dispatches (kernel-exact timing): to every `stride`-th one, `max_launches` pairs
+        at most.  A pair costs a few microseconds of launch overlap, so a timed loop samples rather than brackets every pass."""
         _check(self._lib.moihgp_profile_enable(self._h, int(max_launches)), self._lib)
+        _check(self._lib.moihgp_profile_stride(self._h, int(stride)), self._lib)
         self._prof_cap = int(max_launches)
 
     def profile_read(self):
