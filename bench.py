@@ -31,7 +31,12 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-PROFILE_STRIDE = 4     # every 4th filter launch of the timed region is bracketed by a HIP event pair
+# Every PROFILE_STRIDE-th filter launch of the timed region is bracketed by a HIP event pair.  A pair keeps its dispatch from
+# overlapping the tail of the launch before it and costs 3-6 us per pass (measured: C3 0.0676 -> 0.0650 ms per pass at stride 4,
+# C2 0.0268 -> 0.0223), but a bracketed launch that follows an un-bracketed one reads 1-2 us long (C3 60.2 us against 58.5 us with
+# every launch bracketed and 57.3-57.5 us in the rocprofv3 trace): the roofline figure wants the exact duration, so every launch
+# is bracketed and `value` carries that cost.
+PROFILE_STRIDE = 1
 
 CONFIGS = {
     # name: (L per GPU, T, dtype, kernel, description)
@@ -260,9 +265,6 @@ def main():
         total = one_pass()
     # kernel-exact durations: HIP event pairs attached to each filter dispatch of the timed region
     # (hipExtLaunchKernel, on the launch stream), read back after the region
-    # (an event pair keeps its dispatch from overlapping the previous one's tail and costs 3-6 us per pass, 5 % of a C3 pass
-    # and 25 % of a C2 pass: every PROFILE_STRIDE-th launch of the timed region carries one, the others run as they would in
-    # production; the rocprofv3 kernel trace of the same command, profiles/, sees every launch and agrees)
     bank.profile_enable((args.steps * nslab + PROFILE_STRIDE - 1) // PROFILE_STRIDE, stride=PROFILE_STRIDE)
     torch.cuda.synchronize()
     if world > 1:
@@ -325,7 +327,7 @@ def main():
                        "layout": "series-major [L][ld], HBM-resident", "sharding": f"latents x{world}, NLL scalar all-reduce per pass" + ("" if world == 1 else (" (stream-ordered)" if args.sync_allreduce else " (overlapped with the next pass)"))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "kernel": "filter_x_kernel" if bank.stacked else "filter_scan_kernel", "kernel_ms": kern_ms,
-                         "kernel_ms_from": f"HIP event pairs on {len(kern_samples)} of the {args.steps * nslab} launches of the timed region (every {PROFILE_STRIDE}th)",
+                         "kernel_ms_from": f"HIP event pairs on {len(kern_samples)} of the {args.steps * nslab} launches of the timed region",
                          "algorithmic_bytes_per_launch": alg_bytes, "frac_of_measured_copy_peak": achieved / HBM_COPY_GBPS,
                          # the other wall (mode F is 2 d^2 + 2 d flop per step; the d = 12 fp64 configuration sits on this one)
                          "vector_alu": valu_side(bank.d, dtype, L * min(slab, T) / (kern_ms * 1e-3))},
