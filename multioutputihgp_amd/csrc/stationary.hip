@@ -67,14 +67,17 @@ __device__ void ss_build(int kernel, const double* params, SS<D>& s) {
     (void)kernel;
 }
 
-// One workgroup of 64 lanes updates kLPB = 16 latents in three phases, so that the independent fixed-point chains of a latent
-// run side by side instead of one after the other on a single lane (the 100-iteration loops are latency chains):
-//   phase 1   lanes  0..15: A, Q, DARE, S, K, HA, AKHA (ihgp.h:120-133)     lanes 16..31: the 2d x 2d block expm of the one
+// One workgroup of four wavefronts updates kLPB = 16 latents (lane = latent) in three phases, so that the independent fixed-point
+// chains of a latent run side by side instead of one after the other (the 100-iteration loops are latency chains).  The roles
+// are split by WAVEFRONT, not by lane: lanes of one wavefront that take different branches run them one after the other, which is
+// what the first version did (16 latents per 64-lane block, roles by lane group: 0.27 ms for any latent count up to 4096).
+//   phase 1   wave 0: A, Q, DARE, S, K, HA, AKHA (ihgp.h:120-133)     wave 1: the 2d x 2d block expm of the one
 //             hyper-parameter with dF != 0, which does not depend on the DARE (ihgp.h:163-167)
-//   phase 2   lanes  0..47: one (latent, hyper-parameter) pair each: dQ, QLyap, DLyap, dS, dK, dAKHA, HdA (ihgp.h:136-200)
-//   phase 3   lanes  0..31: the scan tables of recursion.hip, one (latent, stream precision) pair each
+//   phase 2   waves 0..2: one hyper-parameter each: dQ, QLyap, DLyap, dS, dK, dAKHA, HdA (ihgp.h:136-200)
+//   phase 3   waves 0..1: the scan tables of recursion.hip, one stream precision each
 // Every quantity is computed by exactly the expressions of the one-lane evaluation, in the same order.
-constexpr int kLPB = 16;
+// kLPB latents per workgroup (lanes 0..kLPB-1 of the role waves): 16 for up to a few thousand latents (one workgroup per CU, phase 3
+// in two rounds), 64 beyond (four times fewer workgroups: 65536 latents 0.89 instead of 2.05 ms, 4096 latents 0.213 instead of 0.205).
 
 template <int D>
 struct Shared {               // per latent, in LDS
@@ -83,26 +86,26 @@ struct Shared {               // per latent, in LDS
     double S;
 };
 
-template <int D>
-__global__ void __launch_bounds__(64) ihgp_update_kernel(int kernel, double dt, const double* __restrict__ params,
+template <int D, int kLPB>
+__global__ void __launch_bounds__(256) ihgp_update_kernel(int kernel, double dt, const double* __restrict__ params,
                                                          size_t n, double* __restrict__ cb64, float* __restrict__ cb32,
                                                          int* __restrict__ n_unstable) {
     using L = CB<D>;
     constexpr int P = kNumIgpParam, NN = D * D;
     __shared__ Shared<D> sh[kLPB];
-    const int tid = threadIdx.x;
+    const int role = threadIdx.x >> 6, lane_l = threadIdx.x & 63;      // role: wave-uniform; lane_l: the latent within the block
     const size_t l0 = (size_t)blockIdx.x * kLPB;
 
     // ---- phase 1 ----
-    if (tid < 2 * kLPB) {
-        const int li = tid % kLPB;
+    if (role < 2 && lane_l < kLPB) {
+        const int li = lane_l;
         const size_t l = l0 + li;
         if (l < n) {
             double prm[3] = {params[l * 3 + 0], params[l * 3 + 1], params[l * 3 + 2]};
             SS<D> s;
             ss_build<D>(kernel, prm, s);
             Shared<D>& q = sh[li];
-            if (tid < kLPB) {
+            if (role == 0) {
                 double* o64 = cb64 + l * L::SIZE;
                 float* o32 = cb32 + l * L::SIZE;
                 auto put = [&](int off, double v) { o64[off] = v; o32[off] = (float)v; };
@@ -158,8 +161,8 @@ __global__ void __launch_bounds__(64) ihgp_update_kernel(int kernel, double dt, 
     __syncthreads();
 
     // ---- phase 2 ----
-    if (tid < P * kLPB) {
-        const int li = tid % kLPB, p = tid / kLPB;
+    if (role < P && lane_l < kLPB) {
+        const int li = lane_l, p = role;
         const size_t l = l0 + li;
         if (l < n) {
             double prm[3] = {params[l * 3 + 0], params[l * 3 + 1], params[l * 3 + 2]};
@@ -245,48 +248,62 @@ __global__ void __launch_bounds__(64) ihgp_update_kernel(int kernel, double dt, 
         }
     }
 
-    // ---- phase 3: tables of the segment solve (recursion.hip), one set per stream dtype because the chunk length differs ----
-    if (tid < 2 * kLPB) {
-        const int li = tid % kLPB, pass = tid / kLPB;
+    // ---- phase 3: tables of the segment solve (recursion.hip), one set per stream dtype because the chunk length differs.
+    // Sixteen lanes per (latent, precision): lane r builds PJ[r] = M^(r+1), row r of the response table g_r = AKHA^(ck-1-r) K and,
+    // for r < 4, SP[r] = M^(2^r), each from the binary powers AKHA^(1,2,4,8) and M^(1,2,4,8,16) (M = AKHA^ck) it forms itself;
+    // the sixteen lanes write one contiguous run of the block.  (One lane per pair walking all 16 powers and storing 250 scalars
+    // 2.9 KB apart from its neighbours took 76 of the kernel's 220 us.)  These tables are internal to this library: no order of
+    // evaluation to keep.
+    for (int item = threadIdx.x; item < kLPB * 2 * 16; item += 256) {
+        const int r = item & 15, pass = (item >> 4) & 1, li = item >> 5;
         const size_t l = l0 + li;
-        if (l < n) {
-            const Shared<D>& q = sh[li];
-            double* o64 = cb64 + l * L::SIZE;
-            float* o32 = cb32 + l * L::SIZE;
-            const int ck = pass == 0 ? kChunk64 : kChunk32;
-            double tab[L::SIZE - L::G];
-            for (int i = 0; i < L::SIZE - L::G; i++) tab[i] = 0.0;
-            double* G = tab;                       // [16][D]
-            double* SP = tab + (L::SP - L::G);      // [4][NN]
-            double* PJ = tab + (L::PJ - L::G);      // [16][NN]
-            double AKHA[NN], g[D], M[NN];
-            for (int i = 0; i < NN; i++) AKHA[i] = q.AKHA[i];
-            for (int i = 0; i < D; i++) g[i] = q.K[i];
-            for (int k = ck - 1; k >= 0; k--) {      // g_k = AKHA^(ck-1-k) K
-                for (int i = 0; i < D; i++) G[k * D + i] = g[i];
-                mv<D>(AKHA, g, g);
-            }
-            for (int i = 0; i < NN; i++) M[i] = AKHA[i];
-            for (int w = 1; w < ck; w <<= 1) mm<D>(M, M, M);   // M = AKHA^ck
-            double Pw[NN];
-            for (int i = 0; i < NN; i++) Pw[i] = M[i];
-            for (int lv = 0; lv < 4; lv++) {
-                for (int i = 0; i < NN; i++) SP[lv * NN + i] = Pw[i];
-                mm<D>(Pw, Pw, Pw);
-            }
-            for (int i = 0; i < NN; i++) Pw[i] = M[i];
-            for (int r = 0; r < 16; r++) {
-                for (int i = 0; i < NN; i++) PJ[r * NN + i] = Pw[i];
-                mm<D>(Pw, M, Pw);
-            }
-            // scan usable?  every entry finite and far from the overflow threshold of the block's precision
-            const double lim = pass == 0 ? 1e150 : 1e18;
-            bool ok = true;
-            for (int i = 0; i < L::SCANOK - L::G; i++) ok = ok && (fabs(tab[i]) < lim);      // false for NaN too
-            tab[L::SCANOK - L::G] = ok ? 1.0 : 0.0;
-            if (!ok) atomicAdd(&n_unstable[pass], 1);
-            if (pass == 0) for (int i = 0; i < L::SIZE - L::G; i++) o64[L::G + i] = tab[i];
-            else for (int i = 0; i < L::SIZE - L::G; i++) o32[L::G + i] = (float)tab[i];
+        if (l >= n) continue;                                        // (whole 16-lane groups leave together)
+        const Shared<D>& q = sh[li];
+        const int ck = pass == 0 ? kChunk64 : kChunk32;
+        double ak[4][NN], mp[5][NN];
+        for (int i = 0; i < NN; i++) ak[0][i] = q.AKHA[i];
+        for (int b = 1; b < 4; b++) mm<D>(ak[b - 1], ak[b - 1], ak[b]);          // AKHA^(2,4,8)
+        if (ck == 8) { for (int i = 0; i < NN; i++) mp[0][i] = ak[3][i]; }
+        else mm<D>(ak[3], ak[3], mp[0]);                                         // M = AKHA^ck, ck in {8, 16}
+        for (int b = 1; b < 5; b++) mm<D>(mp[b - 1], mp[b - 1], mp[b]);          // M^(2,4,8,16)
+        double pj[NN], g[D];
+        for (int i = 0; i < NN; i++) pj[i] = (i % (D + 1) == 0) ? 1.0 : 0.0;
+        for (int b = 0; b < 5; b++) {
+            double t[NN];
+            mm<D>(mp[b], pj, t);
+            const bool take = ((r + 1) >> b) & 1;
+            for (int i = 0; i < NN; i++) pj[i] = take ? t[i] : pj[i];
+        }
+        const int e = ck - 1 - r;                                    // exponent of this lane's row of the response table (< 0: no row)
+        for (int i = 0; i < D; i++) g[i] = q.K[i];
+        for (int b = 0; b < 4; b++) {
+            double t[D];
+            mv<D>(ak[b], g, t);
+            const bool take = e >= 0 && ((e >> b) & 1);
+            for (int i = 0; i < D; i++) g[i] = take ? t[i] : g[i];
+        }
+        if (e < 0) for (int i = 0; i < D; i++) g[i] = 0.0;
+        // scan usable?  every entry finite and far from the overflow threshold of the block's precision
+        const double lim = pass == 0 ? 1e150 : 1e18;
+        bool ok = true;
+        for (int i = 0; i < NN; i++) ok = ok && (fabs(pj[i]) < lim);                 // false for NaN too
+        for (int i = 0; i < D; i++) ok = ok && (fabs(g[i]) < lim);
+        double spv[NN];                                              // this lane's scan power M^(2^r), r < 4 (selected without indexing by r)
+        for (int i = 0; i < NN; i++) spv[i] = r == 0 ? mp[0][i] : (r == 1 ? mp[1][i] : (r == 2 ? mp[2][i] : mp[3][i]));
+        if (r < 4) for (int i = 0; i < NN; i++) ok = ok && (fabs(spv[i]) < lim);
+        const unsigned long long bal = __ballot(ok);
+        const int grp = (threadIdx.x & 63) >> 4;
+        const bool all_ok = ((bal >> (16 * grp)) & 0xFFFFull) == 0xFFFFull;
+        double* o64 = cb64 + l * L::SIZE;
+        float* o32 = cb32 + l * L::SIZE;
+        auto put = [&](int off, double v) { if (pass == 0) o64[off] = v; else o32[off] = (float)v; };
+        for (int i = 0; i < D; i++) put(L::G + r * D + i, g[i]);
+        for (int i = 0; i < NN; i++) put(L::PJ + r * NN + i, pj[i]);
+        if (r < 4) for (int i = 0; i < NN; i++) put(L::SP + r * NN + i, spv[i]);
+        if (r == 0) {
+            for (int i = L::SCANOK; i < L::SIZE; i++) put(i, 0.0);
+            put(L::SCANOK, all_ok ? 1.0 : 0.0);
+            if (!all_ok) atomicAdd(&n_unstable[pass], 1);
         }
     }
 }
@@ -297,11 +314,15 @@ void launch_ihgp_update(int kernel, int d, double dt, const double* params_dev, 
                         int* n_unstable, hipStream_t stream) {
     if (n == 0) return;
     MOIHGP_HIP_FATAL(hipMemsetAsync(n_unstable, 0, 2 * sizeof(int), stream));
-    dim3 block(64), grid((unsigned)((n + kLPB - 1) / kLPB));
-    if (d == 2)
-        hipLaunchKernelGGL(ihgp_update_kernel<2>, grid, block, 0, stream, kernel, dt, params_dev, n, cb64, cb32, n_unstable);
-    else
-        hipLaunchKernelGGL(ihgp_update_kernel<3>, grid, block, 0, stream, kernel, dt, params_dev, n, cb64, cb32, n_unstable);
+    const bool many = n > 8192;
+    dim3 block(256), grid((unsigned)((n + (many ? 64 : 16) - 1) / (many ? 64 : 16)));
+    if (d == 2) {
+        if (many) hipLaunchKernelGGL((ihgp_update_kernel<2, 64>), grid, block, 0, stream, kernel, dt, params_dev, n, cb64, cb32, n_unstable);
+        else hipLaunchKernelGGL((ihgp_update_kernel<2, 16>), grid, block, 0, stream, kernel, dt, params_dev, n, cb64, cb32, n_unstable);
+    } else {
+        if (many) hipLaunchKernelGGL((ihgp_update_kernel<3, 64>), grid, block, 0, stream, kernel, dt, params_dev, n, cb64, cb32, n_unstable);
+        else hipLaunchKernelGGL((ihgp_update_kernel<3, 16>), grid, block, 0, stream, kernel, dt, params_dev, n, cb64, cb32, n_unstable);
+    }
     MOIHGP_HIP_FATAL(hipGetLastError());
 }
 
