@@ -143,18 +143,11 @@ __global__ void __launch_bounds__(256) ihgp_update_kernel(int kernel, double dt,
                 for (int p = 0; p < P; p++) put(L::PARAMS + p, prm[p]);
             } else {
                 // the lengthscale is the only hyper-parameter with dF != 0 in both models (matern32ss.h:57-58, matern52ss.h:62-64)
-                constexpr int M2 = 2 * D;
-                double FF[M2 * M2], EF[M2 * M2];
-                for (int i = 0; i < M2 * M2; i++) FF[i] = 0.0;
-                for (int i = 0; i < D; i++)
-                    for (int j = 0; j < D; j++) {                                   // ihgp.h:163-166
-                        FF[i * M2 + j] = dt * s.F[i * D + j];
-                        FF[(D + i) * M2 + (D + j)] = dt * s.F[i * D + j];
-                        FF[(D + i) * M2 + j] = dt * s.dF[1][i * D + j];
-                    }
-                expm<M2>(FF, EF);
-                for (int i = 0; i < D; i++)
-                    for (int j = 0; j < D; j++) q.dA1[i * D + j] = EF[(D + i) * M2 + j];   // ihgp.h:167
+                // exp of dt [[F, 0], [dF, F]] (ihgp.h:163-166), evaluated on its blocks; dA is the lower left one (ihgp.h:167)
+                double X[NN], Y[NN], EX[NN], EY[NN];
+                for (int i = 0; i < NN; i++) { X[i] = dt * s.F[i]; Y[i] = dt * s.dF[1][i]; }
+                expm_blt<D>(X, Y, EX, EY);
+                for (int i = 0; i < NN; i++) q.dA1[i] = EY[i];
             }
         }
     }
