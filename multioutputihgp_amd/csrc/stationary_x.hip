@@ -139,19 +139,13 @@ __global__ void __launch_bounds__(64) stack_update_kernel(double dt, const doubl
         const int j = lane - 16;
         double F[BB], Pj[BB], dFl[BB], dPm[BB], dPl[BB];
         component<DB>(prm[2 * j], prm[2 * j + 1], F, Pj, dFl, dPm, dPl);
-        constexpr int M2 = 2 * DB;
-        double FF[M2 * M2], EF[M2 * M2];
-        for (int i = 0; i < M2 * M2; i++) FF[i] = 0.0;
+        // evaluated on its blocks (expm_blt: [[F, 0], [dF, F]] is block lower triangular); dA_j is the lower left block
+        double X[BB], Y[BB], EX[BB], EY[BB];
+        for (int i = 0; i < BB; i++) { X[i] = dt * F[i]; Y[i] = dt * dFl[i]; }
+        expm_blt<DB>(X, Y, EX, EY);
         for (int a = 0; a < DB; a++)
             for (int b = 0; b < DB; b++) {
-                FF[a * M2 + b] = dt * F[a * DB + b];
-                FF[(DB + a) * M2 + (DB + b)] = dt * F[a * DB + b];
-                FF[(DB + a) * M2 + b] = dt * dFl[a * DB + b];
-            }
-        expm<M2>(FF, EF);
-        for (int a = 0; a < DB; a++)
-            for (int b = 0; b < DB; b++) {
-                sdAb[j][a * DB + b] = EF[(DB + a) * M2 + b];
+                sdAb[j][a * DB + b] = EY[a * DB + b];
                 sdPm[j][a * DB + b] = dPm[a * DB + b];
                 sdPl[j][a * DB + b] = dPl[a * DB + b];
             }
