@@ -833,8 +833,13 @@ def test_filter_fuzz_vs_oracle(env, kern, L, T, nanf, dt_, seed):
     assert np.abs(yg[tame] - yo[tame]).max() / scale < tol * 10, (kern, L, T, nanf, dt_)
     xscale = max(np.abs(o["x"][tame]).max(), 1e-6 * np.abs(x0).max())         # (an all-missing stream decays the state to ~0)
     assert np.abs(xT.cpu().numpy()[tame] - o["x"][tame]).max() / xscale < tol * 10
-    nscale = max(np.abs(o["nll_per_latent"][tame]).max(), 1e-300)
-    assert np.abs(nll.cpu().numpy()[tame] - o["nll_per_latent"][tame]).max() / nscale < tol * 10
+    # (the kernel sums v^2 per chunk in the stream's precision: a trajectory beyond ~1e18 squares out of fp32's range, where the
+    # fp64 reference still holds a finite 1e38-sized NLL -- seen for literal-DARE unstable latents that a 2048-tick stream
+    # carries to 5e19; such latents are compared on their means and state only)
+    ntame = tame & (np.nan_to_num(np.abs(yo), nan=0.0, posinf=np.inf).max(axis=1) < (1e100 if dtype == torch.float64 else 1e17))
+    if ntame.any():
+        nscale = max(np.abs(o["nll_per_latent"][ntame]).max(), 1e-300)
+        assert np.abs(nll.cpu().numpy()[ntame] - o["nll_per_latent"][ntame]).max() / nscale < tol * 10
 
 
 def _grad_fuzz_cases(n, seed):
