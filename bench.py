@@ -221,7 +221,7 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    from multioutputihgp_amd.sharded import allreduce_nll, allreduce_nll_async, shard_bounds
+    from multioutputihgp_amd.sharded import allreduce_nll, allreduce_nll_async, allreduce_total, allreduce_total_async, shard_bounds
     from multioutputihgp_amd.streams import LatentBank
 
     if args.config == "c1":
@@ -250,11 +250,16 @@ def main():
 
     x_zero = torch.zeros_like(x)               # every pass starts from this state; it is never written
 
+    tot_ring = [torch.zeros((1,), dtype=torch.float64, device=device) for _ in range(4)]   # NLL totals of the passes in flight
+    pass_no = [0]
+
     def one_pass(reduce=allreduce_nll):
         if nslab == 1:
-            bank.filter(Ty, T=T, x=x, x_start=x_zero, yhat=yhat, nll=nll)
-            return reduce(nll)                 # the path's only exchange: 8 bytes, SUM (local sum by torch: measured faster than
-                                               # the library's own one-workgroup total, 69.9 vs 72.3 us per pass)
+            # the library queues its own one-workgroup total behind the sweep (measured against torch's .sum() on this shape:
+            # 58.7 vs 59.8-61.2 us per pass); the path's only exchange is the all-reduce of that 8-byte scalar
+            tot = tot_ring[pass_no[0] % len(tot_ring)]; pass_no[0] += 1
+            bank.filter(Ty, T=T, x=x, x_start=x_zero, yhat=yhat, nll=nll, nll_total=tot)
+            return (allreduce_total_async if reduce is allreduce_nll_async else allreduce_total)(tot)
         nll_acc.zero_()
         for k in range(nslab):                 # slabs carry the state x from one launch to the next
             bank.filter(Ty_slabs[k], T=Ty_slabs[k].shape[1], x=x, x_start=x_zero if k == 0 else None, yhat=yhat_slabs[k], nll=nll)

@@ -21,16 +21,21 @@ def shard_bounds(L: int, world_size: int, rank: int) -> Tuple[int, int]:
     return lo, lo + q + (1 if rank < r else 0)
 
 
-def allreduce_nll(nll_local: torch.Tensor, group=None) -> torch.Tensor:
-    """Sum of the per-latent NLLs over all shards: one fp64 scalar all-reduce (SUM)."""
-    total = nll_local.sum(dtype=torch.float64).reshape(1)
+def allreduce_total(total: torch.Tensor, group=None) -> torch.Tensor:
+    """All-reduce (SUM) of a rank's fp64 NLL total -- a 1-element tensor, e.g. the `nll_total` of LatentBank.filter -- in place."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         if total.is_cuda and dist.get_backend(group) == "gloo":      # CPU rehearsal of the exchange
             t = total.cpu()
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-            return t.to(total.device)
+            total.copy_(t)
+            return total
         dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
     return total
+
+
+def allreduce_nll(nll_local: torch.Tensor, group=None) -> torch.Tensor:
+    """Sum of the per-latent NLLs over all shards: one fp64 scalar all-reduce (SUM)."""
+    return allreduce_total(nll_local.sum(dtype=torch.float64).reshape(1), group)
 
 
 class PendingSum:
@@ -48,17 +53,22 @@ class PendingSum:
         return self._total
 
 
-def allreduce_nll_async(nll_local: torch.Tensor, group=None) -> PendingSum:
-    """As allreduce_nll, but the collective runs on the communicator's own stream and the caller's stream does not wait for it:
-    the next sweep overlaps the 8-byte exchange of this one (slabs of a long stream, pipelined objective evaluations).  The
-    local sum is taken in stream order first, so the per-latent buffer may be overwritten right away."""
-    total = nll_local.sum(dtype=torch.float64).reshape(1)
+def allreduce_total_async(total: torch.Tensor, group=None) -> PendingSum:
+    """As allreduce_total, but the collective runs on the communicator's own stream and the caller's stream does not wait for it.
+    `total` must not be rewritten before `.wait()` (use a small ring of totals for passes in flight)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         if total.is_cuda and dist.get_backend(group) == "gloo":      # CPU rehearsal of the exchange
             t = total.cpu()
             return PendingSum(total, dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True), host=t)
         return PendingSum(total, dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group, async_op=True))
     return PendingSum(total)
+
+
+def allreduce_nll_async(nll_local: torch.Tensor, group=None) -> PendingSum:
+    """As allreduce_nll, but the collective runs on the communicator's own stream and the caller's stream does not wait for it:
+    the next sweep overlaps the 8-byte exchange of this one (slabs of a long stream, pipelined objective evaluations).  The
+    local sum is taken in stream order first, so the per-latent buffer may be overwritten right away."""
+    return allreduce_total_async(nll_local.sum(dtype=torch.float64).reshape(1), group)
 
 
 def gather_latent_grads(grad_local: torch.Tensor, L: int, group=None) -> torch.Tensor:
