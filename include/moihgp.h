@@ -34,9 +34,15 @@ extern "C" {
 /* Opaque handle; the reference returns `GP32*` / `GP52*` (src/wrapper.cpp:21-22).            */
 typedef struct moihgp_gp moihgp_gp;
 
-/* replaces src/wrapper.cpp:31-34  (MOIHGP ctor, include/moihgp/moihgp.h:81-136).  `threading`
- * is accepted and ignored: it only selects the reference's per-call pthread fan-out
- * (moihgp.h:184-214), which the GPU replaces. */
+/* replaces src/wrapper.cpp:31-34  (MOIHGP ctor, include/moihgp/moihgp.h:81-136).  `threading` selects the
+ * reference's per-call pthread fan-out (moihgp.h:184-214), which the GPU replaces -- but the flag is OBSERVABLE in
+ * the reference and is honoured here: the gradient overload of negLogLikelihood adds the per-latent losses only
+ * on its threaded branch (moihgp.h:590); the serial branch (:597-607) computes the per-latent gradients and drops
+ * the losses.  So with threading == false (the default of pywrapper.py:12, online_learning.py:12, example.py:37;
+ * forced for num_latent < 2 by moihgp.h:128-135) gpXX_lik1 returns 1/2 log(sum S) + 1/2 (M-L)+ log sigma +
+ * 1/2 ||(I-UU^T)y|| / sigma alone, with threading == true the same plus sum_l 1/2 (v_l^2/S_l + log S_l) (= gpXX_lik2).
+ * The gradient is the same in both.  MOIHGP_LIK1_FULL_LOSS=1 (read at construction) selects the summed form
+ * regardless of the flag. */
 moihgp_gp* gp32_new(double dt, size_t num_output, size_t num_latent, bool threading);
 /* replaces src/wrapper.cpp:37-40 (which runs the destructor but leaks the object; we free it) */
 void   gp32_del(moihgp_gp* gp);
@@ -105,6 +111,11 @@ moihgp_gp*  moihgp_new(int kernel, double dt, size_t num_output, size_t num_late
 void        moihgp_del(moihgp_gp* gp);
 size_t      moihgp_num_output(moihgp_gp* gp);
 size_t      moihgp_num_latent(moihgp_gp* gp);
+/* The `threading` constructor argument of moihgp.h:81 for objects made by moihgp_new (which start with it off), with the
+ * override of moihgp.h:128-135 (num_latent < 2: always off).  It decides the value gpXX_lik1 / moihgp_window_eval return
+ * (see gp32_new above). */
+void        moihgp_set_threading(moihgp_gp* gp, int threading);
+int         moihgp_get_threading(moihgp_gp* gp);
 
 /* Deterministic counterpart of the ctor's random U (moihgp.h:103-125 uses std::random_device):
  * reseeds and redraws U = polar(I + N(0,1e-3)) from a fixed 64-bit seed. */
@@ -129,6 +140,15 @@ int         moihgp_set_mixing(moihgp_gp* gp, const double* U, const double* S, d
  * by the reference; exposed here for diagnosis). */
 int         moihgp_get_latent(moihgp_gp* gp, size_t l, double* A, double* K, double* S, double* HA, double* AKHA,
                               double* dA, double* dS, double* dK, double* dAKHA, double* HdA, int* iters);
+
+/* ---- ordering contract of the batched entries ---------------------------------------------------
+ * moihgp_filter_stream(_io), moihgp_grad_stream, moihgp_project_stream and moihgp_unproject_stream are ASYNCHRONOUS on the
+ * stream the caller passes and read the handle's per-latent tables and mixing.  gpXX_update, moihgp_update_latents,
+ * moihgp_set_mixing and moihgp_reseed_U rewrite those; they (a) first make their internal stream wait for everything enqueued so
+ * far on every stream that carried batched work of this handle, so a rewrite never overtakes a sweep that is still in flight,
+ * and (b) return only when the new tables are complete, so batched work enqueued afterwards on any stream sees them.  Buffers
+ * the caller owns (streams, states, nll, grad) are ordered by the caller's own stream discipline as usual.  A handle is not
+ * thread-safe (as the reference object, moihgp.h:431-457 mutates shared matrices): one host thread at a time. */
 
 /* ---- batched recursion over pre-projected streams (DEVICE pointers) -------------------------
  * The stream is SERIES-MAJOR: Ty[l*ld + t], l < L (latents owned by gp), t < T, element type per
@@ -177,7 +197,8 @@ int moihgp_unproject_stream(moihgp_gp* gp, int dtype, const void* Tyhat, size_t 
 /* ---- the learners' windowed objective as one call (HOST pointers, fp64) -----------------------------
  * One evaluation of the loop of moihgp_online.h:61-70 / moihgp_regression.h:42-50 / online_learning.py:83-89:
  *     for t < W:  step(x, y_t, dx, xnew, dxnew);  loss += negLogLikelihood(x, y_t, dx, g);  grad += g;  x = xnew;  dx = dxnew
- * with the object's current parameters (set them with gpXX_update first, moihgp_online.h:43).
+ * with the object's current parameters (set them with gpXX_update first, moihgp_online.h:43).  `loss` is the sum of what
+ * gpXX_lik1 returns per tick, i.e. it follows the object's `threading` flag (moihgp.h:590 vs :597-607, see gp32_new).
  * moihgp_window_set uploads the window Y [W][M] (tick-major, already de-meaned by the caller) once; it stays
  * resident for all evaluations of one L-BFGS solve.  Returns 3 if Y contains NaN (missing outputs need the
  * per-tick least-squares projection, moihgp.h:167-178: use the per-tick ABI for such windows).

@@ -33,9 +33,11 @@ public:
     // moihgp.h:81  MOIHGP(dt, num_output, num_latent, threading)
     MOIHGP(const double& dt, const size_t& num_output, const size_t& num_latent, const bool& threading = false)
         : _num_output(num_output), _num_latent(num_latent) {
-        (void)threading;                                  // selects the reference's pthread fan-out only (moihgp.h:184-214)
         _gp = moihgp_new(StateSpace::kernel_id, dt, num_output, num_latent);
         if (!_gp) throw std::runtime_error(std::string("moihgp::MOIHGP: ") + moihgp_last_error());
+        // no pthread fan-out here (moihgp.h:184-214), but the flag decides what negLogLikelihood(x, y, dx, grad) RETURNS in the
+        // reference (moihgp.h:590 vs :597-607) and the library honours that; it applies the L < 2 override of :128-135 itself
+        moihgp_set_threading(_gp, threading ? 1 : 0);
         _dim = gp32_igp_dim(_gp);
         _igp_num_param = gp32_num_igp_param(_gp);
         _num_param = gp32_num_param(_gp);

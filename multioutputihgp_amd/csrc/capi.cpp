@@ -52,6 +52,10 @@ struct moihgp_gp {
     int d = 2, P = kNumIgpParam;
     size_t num_param = 0;
     bool latents_only = false;
+    // moihgp.h:747 `_threading` (ctor argument, forced off for L < 2 by :128-135).  There is no pthread fan-out here, but the flag
+    // is observable in the reference: the gradient overload of negLogLikelihood returns the per-latent losses only on its threaded
+    // branch (:590), the serial branch (:597-607) drops them.  lik1_full (MOIHGP_LIK1_FULL_LOSS=1) asks for the summed form always.
+    bool threading = false, lik1_full = false;
     // host mirrors of the parameters (moihgp.h:741-744 + per-latent matern*ss.h:_params)
     std::vector<double> U, S, igp;
     double sigma = 1e-2;
@@ -80,6 +84,10 @@ struct moihgp_gp {
     bool fused_ok = false;
     bool polar_pending = false;                                 // a small-matrix polar factor whose verdict has not been read yet
     std::vector<void*> pinned; // caller buffers page-locked through moihgp_pin_host_buffer
+    // caller streams that carried batched work of this handle since the last rewrite of its tables / mixing, and the event used to
+    // make the handle's own stream wait for them before the next rewrite (order_after_sweeps)
+    std::vector<hipStream_t> user_streams;
+    hipEvent_t order_ev = nullptr;
     // window objective (moihgp_window_set / moihgp_window_eval)
     WindowBufs win{};
     double* dwin = nullptr;
@@ -89,7 +97,7 @@ struct moihgp_gp {
     std::vector<hipEvent_t> prof_ev;
     int prof_n = 0;
 
-    TickArgs tick() const { return TickArgs{d, M, L, cb64, dU, dS, dsqrtS, dinvsqrtS, dsigma}; }
+    TickArgs tick() const { return TickArgs{d, M, L, cb64, dU, dS, dsqrtS, dinvsqrtS, dsigma, (threading || lik1_full) ? 1 : 0}; }
 };
 
 static void gp_free(moihgp_gp* g) {
@@ -103,21 +111,47 @@ static void gp_free(moihgp_gp* g) {
     if (g->hgrad) (void)hipHostFree(g->hgrad);
     if (g->hflag) (void)hipHostFree(g->hflag);
     for (hipEvent_t e : g->prof_ev) (void)hipEventDestroy(e);
+    if (g->order_ev) (void)hipEventDestroy(g->order_ev);
     if (g->stream) (void)hipStreamDestroy(g->stream);
     delete g;
 }
 
+// The batched entries (moihgp_filter_stream*, moihgp_grad_stream, moihgp_project/unproject_stream) are asynchronous on the CALLER's
+// stream and read the constant blocks and the mixing; update / update_latents / set_mixing / reseed_U rewrite those on the handle's
+// own (non-blocking) stream.  note_user_stream remembers which streams carried such work; order_after_sweeps, called before every
+// rewrite, makes the handle's stream wait for everything those streams hold at that moment, so a rewrite issued while sweeps are still
+// in flight (pipelined objective evaluations followed by an update) cannot overwrite tables under them.  Nothing is recorded per
+// launch: the hot path pays nothing.
+static void note_user_stream(moihgp_gp* g, hipStream_t s) {
+    for (hipStream_t u : g->user_streams) if (u == s) return;
+    g->user_streams.push_back(s);
+}
+static void order_after_sweeps(moihgp_gp* g) {
+    if (g->user_streams.empty()) return;
+    if (!g->order_ev) MOIHGP_HIP_FATAL(hipEventCreateWithFlags(&g->order_ev, hipEventDisableTiming));
+    for (hipStream_t u : g->user_streams) {
+        if (hipEventRecord(g->order_ev, u) != hipSuccess) { (void)hipGetLastError(); continue; }   // a stream the caller has destroyed since
+        MOIHGP_HIP_FATAL(hipStreamWaitEvent(g->stream, g->order_ev, 0));
+    }
+    g->user_streams.clear();
+}
+
 static void upload_mixing(moihgp_gp* g) {
     if (g->latents_only) return;
+    order_after_sweeps(g);
     g->u32_valid = false;
     if (!g->U_host_stale)    // otherwise the device copy is the current one (device polar factor)
         MOIHGP_HIP_FATAL(hipMemcpyAsync(g->dU, g->U.data(), sizeof(double) * g->M * g->L, hipMemcpyHostToDevice, g->stream));
     MOIHGP_HIP_FATAL(hipMemcpyAsync(g->dS, g->S.data(), sizeof(double) * g->L, hipMemcpyHostToDevice, g->stream));
     launch_scales(g->dS, g->L, g->dsqrtS, g->dinvsqrtS, g->stream);
     MOIHGP_HIP_FATAL(hipMemcpyAsync(g->dsigma, &g->sigma, sizeof(double), hipMemcpyHostToDevice, g->stream));
+    // fp32 image of the mixing for the fp32 stream products, once somebody has asked for it: rebuilt here, on the handle's stream
+    // (every caller of upload_mixing synchronises it), so that the batched entries only ever READ it, whatever stream they run on
+    if (g->dU32) { launch_narrow(g->dU, g->M * g->L, g->dU32, g->stream); g->u32_valid = true; }
 }
 
 static void run_ihgp_update(moihgp_gp* g) {
+    order_after_sweeps(g);
     MOIHGP_HIP_FATAL(hipMemcpyAsync(g->dparams, g->igp.data(), sizeof(double) * g->L * g->P, hipMemcpyHostToDevice, g->stream));
     if (kernel_stack(g->kernel)) {
         // the sensitivities cost nine more 100-iteration Lyapunov solves per latent at d = 12: only for handles that use them
@@ -146,7 +180,7 @@ static void draw_U(moihgp_gp* g, unsigned long long seed, bool use_seed) {
     compute_polar_fwd(g, I.data());
 }
 
-static moihgp_gp* gp_create(int kernel, double dt, size_t M, size_t L, bool latents_only, const double* params_LP) {
+static moihgp_gp* gp_create(int kernel, double dt, size_t M, size_t L, bool latents_only, const double* params_LP, bool threading = false) {
     g_last_error[0] = 0;
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -170,6 +204,8 @@ static moihgp_gp* gp_create(int kernel, double dt, size_t M, size_t L, bool late
     }
     moihgp_gp* g = new moihgp_gp();
     g->kernel = kernel; g->dt = dt; g->M = M; g->L = L; g->latents_only = latents_only;
+    g->threading = (L < 2) ? false : threading;                          // moihgp.h:128-135
+    { const char* fl = std::getenv("MOIHGP_LIK1_FULL_LOSS"); g->lik1_full = fl && fl[0] == '1'; }
     g->d = (kbase == MOIHGP_MATERN32) ? 2 : 3;                           // matern32ss.h:95, matern52ss.h:106
     if (kstack) { g->d *= kstack; g->P = 2 * kstack + 1; }               // (magnitude_j, lengthscale_j) x J, noise
     g->num_param = M * L + L + 1 + L * g->P;                             // moihgp.h:93
@@ -330,6 +366,7 @@ static bool compute_polar(moihgp_gp* g, const double* Uparam) {
     const size_t M = g->M, L = g->L;
     bool small = polar_small_fits(M, L);
     if (const char* e = std::getenv("MOIHGP_POLAR")) { if (e[0] == 'g') small = false; }
+    order_after_sweeps(g);
     g->u32_valid = false;
     MOIHGP_HIP_FATAL(hipMemcpyAsync(g->dU, Uparam, sizeof(double) * M * L, hipMemcpyHostToDevice, g->stream));
     int its = 0;
@@ -394,8 +431,7 @@ extern "C" {
 
 #define MOIHGP_DEFINE_REFERENCE_ABI(PFX, KERNEL_EXPR)                                                                   \
     moihgp_gp* PFX##_new(double dt, size_t num_output, size_t num_latent, bool threading) {                             \
-        (void)threading;                                                                                                 \
-        return gp_create((KERNEL_EXPR), dt, num_output, num_latent, false, nullptr);                                     \
+        return gp_create((KERNEL_EXPR), dt, num_output, num_latent, false, nullptr, threading);                          \
     }                                                                                                                    \
     void PFX##_del(moihgp_gp* gp) { gp_free(gp); }                                                                       \
     void PFX##_step1(moihgp_gp* gp, double* x, double* y, double* dx, double* xnew, double* yhat, double* dxnew) {       \
@@ -437,6 +473,8 @@ moihgp_gp* moihgp_new(int kernel, double dt, size_t num_output, size_t num_laten
 void moihgp_del(moihgp_gp* gp) { gp_free(gp); }
 size_t moihgp_num_output(moihgp_gp* gp) { return gp->M; }
 size_t moihgp_num_latent(moihgp_gp* gp) { return gp->L; }
+void moihgp_set_threading(moihgp_gp* gp, int threading) { if (gp) gp->threading = (gp->L < 2) ? false : (threading != 0); }   // moihgp.h:128-135
+int moihgp_get_threading(moihgp_gp* gp) { return gp && gp->threading ? 1 : 0; }
 
 void moihgp_reseed_U(moihgp_gp* gp, unsigned long long seed) {
     if (gp->latents_only) return;
@@ -529,6 +567,7 @@ int moihgp_filter_stream_io(moihgp_gp* gp, int dtype, const void* Ty, size_t T, 
                             double* nll_total, void* stream) {
     if (int rc = check_stream_args(gp, dtype, Ty, T, ld, x)) return rc;
     if (!x_in) { set_last_error("null start state"); return 1; }
+    note_user_stream(gp, (hipStream_t)stream);
     if (nll_total && !nll) { set_last_error("nll_total needs the per-latent nll buffer"); return 1; }
     if (nll_total && T == 0) MOIHGP_HIP_FATAL(hipMemsetAsync(nll_total, 0, sizeof(double), (hipStream_t)stream));
     if (yhat && ((uintptr_t)yhat & 15) != 0) { set_last_error("yhat base must be 16-byte aligned"); return 1; }
@@ -604,30 +643,37 @@ int moihgp_grad_stream(moihgp_gp* gp, int dtype, const void* Ty, size_t T, size_
     if (int rc = check_stream_args(gp, dtype, Ty, T, ld, x)) return rc;
     if (!dx || !grad) { set_last_error("grad_stream: dx and grad are required"); return 1; }
     ensure_sensitivities(gp);
+    note_user_stream(gp, (hipStream_t)stream);
     if (kernel_stack(gp->kernel))
         return launch_grad_stream_x(gp->kernel, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cbd64, x, dx, yhat, nll, grad, (hipStream_t)stream);
     return launch_grad_stream(gp->d, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cb32, x, dx, yhat, nll, grad, gp->dfallback, (hipStream_t)stream);
 }
 
-// fp32 image of the mixing matrix, (re)built on the caller's stream the first time an fp32 stream product needs it after U changed
-// (update() has synchronised its own stream by then)
-static const float* mixing_f32(moihgp_gp* gp, hipStream_t stream) {
+// fp32 image of the mixing matrix: allocated and built (on the handle's stream, synchronised) the first time an fp32 stream product
+// asks for it, kept current by upload_mixing from then on -- the batched entries only read it
+static const float* mixing_f32(moihgp_gp* gp) {
     if (!gp->dU32) gp->dU32 = dev_alloc<float>(gp->M * gp->L);
-    if (!gp->u32_valid) { launch_narrow(gp->dU, gp->M * gp->L, gp->dU32, stream); gp->u32_valid = true; }
+    if (!gp->u32_valid) {
+        launch_narrow(gp->dU, gp->M * gp->L, gp->dU32, gp->stream);
+        MOIHGP_HIP_FATAL(hipStreamSynchronize(gp->stream));
+        gp->u32_valid = true;
+    }
     return gp->dU32;
 }
 
 int moihgp_project_stream(moihgp_gp* gp, int dtype, const void* Y, size_t T, void* Ty, size_t ld, void* stream) {
     if (!gp || gp->latents_only) { set_last_error("project_stream needs a full MOIHGP object"); return 1; }
     if (ld < T) { set_last_error("ld < T"); return 1; }
-    return launch_project_stream(dtype, Y, T, gp->M, gp->L, gp->dU, dtype == MOIHGP_F64 ? nullptr : mixing_f32(gp, (hipStream_t)stream), gp->dinvsqrtS, Ty, ld,
+    note_user_stream(gp, (hipStream_t)stream);
+    return launch_project_stream(dtype, Y, T, gp->M, gp->L, gp->dU, dtype == MOIHGP_F64 ? nullptr : mixing_f32(gp), gp->dinvsqrtS, Ty, ld,
                                  (hipStream_t)stream);
 }
 
 int moihgp_unproject_stream(moihgp_gp* gp, int dtype, const void* Tyhat, size_t T, size_t ld, void* Yhat, void* stream) {
     if (!gp || gp->latents_only) { set_last_error("unproject_stream needs a full MOIHGP object"); return 1; }
     if (ld < T) { set_last_error("ld < T"); return 1; }
-    return launch_unproject_stream(dtype, Tyhat, T, ld, gp->M, gp->L, gp->dU, dtype == MOIHGP_F64 ? nullptr : mixing_f32(gp, (hipStream_t)stream), gp->dsqrtS, Yhat,
+    note_user_stream(gp, (hipStream_t)stream);
+    return launch_unproject_stream(dtype, Tyhat, T, ld, gp->M, gp->L, gp->dU, dtype == MOIHGP_F64 ? nullptr : mixing_f32(gp), gp->dsqrtS, Yhat,
                                    (hipStream_t)stream);
 }
 

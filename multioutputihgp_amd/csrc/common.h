@@ -146,6 +146,9 @@ struct TickArgs {
     const double* sqrtS;     // [L] S^1/2
     const double* invsqrtS;  // [L] S^-1/2
     const double* sigma;     // [1]
+    // moihgp.h:565-607: the gradient overload of negLogLikelihood adds the per-latent losses in its threaded branch (:590) and drops
+    // them in the serial one (:597-607); 1 = add them (threading on, or MOIHGP_LIK1_FULL_LOSS=1), 0 = the serial branch's value.
+    int lik1_latent_loss;
 };
 void launch_project_tick(const TickArgs& a, const double* y, double* Ty, double* Uty, double* part /* [32][L] scratch or NULL */, hipStream_t s);
 void launch_project_tick_missing(const TickArgs& a, const double* y, double* Ty, double* work /*L*L+L*/, hipStream_t s);

@@ -205,7 +205,7 @@ __device__ double block_sum(double v, double* red) {
 // loss and the S / sigma / per-latent gradient entries (moihgp.h:503, :553-563, :598-609): one workgroup.
 __device__ inline void nll_finalize_body(size_t M, size_t L, const double* __restrict__ S, double sigma, const double* Uty,
                                          const double* lossv, const double* pv, const double* igrad, const double* resid2,
-                                         double* __restrict__ loss, double* __restrict__ grad, double* red) {
+                                         double* __restrict__ loss, double* __restrict__ grad, double* red, bool add_latent_loss) {
     const int tid = threadIdx.x, nt = blockDim.x;
     double a = 0.0, b = 0.0, c = 0.0;
     for (size_t l = tid; l < L; l += nt) { a += S[l]; c += lossv[l]; }
@@ -215,7 +215,9 @@ __device__ inline void nll_finalize_body(size_t M, size_t L, const double* __res
     const double lsum = block_sum(c, red);
     double m_n = (double)M - (double)L;
     if (m_n < 0.0) m_n = 0.0;                                            // moihgp.h:502
-    if (tid == 0) *loss = 0.5 * log(Ssum) + 0.5 * m_n * log(sigma) + 0.5 * nrm / sigma + lsum;   // moihgp.h:503 (sic)
+    // moihgp.h:503 (sic) + the per-latent terms: always in the overload without gradient (:684); in the gradient overload only on
+    // its threaded branch (:590) -- the serial branch (:597-607) computes them and drops them
+    if (tid == 0) *loss = 0.5 * log(Ssum) + 0.5 * m_n * log(sigma) + 0.5 * nrm / sigma + (add_latent_loss ? lsum : 0.0);
     if (!grad) return;
     const size_t sizeU = M * L;
     double gs = 0.0;
@@ -236,9 +238,9 @@ __global__ void __launch_bounds__(256) nll_finalize_kernel(size_t M, size_t L, c
                                                            const double* __restrict__ sigma_p, const double* __restrict__ Uty,
                                                            const double* __restrict__ lossv, const double* __restrict__ pv,
                                                            const double* __restrict__ igrad, const double* __restrict__ resid2,
-                                                           double* __restrict__ loss, double* __restrict__ grad) {
+                                                           double* __restrict__ loss, double* __restrict__ grad, int add_latent_loss) {
     __shared__ double red[256];
-    nll_finalize_body(M, L, S, *sigma_p, Uty, lossv, pv, igrad, resid2, loss, grad, red);
+    nll_finalize_body(M, L, S, *sigma_p, Uty, lossv, pv, igrad, resid2, loss, grad, red, add_latent_loss != 0);
 }
 
 // U-gradient (moihgp.h:538-552).  U is a polar factor (moihgp.h:438-446) so its singular values are
@@ -377,7 +379,7 @@ __global__ void __launch_bounds__(256) fused_lik_kernel(size_t M, size_t L, cons
                                                         const double* __restrict__ S, const double* __restrict__ sigma_p,
                                                         const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ dx,
                                                         double* __restrict__ loss, double* __restrict__ grad,
-                                                        volatile unsigned long long* flag, unsigned long long seq) {
+                                                        volatile unsigned long long* flag, unsigned long long seq, int lik1_latent_loss) {
     extern __shared__ double sm[];
     double* sy = sm;                 // [M]
     double* sres = sy + M;           // [M]
@@ -409,7 +411,7 @@ __global__ void __launch_bounds__(256) fused_lik_kernel(size_t M, size_t L, cons
     }
     __syncthreads();
     const double sigma = *sigma_p;
-    nll_finalize_body(M, L, S, sigma, sUty, slos, spv, sig, sres, loss, dx ? grad : nullptr, red);
+    nll_finalize_body(M, L, S, sigma, sUty, slos, spv, sig, sres, loss, dx ? grad : nullptr, red, !dx || lik1_latent_loss != 0);
     if (dx && grad)
         for (size_t idx = tid; idx < M * L; idx += 256) {                // moihgp.h:538-552 in its rank-1 form (ugrad_kernel)
             const size_t r = idx / L, c = idx % L;
@@ -427,9 +429,9 @@ void launch_fused_lik(const TickArgs& a, const double* x, const double* y, const
                       unsigned long long* flag, unsigned long long seq, hipStream_t s) {
     const size_t smem = fused_lik_smem(a.M, a.L);
     if (a.d == 2)
-        hipLaunchKernelGGL(fused_lik_kernel<2>, dim3(1), dim3(256), smem, s, a.M, a.L, a.cb64, a.U, a.S, a.sigma, x, y, dx, loss, grad, flag, seq);
+        hipLaunchKernelGGL(fused_lik_kernel<2>, dim3(1), dim3(256), smem, s, a.M, a.L, a.cb64, a.U, a.S, a.sigma, x, y, dx, loss, grad, flag, seq, a.lik1_latent_loss);
     else
-        hipLaunchKernelGGL(fused_lik_kernel<3>, dim3(1), dim3(256), smem, s, a.M, a.L, a.cb64, a.U, a.S, a.sigma, x, y, dx, loss, grad, flag, seq);
+        hipLaunchKernelGGL(fused_lik_kernel<3>, dim3(1), dim3(256), smem, s, a.M, a.L, a.cb64, a.U, a.S, a.sigma, x, y, dx, loss, grad, flag, seq, a.lik1_latent_loss);
     MOIHGP_HIP_FATAL(hipGetLastError());
 }
 
@@ -451,7 +453,7 @@ void launch_nll_tick(const TickArgs& a, const double* x, const double* y, const 
         hipLaunchKernelGGL(igp_nll_kernel<3>, grid, block, 0, s, a.L, a.cb64, x, y, Ty, dx, lossv, pv, igrad);
     hipLaunchKernelGGL(resid_kernel, dim3(nblk(a.M, 4)), dim3(256), 0, s, a.M, a.L, a.U, y, Uty, resid2);
     hipLaunchKernelGGL(nll_finalize_kernel, dim3(1), dim3(256), 0, s, a.M, a.L, a.S, a.sigma, Uty, lossv, pv, igrad,
-                       resid2, loss, dx ? grad : nullptr);
+                       resid2, loss, dx ? grad : nullptr, (!dx || a.lik1_latent_loss) ? 1 : 0);
     if (dx && grad)
         hipLaunchKernelGGL(ugrad_kernel, dim3(nblk(a.M * a.L, 256)), dim3(256), 0, s, a.M, a.L, a.S, a.sigma, y, Uty, pv, grad);
     MOIHGP_HIP_FATAL(hipGetLastError());

@@ -9,7 +9,8 @@
 //     pv_{l,t} = (y_t(l) - HA x_{l,t}) (1 - HA K) / S_l      (raw y(l), sic moihgp.h:510)
 //     grad_U   = Y^T Z,  Z_{t,l} = pv/sqrt(S_l) - (U^T y_t)_l / sigma          one GEMM   (closed form of moihgp.h:538-552)
 //     r_t      = || y_t - U U^T y_t ||                         one GEMM + row norms
-//     loss     = W (1/2 log sum S + 1/2 m_n log sigma) + 1/2 sum_t r_t / sigma + sum_l nll_l            (moihgp.h:503)
+//     loss     = W (1/2 log sum S + 1/2 m_n log sigma) + 1/2 sum_t r_t / sigma [+ sum_l nll_l]          (moihgp.h:503; the bracket only
+//                with threading on: the serial branch of the gradient overload drops the per-latent losses, moihgp.h:590 vs :597-607)
 //     grad_S_l = W/(2 S_l) - 1/2 S_l^-3/2 sum_t pv (U^T y) - sigma/S_l^2 g_l[noise]                     (moihgp.h:555-561, :604)
 //     grad_sigma = sum_t 1/2 (m_n - r_t/sigma)/sigma + sum_l g_l[noise]/S_l                             (moihgp.h:563, :605)
 // all fp64.  Ticks with missing outputs (NaN) are not supported here (the caller falls back to the per-tick ABI).
@@ -74,7 +75,7 @@ __global__ void __launch_bounds__(256) window_finalize_kernel(size_t M, size_t L
                                                               const double* __restrict__ sigma_p, const double* __restrict__ rt,
                                                               const double* __restrict__ spu, const double* __restrict__ nll,
                                                               const double* __restrict__ gl, double* __restrict__ loss,
-                                                              double* __restrict__ grad) {
+                                                              double* __restrict__ grad, int add_latent_loss) {
     __shared__ double red[256];
     const int tid = threadIdx.x, nt = blockDim.x;
     const double sigma = *sigma_p;
@@ -86,7 +87,8 @@ __global__ void __launch_bounds__(256) window_finalize_kernel(size_t M, size_t L
     if (m_n < 0.0) m_n = 0.0;
     const double Wd = (double)W;
     if (tid == 0) {
-        *loss = Wd * (0.5 * log(Ssum) + 0.5 * m_n * log(sigma)) + 0.5 * rsum / sigma + lsum;                 // moihgp.h:503 summed over ticks
+        // moihgp.h:503 summed over ticks; the per-latent losses only on the threaded branch (:590), the serial one (:597-607) drops them
+        *loss = Wd * (0.5 * log(Ssum) + 0.5 * m_n * log(sigma)) + 0.5 * rsum / sigma + (add_latent_loss ? lsum : 0.0);
         grad[M * L + L] = 0.5 * (Wd * m_n - rsum / sigma) / sigma + gsum;                                     // moihgp.h:563, :605
     }
     for (size_t l = tid; l < L; l += nt) {
@@ -111,7 +113,7 @@ int launch_window_objective(const TickArgs& a, const double* cb64, const float* 
     if ((rc = launch_ugrad_gemm(w.Y, w.W, a.M, w.Z, w.ldw, a.L, grad, s))) return rc;                         // grad[0 .. M*L) = U-gradient
     if ((rc = launch_unproject_stream(0, w.Ty, w.W, w.ldw, a.M, a.L, a.U, nullptr, a.sqrtS, w.UU, s))) return rc;           // U (U^T y_t)
     hipLaunchKernelGGL(window_resid_kernel, dim3((unsigned)((w.W + 3) / 4)), b256, 0, s, a.M, w.W, w.Y, w.UU, w.rt);
-    hipLaunchKernelGGL(window_finalize_kernel, dim3(1), b256, 0, s, a.M, a.L, w.W, a.S, a.sigma, w.rt, w.spu, w.nll, w.gl, loss, grad);
+    hipLaunchKernelGGL(window_finalize_kernel, dim3(1), b256, 0, s, a.M, a.L, w.W, a.S, a.sigma, w.rt, w.spu, w.nll, w.gl, loss, grad, a.lik1_latent_loss);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_last_error("window objective launch: %s", hipGetErrorString(e)); return 2; }
     return 0;

@@ -10,6 +10,9 @@ Differences, all documented in INTEGRATION.md:
     MOIHGP_GP52_MATERN52=1.  `kernel="Matern52ss"` selects the real matern52ss.h model explicitly.
   * construction raises `MoihgpError` when no GPU / library is available (the reference would
     fail inside `cdll.LoadLibrary`).
+`threading` is passed through as in the reference (pywrapper.py:12,32).  There is no thread fan-out behind it, but the
+value `negLogLikelihood(x, y, dx)` returns depends on it exactly as in the reference (moihgp.h:590 vs :597-607): with the
+default `threading=False` the per-latent loss terms are NOT part of the returned loss (the gradient is the same either way).
 """
 from __future__ import annotations
 
@@ -37,6 +40,8 @@ class MOIHGP(object):
         elif kernel == "Matern52ss":
             pfx = "gp52"     # same entry points; object built with the true Matern-5/2 state space
             self.__obj = lib.moihgp_new(1, c_double(dt), c_size_t(num_output), c_size_t(num_latent))
+            if self.__obj:
+                lib.moihgp_set_threading(self.__obj, int(bool(threading)))
         else:
             raise NotImplementedError("Unsupported kernel type.")
         if not self.__obj:

@@ -5,6 +5,11 @@ torch is plumbing here: it owns device memory and streams; all arithmetic is in 
 Stream layout: SERIES-MAJOR `[L, ld]` (one contiguous row per latent), fp32 or fp64.  The per-tick loop of
 the reference callers (`for y in data: gp.step(x, y)`, example.py:40-42; moihgp_online.h:61-70;
 moihgp_regression.h:42-50) becomes ONE call over T ticks.
+
+Ordering (include/moihgp.h "ordering contract"): `filter`, `grad`, `project_stream`, `unproject_stream` are asynchronous on
+the torch stream they are given and read the handle's tables; `LatentBank.update`, `MOIHGP.update` and `set_mixing` first wait
+(on the device) for all such work already enqueued through the handle, then rewrite the tables and return when they are
+complete -- an update issued behind pipelined sweeps neither overtakes them nor needs a host synchronisation from the caller.
 """
 from __future__ import annotations
 

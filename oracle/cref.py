@@ -111,6 +111,11 @@ def lib(native: bool = False, wide: bool = False):
     L.orc_gp_new.argtypes = [C.c_int, C.c_double, C.c_size_t, C.c_size_t]
     L.orc_gp_new.restype = C.c_void_p
     L.orc_gp_del.argtypes = [C.c_void_p]
+    L.orc_gp_new_t.argtypes = [C.c_int, C.c_double, C.c_size_t, C.c_size_t, C.c_int]
+    L.orc_gp_new_t.restype = C.c_void_p
+    L.orc_gp_set_threading.argtypes = [C.c_void_p, C.c_int]
+    L.orc_gp_get_threading.argtypes = [C.c_void_p]
+    L.orc_gp_get_threading.restype = C.c_int
     L.orc_gp_step1.argtypes = [C.c_void_p] + [_dp] * 6
     L.orc_gp_step2.argtypes = [C.c_void_p] + [_dp] * 5
     L.orc_gp_step3.argtypes = [C.c_void_p] + [_dp] * 4
@@ -191,10 +196,11 @@ def polar(A):
 class GP:
     """Mirror of the reference ctypes class (pywrapper.py:10-270) over the C oracle."""
 
-    def __init__(self, dt, num_output, num_latent, kernel="Matern32"):
+    def __init__(self, dt, num_output, num_latent, kernel="Matern32", threading=False):
         self._L = lib()
         self.M, self.L = num_output, num_latent
-        self._h = self._L.orc_gp_new(KERNEL_ID[kernel], float(dt), num_output, num_latent)
+        # `threading` (pywrapper.py:12, moihgp.h:81,128-135) changes the VALUE negLogLikelihood(x, y, dx) returns: moihgp.h:590 vs :597-607
+        self._h = self._L.orc_gp_new_t(KERNEL_ID[kernel], float(dt), num_output, num_latent, int(bool(threading)))
         self.igp_dim = int(self._L.orc_gp_igp_dim(self._h))
         self.num_param = int(self._L.orc_gp_num_param(self._h))
         self.num_igp_param = int(self._L.orc_gp_num_igp_param(self._h))
@@ -256,6 +262,10 @@ class GP:
         U = np.zeros((self.M, self.L))
         self._L.orc_gp_get_U(self._h, _ptr(U))
         return U
+
+    @property
+    def threading(self):
+        return bool(self._L.orc_gp_get_threading(self._h))
 
     def latent(self, l) -> OrcIHGP:
         return self._L.orc_gp_latent(self._h, l).contents

@@ -69,23 +69,35 @@ def gen_moihgp():
     rng = np.random.default_rng(SEED + 1)
     for kern in ("Matern32", "Matern52"):
         for (M, L) in [(2, 1), (4, 2), (6, 6), (8, 4)]:
+            # `threading` (moihgp.h:81) is observable in the value of negLogLikelihood(x, y, dx): the serial branch (:597-607, the
+            # default, and forced for L < 2 by :128-135) drops the per-latent losses the threaded branch (:590) adds.
             n = onp.MOIHGP(0.1, M, L, kern)
             c = cref.GP(0.1, M, L, kern)
+            nt = onp.MOIHGP(0.1, M, L, kern, threading=True)
+            ct = cref.GP(0.1, M, L, kern, threading=True)
             d, P = n.dim, n.P
             params = np.concatenate([
                 (np.eye(M, L) + 0.3 * rng.standard_normal((M, L))).ravel(), rng.uniform(0.5, 2, L),
                 [rng.uniform(0.01, 0.1)], synth_params(L, rng).ravel()])
-            n.update(params); c.update(params)
+            n.update(params); c.update(params); nt.update(params); ct.update(params)
             x = rng.standard_normal((L, d)); dx = rng.standard_normal((L, P, d)); y = rng.standard_normal(M)
             s1 = n.step(x, y, dx); s3 = n.step(x, y); s4 = n.step(x)
             l2 = n.nll(x, y); l1, g1 = n.nll(x, y, dx)
             c1 = c.step(x, y, dx); c3 = c.step(x, y); c4 = c.step(x)
             cl2 = c.negLogLikelihood(x, y); cl1, cg1 = c.negLogLikelihood(x, y, dx)
-            for a, b in list(zip(c1, s1)) + list(zip(c3, s3)) + list(zip(c4, s4)) + [(cl2, l2), (cl1, l1), (cg1, g1), (c.params, n.get_params())]:
+            l1t, g1t = nt.nll(x, y, dx); cl1t, cg1t = ct.negLogLikelihood(x, y, dx)
+            for a, b in list(zip(c1, s1)) + list(zip(c3, s3)) + list(zip(c4, s4)) + [(cl2, l2), (cl1, l1), (cg1, g1), (c.params, n.get_params()),
+                                                                                    (cl1t, l1t), (cg1t, g1t), (ct.negLogLikelihood(x, y), l2)]:
                 assert rel(a, b) < 1e-11, (kern, M, L, rel(a, b))
+            assert np.array_equal(g1t, g1)                      # the flag never touches the gradient
+            sum_a4 = sum(n.igps[l].nll(x[l], n.project(y)[l]) for l in range(L))
+            if L >= 2:
+                assert abs(l1t - l2) <= 1e-12 * abs(l2) and abs(l1 - (l2 - sum_a4)) <= 1e-12 * max(abs(l2), abs(sum_a4))
+            else:
+                assert l1t == l1                                  # :128-135
             out = dict(dt=0.1, M=M, L=L, params_in=params, params_out=n.get_params(), x=x, dx=dx, y=y,
                        s1_xnew=s1[0], s1_yhat=s1[1], s1_dxnew=s1[2], s3_xnew=s3[0], s3_yhat=s3[1],
-                       s4_xnew=s4[0], s4_yhat=s4[1], lik2=l2, lik1=l1, grad=g1)
+                       s4_xnew=s4[0], s4_yhat=s4[1], lik2=l2, lik1=l1, lik1_threaded=l1t, sum_latent_nll=sum_a4, grad=g1)
             if M > L:   # missing-output projection, moihgp.h:167-178
                 ym = y.copy(); ym[rng.integers(0, M)] = np.nan
                 m3 = n.step(x, ym); cm3 = c.step(x, ym)
@@ -196,11 +208,14 @@ def gen_stacked():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    if "--stacked-only" not in sys.argv:
-        gen_stationary()
+    if "--moihgp-only" in sys.argv:
         gen_moihgp()
-        gen_streams()
-    gen_stacked()
+    else:
+        if "--stacked-only" not in sys.argv:
+            gen_stationary()
+            gen_moihgp()
+            gen_streams()
+        gen_stacked()
     print("golden fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):
         print(f"  {f:40s} {os.path.getsize(os.path.join(OUT, f)):8d} B")

@@ -331,9 +331,10 @@ class MOIHGP:
     (the reference adds N(0,1e-3) noise from std::random_device, :105-125, which is
     not reproducible; callers must `update(params)` before comparing anything)."""
 
-    def __init__(self, dt, num_output, num_latent, kernel="Matern32"):
+    def __init__(self, dt, num_output, num_latent, kernel="Matern32", threading=False):
         self.dt = float(dt)
         self.M, self.L = int(num_output), int(num_latent)
+        self.threading = bool(threading) and self.L >= 2          # :128-135 (fewer than two latents: always off)
         self.igps = [IHGP(dt, kernel) for _ in range(self.L)]
         self.dim = self.igps[0].dim
         self.P = self.igps[0].num_param
@@ -448,7 +449,8 @@ class MOIHGP:
         igp_grad = np.zeros((L, P))
         for l in range(L):                                        # :598-606
             li, g = self.igps[l].nll(x[l], Ty[l], dx[l])
-            loss += li
+            if self.threading:                                    # :590 adds the per-latent loss; the serial branch
+                loss += li                                        # :597-607 calls IHGP::negLogLikelihood and drops its value
             igp_grad[l] = g
             dn = g[P - 1]
             grad[sizeU + l] -= dn * sigma / S[l] / S[l]

@@ -451,6 +451,7 @@ struct orc_gp {
     double sigma;
     orc_ihgp* igp;  /* [L] */
     int literal_ugrad;
+    int threading;  /* moihgp.h:747 _threading: observable through the value lik1 returns (:590 vs :597-607) */
 };
 
 orc_gp* orc_gp_new(int kernel, double dt, size_t M, size_t L) {
@@ -467,6 +468,15 @@ orc_gp* orc_gp_new(int kernel, double dt, size_t M, size_t L) {
     for (size_t l = 0; l < L; l++) gp->S[l] = 1.0;                    /* :126 */
     gp->sigma = 1e-2;                                                 /* :127 */
     gp->literal_ugrad = 1;
+    gp->threading = 0;                                                /* the reference's default everywhere (pywrapper.py:12) */
+    return gp;
+}
+/* moihgp.h:81 constructor argument `threading`, with the override of :128-135 (fewer than two latents: always off) */
+void orc_gp_set_threading(orc_gp* gp, int threading) { gp->threading = (gp->L < 2) ? 0 : (threading != 0); }
+int orc_gp_get_threading(orc_gp* gp) { return gp->threading; }
+orc_gp* orc_gp_new_t(int kernel, double dt, size_t M, size_t L, int threading) {
+    orc_gp* gp = orc_gp_new(kernel, dt, M, L);
+    orc_gp_set_threading(gp, threading);
     return gp;
 }
 void orc_gp_del(orc_gp* gp) { if (!gp) return; free(gp->U); free(gp->S); free(gp->igp); free(gp); }
@@ -670,9 +680,13 @@ double orc_gp_lik1(orc_gp* gp, const double* x, const double* y, const double* d
         grad[sizeU + l] = 0.5 / gp->S[l] + pv[l] * (-0.5 * (1.0 / sq / sq / sq) * Uty[l]);
     }
     grad[sizeU + L] = 0.5 * (m_n - nrm / sigma) / sigma;              /* :563 */
-    for (size_t l = 0; l < L; l++) {                                  /* :598-606 */
+    for (size_t l = 0; l < L; l++) {                                  /* :564-607 */
         double g[NP];
-        loss += orc_ihgp_nll(&gp->igp[l], x + l * d, Ty[l], dx + l * P * d, g);
+        double ll = orc_ihgp_nll(&gp->igp[l], x + l * d, Ty[l], dx + l * P * d, g);
+        /* The two branches of the reference differ: the threaded one adds the per-latent loss (:590 `loss += args[idx].loss`),
+         * the serial one calls IHGP::negLogLikelihood for its gradient and DROPS the value it returns (:600, no `loss +=`).
+         * With threading off (the default, and forced for L < 2) lik1 therefore returns the three global terms of :503 only. */
+        if (gp->threading) loss += ll;
         double dn = g[P - 1];
         grad[sizeU + l] -= dn * sigma / gp->S[l] / gp->S[l];
         grad[sizeU + L] += dn / gp->S[l];

@@ -68,7 +68,13 @@ double orc_ihgp_nll(const orc_ihgp* g, const double* x, double y, const double* 
 
 /* ---- L2: MOIHGP mirror of the reference C ABI (src/wrapper.cpp:31-326) --- */
 typedef struct orc_gp orc_gp;
-orc_gp* orc_gp_new(int kernel, double dt, size_t num_output, size_t num_latent);
+orc_gp* orc_gp_new(int kernel, double dt, size_t num_output, size_t num_latent);   /* threading off (the reference's default) */
+/* moihgp.h:81 with its `threading` argument; :128-135 forces it off for num_latent < 2.  The flag is observable: the
+ * gradient overload of negLogLikelihood adds the per-latent losses only in its threaded branch (:590), not in the serial
+ * one (:597-607), so lik1 returns the global terms of :503 alone when threading is off.  lik2 (:614-688) adds them in both. */
+orc_gp* orc_gp_new_t(int kernel, double dt, size_t num_output, size_t num_latent, int threading);
+void    orc_gp_set_threading(orc_gp* gp, int threading);
+int     orc_gp_get_threading(orc_gp* gp);
 void    orc_gp_del(orc_gp* gp);
 void    orc_gp_step1(orc_gp* gp, const double* x, const double* y, const double* dx, double* xnew, double* yhat, double* dxnew);
 void    orc_gp_step2(orc_gp* gp, const double* x, const double* y, const double* dx, double* xnew, double* dxnew);

@@ -7,7 +7,7 @@
 #include "moihgp_oracle.h"
 
 #define SHIM(PFX)                                                                                                   \
-    void* PFX##_new(double dt, size_t M, size_t L, bool threading) { (void)threading; return orc_gp_new(ORC_MATERN32, dt, M, L); } \
+    void* PFX##_new(double dt, size_t M, size_t L, bool threading) { return orc_gp_new_t(ORC_MATERN32, dt, M, L, threading); } \
     void PFX##_del(void* g) { orc_gp_del((orc_gp*)g); }                                                              \
     void PFX##_step1(void* g, double* x, double* y, double* dx, double* xn, double* yh, double* dxn) { orc_gp_step1((orc_gp*)g, x, y, dx, xn, yh, dxn); } \
     void PFX##_step2(void* g, double* x, double* y, double* dx, double* xn, double* dxn) { orc_gp_step2((orc_gp*)g, x, y, dx, xn, dxn); } \

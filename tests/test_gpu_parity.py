@@ -101,6 +101,75 @@ def test_reference_abi_vs_golden(env, kern, ML):
         assert np.isnan(gp.negLogLikelihood(g["x"], g["y_missing"]))   # moihgp.h:651 does not guard NaN
 
 
+# ------------------------------------------------------------------------------------------ A6: the `threading` flag is observable
+@pytest.mark.parametrize("kern", ["Matern32", "Matern52"])
+@pytest.mark.parametrize("ML", [(2, 1), (4, 2), (6, 6), (8, 4), (200, 150)])       # (200, 150): beyond the fused one-workgroup kernels
+def test_lik1_follows_the_threading_flag(env, kern, ML):
+    """moihgp.h:565-607: the gradient overload of negLogLikelihood adds the per-latent losses sum_l 1/2 (v_l^2/S_l + log S_l)
+    (A4, ihgp.h:204-209) only in its threaded branch (:590); the serial branch (:597-607) drops them.  threading=False is the
+    default everywhere (pywrapper.py:12) and is forced for L < 2 (:128-135).  So:
+        lik1(threading=False) == lik2 - sum_l A4      lik1(threading=True) == lik2      gradient identical."""
+    M, L = ML
+    rng = np.random.default_rng(17 * M + L)
+    if M <= 8:
+        g = load_golden(f"moihgp_{kern}_M{M}_L{L}.npz")
+        params, x, y, dx = g["params_in"], g["x"], g["y"], g["dx"]
+    else:
+        d = 2 if kern == "Matern32" else 3
+        params = np.concatenate([(np.eye(M, L) + 0.2 * rng.standard_normal((M, L))).ravel(), rng.uniform(0.5, 2, L), [0.03], synth_params(L, rng).ravel()])
+        x, y, dx = rng.standard_normal((L, d)), rng.standard_normal(M), rng.standard_normal((L, 3, d))
+    off = env["MOIHGP"](0.1, M, L, kernel=KMAP[kern]); off.update(params)                      # default: threading off
+    on = env["MOIHGP"](0.1, M, L, kernel=KMAP[kern], threading=True); on.update(params)
+    assert env["lib"].moihgp_get_threading(off.handle) == 0 and env["lib"].moihgp_get_threading(on.handle) == (1 if L >= 2 else 0)
+    ref_off = env["cref"].GP(0.1, M, L, kern); ref_off.update(params); ref_off.set_literal_ugrad(0)
+    ref_on = env["cref"].GP(0.1, M, L, kern, threading=True); ref_on.update(params); ref_on.set_literal_ugrad(0)
+    lik2 = off.negLogLikelihood(x, y)
+    assert abs(on.negLogLikelihood(x, y) - lik2) <= 1e-15 * abs(lik2)                         # lik2 (:654-686) adds them in both branches
+    l_off, g_off = off.negLogLikelihood(x, y, dx)
+    l_on, g_on = on.negLogLikelihood(x, y, dx)
+    assert np.array_equal(g_off, g_on)
+    # sum_l A4 from the oracle's per-latent function on the projected observation
+    Ty = ref_off.project(y)
+    sum_a4 = sum(env["cref"].lib().orc_ihgp_nll(ref_off.latent(l), x[l].ctypes.data_as(env["cref"]._dp), float(Ty[l]), None, None) for l in range(L))
+    scale = max(abs(lik2), abs(sum_a4))
+    if L >= 2:
+        assert abs(l_on - lik2) < FP64_TIGHT * scale
+        assert abs(l_off - (lik2 - sum_a4)) < FP64_TIGHT * scale
+        assert abs(sum_a4) > 1e-3 * scale                      # the two values really differ
+    else:
+        assert l_on == l_off                                   # :128-135
+    assert abs(l_off - ref_off.negLogLikelihood(x, y, dx)[0]) < FP64_TIGHT * scale
+    assert abs(l_on - ref_on.negLogLikelihood(x, y, dx)[0]) < FP64_TIGHT * scale
+    if M <= 8:
+        assert abs(l_off - g["lik1"]) < FP64_TIGHT * scale and abs(l_on - g["lik1_threaded"]) < FP64_TIGHT * scale
+    # the windowed objective sums what lik1 returns per tick, so it follows the flag too
+    W = 6
+    Y = 0.5 * rng.standard_normal((W, M))
+    for gp, ref in ((off, ref_off), (on, ref_on)):
+        loss, grad, _, _ = gp.window_objective(Y, x, dx)
+        grad = grad.copy()
+        xr, dxr, lref, gref = x, dx, 0.0, np.zeros(gp.num_param)
+        for t in range(W):
+            l1, g1 = ref.negLogLikelihood(xr, Y[t], dxr)
+            xr, _, dxr = ref.step(xr, Y[t], dxr)
+            lref += l1; gref += g1
+        assert abs(loss - lref) < 1e-9 * max(abs(lref), scale) and rel_err(grad, gref) < 1e-8
+    # the additive setter applies the same L < 2 override
+    env["lib"].moihgp_set_threading(off.handle, 1)
+    assert env["lib"].moihgp_get_threading(off.handle) == (1 if L >= 2 else 0)
+    assert abs(off.negLogLikelihood(x, y, dx)[0] - l_on) <= 1e-15 * scale
+
+
+def test_lik1_full_loss_opt_in(env, monkeypatch):
+    """MOIHGP_LIK1_FULL_LOSS=1 (read at construction): the summed form regardless of the flag."""
+    g = load_golden("moihgp_Matern32_M8_L4.npz")
+    monkeypatch.setenv("MOIHGP_LIK1_FULL_LOSS", "1")
+    gp = env["MOIHGP"](0.1, 8, 4, kernel="Matern32"); gp.update(g["params_in"])
+    monkeypatch.delenv("MOIHGP_LIK1_FULL_LOSS")
+    l1, g1 = gp.negLogLikelihood(g["x"], g["y"], g["dx"])
+    assert abs(l1 - g["lik1_threaded"]) < FP64_TIGHT * abs(g["lik1_threaded"]) and rel_err(g1, g["grad"]) < 1e-8
+
+
 @pytest.mark.parametrize("kern,M,L", [("Matern32", 64, 32), ("Matern52", 96, 96), ("Matern52", 300, 40)])
 def test_reference_abi_vs_oracle_larger(env, kern, M, L):
     rng = np.random.default_rng(M * 1000 + L)
@@ -1026,3 +1095,37 @@ def test_nll_total_from_the_sweep(env, kern, L, T, dtype):
         ref = nll.sum().item()
         assert abs(tot.item() - ref) <= 1e-12 * abs(ref), (rep, tot.item(), ref)
         tot.fill_(-1.0)
+
+
+# ------------------------------------------------------------------------------------------ ordering: sweeps in flight vs update()
+@pytest.mark.parametrize("kernel,J", [("Matern52ss", 0), ("Matern52x4", 4)])
+def test_update_waits_for_sweeps_in_flight(env, kernel, J):
+    """A sweep is asynchronous on the caller's stream and reads the per-latent tables; update() rewrites them on the handle's own
+    stream.  An update issued right behind queued sweeps must not change their results (include/moihgp.h, ordering contract)."""
+    rng = np.random.default_rng(5)
+    L, T = 2048, 6000
+    P = 2 * J + 1 if J else 3
+    def draw():
+        cols = [rng.uniform(0.5, 2, L) for _ in range(P - 1)] + [rng.uniform(0.05, 0.2, L)]
+        return np.column_stack(cols)
+    p_old, p_new = draw(), draw()
+    Ty = to_dev(synth(L, T, rng), torch.float64)
+    bank = env["streams"].LatentBank(0.1, p_old, kernel=kernel)
+    y_ref, x_ref, nll_ref = bank.filter(Ty, T)
+    torch.cuda.synchronize()
+    y_ref, nll_ref = y_ref.clone(), nll_ref.clone()
+    side = torch.cuda.Stream()
+    outs = []
+    with torch.cuda.stream(side):
+        for _ in range(6):                                     # a pipeline of sweeps, none of them waited for ...
+            outs.append(bank.filter(Ty, T, stream=side))
+    bank.update(p_new)                                         # ... and the tables are rewritten right behind them
+    y_new, _, nll_new = bank.filter(Ty, T)                     # enqueued after update() returned: sees the new tables
+    torch.cuda.synchronize()
+    for yh, _, nll in outs:
+        assert torch.equal(yh[:, :T], y_ref[:, :T]) and torch.equal(nll, nll_ref)
+    fresh = env["streams"].LatentBank(0.1, p_new, kernel=kernel)
+    y_f, _, nll_f = fresh.filter(Ty, T)
+    torch.cuda.synchronize()
+    assert torch.equal(y_new[:, :T], y_f[:, :T]) and torch.equal(nll_new, nll_f)
+    assert not torch.equal(nll_new, nll_ref)

@@ -12,7 +12,7 @@ class OracleBackend:
 
     def __init__(self, dt, num_output, num_latent, kernel="Matern32", threading=False):
         from oracle import cref
-        self._gp = cref.GP(dt, num_output, num_latent, kernel)
+        self._gp = cref.GP(dt, num_output, num_latent, kernel, threading=threading)
         self.num_output, self.num_latent = num_output, num_latent
         self.igp_dim, self.num_param, self.num_igp_param = self._gp.igp_dim, self._gp.num_param, self._gp.num_igp_param
 
@@ -33,7 +33,9 @@ class OracleBackend:
 def run_learner(g, backend=None):
     from multioutputihgp_amd.online_learning import MOIHGPOnlineLearning
     M, L = int(g["M"]), int(g["L"])
-    learner = MOIHGPOnlineLearning(float(g["dt"]), M, L, float(g["gamma"]), windowsize=int(g["W"]), kernel="Matern32", backend=backend)
+    # `threading` (online_learning.py:12) decides whether the objective VALUE holds the per-latent losses (moihgp.h:590 vs :597-607)
+    learner = MOIHGPOnlineLearning(float(g["dt"]), M, L, float(g["gamma"]), windowsize=int(g["W"]), kernel="Matern32", threading=bool(g["threading"]),
+                                   backend=backend)
     learner.moihgp.update(g["p0"])            # the reference's ctor draws a random U; start from the golden's parameters
     yhat, params = [], []
     for y in g["Y"]:
@@ -42,7 +44,17 @@ def run_learner(g, backend=None):
     return np.array(yhat), np.array(params)
 
 
-@pytest.mark.parametrize("case", ["a", "b", "c"])
+CASES = ["a", "b", "c", "at", "bt"]          # "at" / "bt": the streams of "a" / "b" with threading=True
+
+
+def test_threading_changes_the_learner_trajectory():
+    """The flag is not 'speed only': the golden trajectories of the reference's own learner differ between its two values."""
+    a, at = load_golden("learner_a.npz"), load_golden("learner_at.npz")
+    assert np.array_equal(a["Y"], at["Y"]) and not bool(a["threading"]) and bool(at["threading"])
+    assert rel_err(at["params"][-1], a["params"][-1]) > 1e-3
+
+
+@pytest.mark.parametrize("case", CASES)
 def test_learner_logic_over_oracle_backend(case):
     g = load_golden(f"learner_{case}.npz")
     yhat, params = run_learner(g, backend=OracleBackend)
@@ -51,7 +63,7 @@ def test_learner_logic_over_oracle_backend(case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["a", "b", "c"])
+@pytest.mark.parametrize("case", CASES)
 def test_learner_over_hip_library(hip_built, case):
     g = load_golden(f"learner_{case}.npz")
     yhat, params = run_learner(g)

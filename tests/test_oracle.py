@@ -97,6 +97,16 @@ def test_moihgp_golden(kern, ML):
         assert abs(nll(g["x"], g["y"]) - g["lik2"]) < 1e-11 * abs(g["lik2"])
         l1, g1 = nll(g["x"], g["y"], g["dx"])
         assert abs(l1 - g["lik1"]) < 1e-11 * abs(g["lik1"]) and rel_err(g1, g["grad"]) < 1e-11
+        # moihgp.h:565-607: the serial branch (threading off: the default, and forced for L < 2 by :128-135) computes the per-latent
+        # gradients but drops the per-latent losses; the threaded branch (:590) adds them.  lik2 (:654-686) adds them in both.
+        gt = (cref.GP if impl == "c" else onp.MOIHGP)(0.1, M, L, kern, threading=True); gt.update(g["params_in"])
+        l1t, g1t = (gt.negLogLikelihood if impl == "c" else gt.nll)(g["x"], g["y"], g["dx"])
+        assert abs(l1t - g["lik1_threaded"]) < 1e-11 * abs(g["lik1_threaded"]) and np.array_equal(g1t, g1)
+        if L >= 2:
+            assert abs(l1t - g["lik2"]) < 1e-12 * abs(g["lik2"])
+            assert abs(l1 - (g["lik2"] - g["sum_latent_nll"])) < 1e-11 * max(abs(g["lik2"]), abs(g["sum_latent_nll"]))
+        else:
+            assert l1t == l1 and gt.threading is False
         if "y_missing" in g:
             a = step(g["x"], g["y_missing"])
             assert rel_err(a[0], g["m3_xnew"]) < 1e-11 and rel_err(a[1], g["m3_yhat"]) < 1e-11
