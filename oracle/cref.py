@@ -75,10 +75,15 @@ def _ptr(a, typ=_dp):
 
 
 def _libname(native, wide):
+    if os.environ.get("MOIHGP_ORACLE_ASAN") == "1":          # `make -C oracle asan-test`: the sanitizer builds stand in for both
+        return "libmoihgp_oracle%s_asan.so" % ("_x" if wide else "")
     return "libmoihgp_oracle%s%s.so" % ("_x" if wide else "", "_native" if native else "")
 
 
 def build(native: bool = False, wide: bool = False) -> str:
+    if os.environ.get("MOIHGP_ORACLE_ASAN") == "1":
+        subprocess.run(["make", "-s", "-C", _HERE, "asan"], check=True)
+        return os.path.join(_HERE, "_build", _libname(native, wide))
     target = ("wide-native" if native else "wide") if wide else ("native" if native else "all")
     subprocess.run(["make", "-s", "-C", _HERE, target], check=True)
     return os.path.join(_HERE, "_build", _libname(native, wide))
@@ -105,6 +110,8 @@ def lib(native: bool = False, wide: bool = False):
     L.orc_expm.argtypes = [C.c_int, _dp, _dp]
     L.orc_ihgp_update.argtypes = [C.POINTER(OrcIHGP), C.c_int, C.c_double, _dp]
     L.orc_ihgp_update.restype = C.c_int
+    L.orc_ihgp_update_ss.argtypes = [C.POINTER(OrcIHGP), C.c_int, C.c_int, C.c_double, _dp, _dp, _dp, C.c_double, _dp, _dp, _dp]
+    L.orc_ihgp_update_ss.restype = C.c_int
     L.orc_ihgp_step.argtypes = [C.POINTER(OrcIHGP), _dp, C.c_int, C.c_double, _dp, _dp, _dp, _dp]
     L.orc_ihgp_nll.argtypes = [C.POINTER(OrcIHGP), _dp, C.c_double, _dp, _dp]
     L.orc_ihgp_nll.restype = C.c_double
@@ -165,6 +172,19 @@ def ihgp_update(kernel, dt, params):
     g = OrcIHGPX() if w else OrcIHGP()
     p = np.ascontiguousarray(params, dtype=np.float64)
     rc = lib(wide=w).orc_ihgp_update(C.byref(g), KERNEL_ID[kernel] if isinstance(kernel, str) else kernel, float(dt), _ptr(p))
+    assert rc >= 0
+    return g
+
+
+def ihgp_update_ss(ss, dt):
+    """IHGP::update (ihgp.h:117-201) on an arbitrary state-space object with numpy members F, Pinf, H, R, dF, dPinf, dR."""
+    d, P = ss.F.shape[0], len(ss.dF)
+    w = d > DMAX or P > PMAX
+    g = OrcIHGPX() if w else OrcIHGP()
+    c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    F, Pinf, H = c(ss.F), c(ss.Pinf), c(ss.H).reshape(-1)
+    dF, dPinf, dR = c(np.array(ss.dF)), c(np.array(ss.dPinf)), c([r[0, 0] for r in ss.dR])
+    rc = lib(wide=w).orc_ihgp_update_ss(C.byref(g), d, P, float(dt), _ptr(F), _ptr(Pinf), _ptr(H), float(ss.R[0, 0]), _ptr(dF), _ptr(dPinf), _ptr(dR))
     assert rc >= 0
     return g
 

@@ -214,7 +214,7 @@ class IHGP:
 
     def __init__(self, dt, kernel="Matern32"):
         self.dt = float(dt)
-        self.ss = KERNELS[kernel]()
+        self.ss = KERNELS[kernel]() if isinstance(kernel, str) else kernel    # or any StateSpace-like object (ihgp.h:17 template)
         self.num_param = self.ss.num_param
         self.dim = self.ss.dim
         self.update(self.ss.params)                               # :33

