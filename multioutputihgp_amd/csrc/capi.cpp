@@ -589,20 +589,20 @@ int moihgp_filter_stream_io(moihgp_gp* gp, int dtype, const void* Ty, size_t T, 
         return rc;
     }
     // time split across the wavefronts of a workgroup when there are too few latents to fill the chip
-    int nsplit = 1; size_t Tslice = T;
-    filter_split_plan(dtype, T, gp->L, &nsplit, &Tslice);
+    int nsplit = 1, nbig = 1; size_t Tslice = T;
+    filter_split_plan(dtype, T, gp->L, &nsplit, &Tslice, &nbig);
     if (const char* se = std::getenv("MOIHGP_FILTER_SPLIT")) {          // tuning hook: force the slice count (1 = off)
         int n = std::atoi(se);
         const size_t seg = 64 * (size_t)(dtype == 0 ? kChunk64 : kChunk32);
-        if (n <= 1 || T == 0) { nsplit = 1; Tslice = T; }
+        if (n <= 1 || T == 0) { nsplit = 1; Tslice = T; nbig = 1; }
         else {
             if (n > 8) n = 8;
             size_t per = ((T + seg - 1) / seg + n - 1) / n; if (per < 1) per = 1;
-            Tslice = per * seg; nsplit = (int)((T + Tslice - 1) / Tslice);
+            Tslice = per * seg; nsplit = (int)((T + Tslice - 1) / Tslice); nbig = nsplit;      // forced count: equal slices
         }
     }
     return launch_filter_stream(gp->d, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cb32, x_in, x, yhat, nll, (hipStream_t)stream, variant, e0, e1,
-                                nsplit, Tslice, gp->n_unstable[dtype == MOIHGP_F64 ? 0 : 1], nll_total);
+                                nsplit, Tslice, gp->n_unstable[dtype == MOIHGP_F64 ? 0 : 1], nll_total, nbig);
 }
 
 int moihgp_profile_enable(moihgp_gp* gp, int max_launches) {

@@ -128,10 +128,10 @@ int launch_filter_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, 
                          void* yhat, double* nll,
                          hipStream_t stream, int variant = 0, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
                          int nsplit = 1, size_t Tslice = 0, int n_unstable = 0 /* latents with SCANOK == 0 in this dtype's blocks */,
-                         double* total = nullptr /* device scalar: sum of nll[] (optional) */);
+                         double* total = nullptr /* device scalar: sum of nll[] (optional) */, int nbig = 0 /* see filter_split_plan; 0 = all slices alike */);
 void launch_nll_total(const double* nll, size_t L, double* total, hipStream_t stream);
 // Time split for small L (slices of one latent = wavefronts of one workgroup): nsplit == 1 means none.
-void filter_split_plan(int dtype, size_t T, size_t L, int* nsplit, size_t* Tslice);
+void filter_split_plan(int dtype, size_t T, size_t L, int* nsplit, size_t* Tslice, int* nbig /* leading slices of Tslice ticks; the rest hold one segment less */);
 int launch_grad_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, size_t L,
                        const double* cb64, const float* cb32, void* x, void* dx, void* yhat,
                        double* nll, double* grad, int* fallback /* int[L] scratch */, hipStream_t stream,

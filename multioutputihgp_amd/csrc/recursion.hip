@@ -392,7 +392,8 @@ template <typename T, int D, int CK, bool WRITE, bool NLL, int MINW, bool SPLIT,
 __global__ void __launch_bounds__(SPLIT ? 64 * kMaxSplit : 64 * kWavesPerBlock, SPLIT ? 1 : MINW)
 filter_scan_kernel(const T* __restrict__ Ty, size_t Ttot, size_t ld, size_t L, const T* __restrict__ cbT,
                    const double* __restrict__ cb64, const T* xin0 /* start state */, T* x /* end state; may be the same buffer */,
-                   T* __restrict__ yhat, double* __restrict__ nll, int nsplit, size_t Tslice) {
+                   T* __restrict__ yhat, double* __restrict__ nll, int nsplit, size_t Tslice,
+                   int nbig /* split: slices [0, nbig) hold Tslice ticks, the later ones one segment less (nbig == nsplit: all alike) */) {
     using V = typename VecOf<T>::type;
     using Lay = CB<D>;
     constexpr int EPV = 16 / sizeof(T);
@@ -410,8 +411,11 @@ filter_scan_kernel(const T* __restrict__ Ty, size_t Ttot, size_t ld, size_t L, c
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t l = SPLIT ? (size_t)blockIdx.x : (size_t)blockIdx.x * kWavesPerBlock + wave;
     if (!SPLIT && l >= L) return;
-    const size_t toff = SPLIT ? (size_t)wave * Tslice : 0;
-    const size_t Tlen = SPLIT ? (toff >= Ttot ? 0 : ((Ttot - toff) < Tslice ? (Ttot - toff) : Tslice)) : Ttot;
+    // split: the slice lengths differ by one segment at most, the longer ones first, so that with 8 waves (two per SIMD, wave w on
+    // SIMD w % 4) every SIMD carries the same number of segments: both passes are issue-bound once two waves share a SIMD
+    const size_t Tsl = SPLIT ? (wave < nbig ? Tslice : Tslice - 64 * CK) : 0;
+    const size_t toff = SPLIT ? (wave < nbig ? (size_t)wave * Tslice : (size_t)nbig * Tslice + (size_t)(wave - nbig) * (Tslice - 64 * CK)) : 0;
+    const size_t Tlen = SPLIT ? (toff >= Ttot ? 0 : ((Ttot - toff) < Tsl ? (Ttot - toff) : Tsl)) : Ttot;
     V* lds = lds_all[wave];
 
     // ---- per-latent constants: wave-uniform scalar loads, plus this lane's cross-row power ----------
@@ -591,7 +595,7 @@ filter_seq_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, co
 template <typename T, int D, int CK, int MINW, bool SPLIT>
 int launch_filter_t(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, const double* cb64, const void* xin, void* x,
                     void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, int nsplit, size_t Tslice, int n_unstable,
-                    double* total) {
+                    double* total, int nbig) {
     dim3 block(SPLIT ? 64 * nsplit : 64 * kWavesPerBlock);
     dim3 grid(SPLIT ? (unsigned)L : (unsigned)((L + kWavesPerBlock - 1) / kWavesPerBlock));
     constexpr size_t tile = 64 * (CK / (16 / sizeof(T)) + 1) * 16;                    // padded LDS tile per wave
@@ -603,13 +607,13 @@ int launch_filter_t(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* c
     T* yh = static_cast<T*>(yhat);
     // hipExtLaunchKernelGGL attaches the (optional) events to the dispatch itself: kernel-exact timing
     if (yhat && nll)
-        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, true, true, MINW, SPLIT>), grid, block, smem, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nsplit, Tslice);
+        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, true, true, MINW, SPLIT>), grid, block, smem, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nsplit, Tslice, nbig);
     else if (yhat)
-        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, true, false, MINW, SPLIT>), grid, block, smem, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nsplit, Tslice);
+        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, true, false, MINW, SPLIT>), grid, block, smem, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nsplit, Tslice, nbig);
     else if (nll)
-        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, false, true, MINW, SPLIT>), grid, block, smem, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nsplit, Tslice);
+        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, false, true, MINW, SPLIT>), grid, block, smem, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nsplit, Tslice, nbig);
     else
-        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, false, false, MINW, SPLIT>), grid, block, smem, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nsplit, Tslice);
+        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, false, false, MINW, SPLIT>), grid, block, smem, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nsplit, Tslice, nbig);
     if (n_unstable > 0)
         hipLaunchKernelGGL((filter_seq_kernel<T, D>), dim3((unsigned)((L + 63) / 64)), dim3(64), 0, stream, ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll);
     if (total && nll) hipLaunchKernelGGL(nll_total_kernel, dim3(1), dim3(1024), 0, stream, nll, L, total);
@@ -626,28 +630,33 @@ void launch_nll_total(const double* nll, size_t L, double* total, hipStream_t st
 
 // Slices per latent for the time split: enough wavefronts to occupy the chip when L is small, each slice a whole
 // number of segments so that only a latent's last slice is ragged; at most kMaxSplit slices (one workgroup).
-void filter_split_plan(int dtype, size_t T, size_t L, int* nsplit, size_t* Tslice) {
+void filter_split_plan(int dtype, size_t T, size_t L, int* nsplit, size_t* Tslice, int* nbig) {
     const size_t seg = 64 * (size_t)(dtype == 0 ? kChunk64 : kChunk32);
-    *nsplit = 1; *Tslice = T;
+    *nsplit = 1; *Tslice = T; *nbig = 1;
     if (L == 0 || L >= 1024 || T < 2 * seg) return;        // measured: pays below ~1024 latents (1 wave/SIMD)
     size_t want = (2048 + L - 1) / L;                      // aim for >= 2048 wavefronts
     if (want > (size_t)kMaxSplit) want = kMaxSplit;
-    size_t segs = (T + seg - 1) / seg;
-    size_t per = (segs + want - 1) / want;                   // segments per slice
-    size_t n = (segs + per - 1) / per;
-    if (n < 2) return;
-    *nsplit = (int)n; *Tslice = per * seg;
+    const size_t segs = (T + seg - 1) / seg;
+    if (want > segs) want = segs;
+    if (want < 2) return;
+    // `want` slices of per or per - 1 segments, the longer ones first (20 segments over 8 waves: 3 3 3 3 2 2 2 2, i.e. 5 segments on
+    // each of the four SIMDs; equal slices of 3 would put 6 on three of them)
+    const size_t per = (segs + want - 1) / want;
+    const size_t big = segs - want * (per - 1);              // slices that hold `per` segments; 1 <= big <= want
+    if (per == 1 && big < want) { *nsplit = (int)big; *Tslice = seg; *nbig = (int)big; return; }
+    *nsplit = (int)want; *Tslice = per * seg; *nbig = (int)big;
 }
 
 int launch_filter_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* cb64,
                          const float* cb32, const void* xin, void* x, void* yhat, double* nll, hipStream_t stream, int variant,
-                         hipEvent_t ev0, hipEvent_t ev1, int nsplit, size_t Tslice, int n_unstable, double* total) {
+                         hipEvent_t ev0, hipEvent_t ev1, int nsplit, size_t Tslice, int n_unstable, double* total, int nbig) {
     if (L == 0) return 0;
     if (nsplit > kMaxSplit) { set_last_error("nsplit > %d", kMaxSplit); return 1; }
+    if (nbig <= 0 || nbig > nsplit) nbig = nsplit;
 #define MOIHGP_FILTER_CASE(TT, DD, CKK, MW, CB)                                                                                   \
     do {                                                                                                                          \
-        if (nsplit > 1) return launch_filter_t<TT, DD, CKK, 1, true>(Ty, T, ld, L, CB, cb64, xin, x, yhat, nll, stream, ev0, ev1, nsplit, Tslice, n_unstable, total); \
-        return launch_filter_t<TT, DD, CKK, MW, false>(Ty, T, ld, L, CB, cb64, xin, x, yhat, nll, stream, ev0, ev1, 1, T, n_unstable, total);             \
+        if (nsplit > 1) return launch_filter_t<TT, DD, CKK, 1, true>(Ty, T, ld, L, CB, cb64, xin, x, yhat, nll, stream, ev0, ev1, nsplit, Tslice, n_unstable, total, nbig); \
+        return launch_filter_t<TT, DD, CKK, MW, false>(Ty, T, ld, L, CB, cb64, xin, x, yhat, nll, stream, ev0, ev1, 1, T, n_unstable, total, 1);             \
     } while (0)
     // register caps: fp32 <= 128 VGPRs (4 waves/SIMD: all 4096 wavefronts of a 4096-latent shard resident),
     // fp64 uncapped (188 VGPRs, 2 waves/SIMD: capping it to 168 spills and is 35 % slower)
@@ -660,15 +669,15 @@ int launch_filter_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, 
     if (variant == 2 || variant == 4 || variant == 6) {   // tuning probes: plain stores (2), nontemporal loads (4), both (6)
         dim3 block(64 * kWavesPerBlock), grid((unsigned)((L + kWavesPerBlock - 1) / kWavesPerBlock));
         const size_t sm = (size_t)kWavesPerBlock * (64 * 5 * 16 + 36 * 4);
-        if (variant == 2) hipExtLaunchKernelGGL((filter_scan_kernel<float, 3, kChunk32, true, true, 4, false, 2>), grid, block, sm, stream, ev0, ev1, 0, (const float*)Ty, T, ld, L, cb32, cb64, (const float*)xin, (float*)x, (float*)yhat, nll, 1, T);
-        else if (variant == 4) hipExtLaunchKernelGGL((filter_scan_kernel<float, 3, kChunk32, true, true, 4, false, 4>), grid, block, sm, stream, ev0, ev1, 0, (const float*)Ty, T, ld, L, cb32, cb64, (const float*)xin, (float*)x, (float*)yhat, nll, 1, T);
-        else hipExtLaunchKernelGGL((filter_scan_kernel<float, 3, kChunk32, true, true, 4, false, 6>), grid, block, sm, stream, ev0, ev1, 0, (const float*)Ty, T, ld, L, cb32, cb64, (const float*)xin, (float*)x, (float*)yhat, nll, 1, T);
+        if (variant == 2) hipExtLaunchKernelGGL((filter_scan_kernel<float, 3, kChunk32, true, true, 4, false, 2>), grid, block, sm, stream, ev0, ev1, 0, (const float*)Ty, T, ld, L, cb32, cb64, (const float*)xin, (float*)x, (float*)yhat, nll, 1, T, 1);
+        else if (variant == 4) hipExtLaunchKernelGGL((filter_scan_kernel<float, 3, kChunk32, true, true, 4, false, 4>), grid, block, sm, stream, ev0, ev1, 0, (const float*)Ty, T, ld, L, cb32, cb64, (const float*)xin, (float*)x, (float*)yhat, nll, 1, T, 1);
+        else hipExtLaunchKernelGGL((filter_scan_kernel<float, 3, kChunk32, true, true, 4, false, 6>), grid, block, sm, stream, ev0, ev1, 0, (const float*)Ty, T, ld, L, cb32, cb64, (const float*)xin, (float*)x, (float*)yhat, nll, 1, T, 1);
         return 0;
     }
     if (variant == 9) {   // tuning probe (staging only)
         dim3 block(64 * kWavesPerBlock), grid((unsigned)((L + kWavesPerBlock - 1) / kWavesPerBlock));
         hipExtLaunchKernelGGL((filter_scan_kernel<float, 3, kChunk32, true, true, 1, false, 1>), grid, block, (size_t)kWavesPerBlock * (64 * 5 * 16 + 36 * 4), stream, ev0, ev1, 0,
-                              (const float*)Ty, T, ld, L, cb32, cb64, (const float*)xin, (float*)x, (float*)yhat, nll, 1, T);
+                              (const float*)Ty, T, ld, L, cb32, cb64, (const float*)xin, (float*)x, (float*)yhat, nll, 1, T, 1);
         return 0;
     }
     if (variant == 1) MOIHGP_FILTER_CASE(float, 3, kChunk32, 1, cb32);

@@ -387,7 +387,8 @@ def test_project_unproject_stream(env, dtype, M, L, T):
 
 # ------------------------------------------------------------------------------------------ time split (small L)
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
-@pytest.mark.parametrize("L,T,nan", [(3, 5000, 0.0), (16, 10000, 0.0), (7, 4097, 0.03), (256, 10000, 0.0), (5, 2047, 0.0)])
+@pytest.mark.parametrize("L,T,nan", [(3, 5000, 0.0), (16, 10000, 0.0), (7, 4097, 0.03), (256, 10000, 0.0), (5, 2047, 0.0), (9, 16384, 0.001), (4, 16000, 0.0),
+                                     (6, 1025, 0.0), (5, 9000, 1.0)])
 def test_time_split_matches_unsplit(env, dtype, L, T, nan, monkeypatch):
     """With few latents the filter splits each stream into slices handled by different wavefronts (slice
     affine maps + carry).  Results must equal the unsplit sweep to rounding, and the oracle."""
@@ -399,7 +400,7 @@ def test_time_split_matches_unsplit(env, dtype, L, T, nan, monkeypatch):
     o = env["cref"].filter_stream(env["cref"].ihgp_array("Matern52", 0.1, prm), Ty, x0=x0)
     Tyd = to_dev(Ty, dtype)
     res = {}
-    for split in ("1", "0", "5"):                  # off, automatic, forced 5 slices
+    for split in ("1", "0", "5"):                  # off, automatic (slices of uneven length: the same number of segments per SIMD), forced 5 equal slices
         if split == "0":
             monkeypatch.delenv("MOIHGP_FILTER_SPLIT", raising=False)
         else:
