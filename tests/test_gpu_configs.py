@@ -1,0 +1,175 @@
+"""GPU suite (-m gpu): BASELINE.json's configurations that the kernel-level tests do not reach at their worded sizes.
+
+C1  configs[0]  "example_regression: M=4 outputs, T=500, Matern-3/2, fp64": 500 ticks through the per-tick reference ABI
+                (gp32_step3, one FFI crossing per tick, exactly as example.py:40-42 drives it) against the oracle's tick loop;
+                plus BASELINE's "d=4" reading of it: a bank of stacked 2 x Matern-3/2 latents over the same projected stream.
+C4  configs[3]  "M=32768, T=100000 streamed, fp32, sharded 8 x MI355X": ONE GPU's shard, 4096 latents x 10^5 ticks in ten 10^4-tick slabs
+                that carry the state: a 64-latent subset against the oracle, slab carry == one launch, additivity of the NLL over
+                slabs; and two ranks (gloo, both on the one GPU of the test box) whose 2048-latent shards add up to the 4096-latent
+                total through the path's only exchange, the 8-byte all-reduce.
+Tolerances (BASELINE.json north_star): 1e-6 relative fp64, 1e-3 fp32 on filtered means and NLL; tighter where the arithmetic allows."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err, rel_err_rows
+
+pytestmark = pytest.mark.gpu
+SEED = 20260101
+
+
+@pytest.fixture(scope="module")
+def env(hip_built):
+    assert torch.cuda.is_available(), "GPU suite needs a GPU"
+    torch.cuda.set_device(0)
+    from multioutputihgp_amd import MOIHGP, load_library
+    from multioutputihgp_amd import streams
+    from oracle import cref
+    assert load_library().moihgp_device_count() >= 1
+    return dict(MOIHGP=MOIHGP, streams=streams, cref=cref)
+
+
+def synth_params(L, rng):
+    return np.column_stack([rng.uniform(0.5, 2, L), rng.uniform(0.5, 2, L), rng.uniform(0.05, 0.2, L)])
+
+
+# ------------------------------------------------------------------------------------------ C1
+def test_c1_example_shape_through_the_per_tick_abi(env):
+    """configs[0]: M = L = 4, T = 500, Matern-3/2, fp64, one gp32_step3 per tick (example.py:40-42), then the same ticks through
+    step1 (with sensitivities) + lik1 / lik2 as the learners call them (online_learning.py:84-89)."""
+    M = L = 4; T = 500
+    rng = np.random.default_rng(SEED)
+    gp = env["MOIHGP"](0.1, M, L, kernel="Matern32")
+    ref = env["cref"].GP(0.1, M, L, "Matern32"); ref.set_literal_ugrad(0)
+    params = np.concatenate([(np.eye(M, L) + 0.1 * rng.standard_normal((M, L))).ravel(), rng.uniform(0.5, 2, L), [0.05], synth_params(L, rng).ravel()])
+    gp.update(params); ref.update(params)
+    Y = np.sin(0.05 * np.arange(T)[:, None] * (1 + np.arange(M)[None, :])) + 0.1 * rng.standard_normal((T, M))
+    x = np.zeros((L, 2)); xr = np.zeros((L, 2))
+    out, out_r = np.empty((T, M)), np.empty((T, M))
+    for t in range(T):
+        x, out[t] = gp.step(x, Y[t])
+        xr, out_r[t] = ref.step(xr, Y[t])
+    assert rel_err(out, out_r) < 1e-9 and rel_err(x, xr) < 1e-9
+    # the learners' loop on the same stream: step with sensitivities, NLL on the pre-step state (moihgp_online.h:64-66)
+    x, dx = np.zeros((L, 2)), np.zeros((L, 3, 2)); xr, dxr = x.copy(), dx.copy()
+    loss, loss_r, grad, grad_r = 0.0, 0.0, np.zeros(gp.num_param), np.zeros(gp.num_param)
+    for t in range(60):
+        l1, g1 = gp.negLogLikelihood(x, Y[t], dx); l2, g2 = ref.negLogLikelihood(xr, Y[t], dxr)
+        loss += l1; loss_r += l2; grad += g1; grad_r += g2
+        assert abs(gp.negLogLikelihood(x, Y[t]) - ref.negLogLikelihood(xr, Y[t])) < 1e-9 * abs(ref.negLogLikelihood(xr, Y[t]))
+        x, _, dx = gp.step(x, Y[t], dx); xr, _, dxr = ref.step(xr, Y[t], dxr)
+    assert abs(loss - loss_r) < 1e-9 * abs(loss_r) and rel_err(grad, grad_r) < 1e-8
+    # the batched entries on the same 500 ticks: project -> sweep -> unproject == the tick loop
+    from multioutputihgp_amd.streams import LatentBank, project_stream, unproject_stream
+    Yd = torch.from_numpy(Y).cuda()
+    Ty = project_stream(gp, Yd)
+    yl, xT, nll = LatentBank.from_handle(gp).filter(Ty, T=T)
+    Yhat = unproject_stream(gp, yl, T)
+    torch.cuda.synchronize()
+    assert rel_err(Yhat.cpu().numpy(), out_r) < 1e-9
+
+
+def test_c1_d4_reading_stacked_matern32_bank(env):
+    """BASELINE.json words configs[0] "Matern-3/2 d=4": the reference's Matern-3/2 has d = 2 (matern32ss.h:95); d = 4 is the stacked
+    2 x Matern-3/2 latent.  Four such latents over 500 ticks of the projected C1 stream, against the oracle."""
+    L, T = 4, 500
+    rng = np.random.default_rng(SEED + 1)
+    prm = np.column_stack([rng.uniform(0.5, 2, L), rng.uniform(0.5, 2, L), rng.uniform(0.5, 2, L), rng.uniform(0.5, 2, L), rng.uniform(0.05, 0.2, L)])
+    Ty = np.sin(0.05 * np.arange(T)[None, :] * (1 + np.arange(L)[:, None])) + 0.1 * rng.standard_normal((L, T))
+    bank = env["streams"].LatentBank(0.1, prm, kernel="Matern32x2")
+    assert bank.d == 4
+    o = env["cref"].filter_stream(env["cref"].ihgp_array("Matern32x2", 0.1, prm), Ty)
+    from multioutputihgp_amd.streams import alloc_stream
+    Tyd = alloc_stream(L, T, torch.float64); Tyd.zero_(); Tyd[:, :T] = torch.from_numpy(Ty)
+    yhat, xT, nll = bank.filter(Tyd, T=T)
+    torch.cuda.synchronize()
+    ok = np.isfinite(o["yhat"]).all(axis=1) & (np.abs(o["yhat"]).max(axis=1) < 1e6)       # (the literal DARE can give an unstable stacked latent)
+    assert ok.sum() >= 2
+    assert rel_err(yhat[:, :T].cpu().numpy()[ok], o["yhat"][ok]) < 1e-9 and rel_err(nll.cpu().numpy()[ok], o["nll_per_latent"][ok]) < 1e-9
+
+
+# ------------------------------------------------------------------------------------------ C4
+def _c4_inputs(L, T, lo=0):
+    """bench.py's C4 shard inputs (same generator, same seed): fp32 stream, 4096 latents per GPU."""
+    import bench
+    prm = bench.synth_params(4096, 0, np.random.default_rng(bench.SEED))[lo:lo + L]
+    Ty = bench.synth_stream(4096, 0, T, torch.float32, torch.device("cuda", 0), bench.SEED + 1)[lo:lo + L]
+    return prm, Ty
+
+
+def test_c4_shard_in_slabs(env):
+    """One GPU's shard of configs[3]: 4096 latents x 10^5 ticks, fp32, swept as ten 10^4-tick slabs that carry the state."""
+    L, T, SLAB = 4096, 100000, 10000
+    prm, Ty = _c4_inputs(L, T)
+    bank = env["streams"].LatentBank(0.1, prm, kernel="Matern52ss")
+    # (a) the whole stream in ONE launch
+    y1, x1, n1 = bank.filter(Ty, T=T)
+    # (b) ten slabs, each its own contiguous buffer (as slabs of a stream arrive), the state carried from launch to launch
+    x = torch.zeros((L, 3), dtype=torch.float32, device="cuda")
+    nll_slabs, y_slabs = [], []
+    for k in range(T // SLAB):
+        slab = Ty[:, k * SLAB:(k + 1) * SLAB].contiguous()
+        yk, x, nk = bank.filter(slab, T=SLAB, x=x)
+        y_slabs.append(yk[:, :SLAB]); nll_slabs.append(nk.clone())
+    torch.cuda.synchronize()
+    y2 = torch.cat(y_slabs, dim=1)
+    n2 = torch.stack(nll_slabs).sum(dim=0)
+    # slab carry == one launch (fp32 rounding order differs at the slab boundaries only: 10^4 is not a multiple of the 1024-tick segment)
+    assert rel_err_rows(y2.double().cpu().numpy(), y1[:, :T].double().cpu().numpy()) < 2e-5
+    assert rel_err_rows(x.double().cpu().numpy(), x1.double().cpu().numpy(), floor=1e-3) < 1e-4
+    # additivity of the NLL over slabs: per latent and in total
+    assert rel_err(n2.cpu().numpy(), n1.cpu().numpy()) < 1e-6
+    assert abs(n2.sum().item() - n1.sum().item()) < 1e-7 * abs(n1.sum().item())
+    # a 64-latent subset against the fp64 oracle on identical inputs (the bar: 1e-3 on filtered means and NLL)
+    sub = np.arange(0, L, L // 64)[:64]
+    o = env["cref"].filter_stream(env["cref"].ihgp_array("Matern52", 0.1, prm[sub]), Ty[sub][:, :T].double().cpu().numpy(), nthreads=8)
+    assert rel_err_rows(y2[sub].double().cpu().numpy(), o["yhat"]) < 1e-3
+    assert rel_err(n2[sub].cpu().numpy(), o["nll_per_latent"]) < 1e-4
+    # and the oracle's own fp32 loop (same arithmetic type) on a few of them, tighter
+    of = env["cref"].filter_stream(env["cref"].ihgp_array("Matern52", 0.1, prm[sub[:8]]), Ty[sub[:8]][:, :T].cpu().numpy(), nthreads=8)
+    assert rel_err_rows(y2[sub[:8]].cpu().numpy(), of["yhat"]) < 1e-4
+
+
+def _c4_rank(rank, world, port, q):
+    import os
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)       # 2 ranks share the one GPU of the test box: exchange on gloo
+    torch.cuda.set_device(0)
+    from multioutputihgp_amd.sharded import allreduce_nll, shard_bounds
+    from multioutputihgp_amd.streams import LatentBank
+    Lg, T, SLAB = 4096, 20000, 10000
+    lo, hi = shard_bounds(Lg, world, rank)
+    prm, Ty = _c4_inputs(hi - lo, T, lo)
+    bank = LatentBank(0.1, prm, kernel="Matern52ss")
+    x = torch.zeros((hi - lo, 3), dtype=torch.float32, device="cuda")
+    acc = torch.zeros((hi - lo,), dtype=torch.float64, device="cuda")
+    for k in range(T // SLAB):
+        _, x, nk = bank.filter(Ty[:, k * SLAB:(k + 1) * SLAB].contiguous(), T=SLAB, x=x, want_yhat=False)
+        acc += nk
+    total = allreduce_nll(acc)                                          # the path's only exchange: 8 bytes
+    torch.cuda.synchronize()
+    q.put((rank, lo, hi, float(total.item()), float(acc.sum().item())))
+    dist.destroy_process_group()
+
+
+def test_c4_two_shards_add_up_to_the_unsharded_total(env):
+    """configs[3] shards the latents over ranks with no data-path collective; the only exchange is the all-reduce of the NLL scalar.
+    Two 2048-latent shards (two processes, gloo) against one 4096-latent bank on the same streams."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_c4_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
+    for p in procs: p.join(timeout=60)
+    (_, lo0, hi0, tot0, own0), (_, lo1, hi1, tot1, own1) = res
+    assert (lo0, hi0, lo1, hi1) == (0, 2048, 2048, 4096)
+    assert tot0 == tot1 and abs(tot0 - (own0 + own1)) <= 1e-12 * abs(tot0)
+    prm, Ty = _c4_inputs(4096, 20000)
+    bank = env["streams"].LatentBank(0.1, prm, kernel="Matern52ss")
+    _, _, nll = bank.filter(Ty, T=20000, want_yhat=False)
+    torch.cuda.synchronize()
+    assert abs(nll.sum().item() - tot0) < 1e-6 * abs(tot0)             # (one 2 x 10^4 launch vs two 10^4 slabs: fp32 rounding at the slab seam)

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, rel_err
+from conftest import load_golden, rel_err, rel_err_rows
 
 pytestmark = pytest.mark.gpu
 
@@ -220,7 +220,7 @@ def test_stream_vs_golden_fp64(env, kern, tag):
     x = torch.from_numpy(g["x0"]).cuda()
     yhat, xT, nll = bank.filter(Ty, T=T, x=x)
     torch.cuda.synchronize()
-    e = (rel_err(yhat[:, :T].cpu().numpy(), g["yhat"]), rel_err(xT.cpu().numpy(), g["xT"]), rel_err(nll.cpu().numpy(), g["nll"]))
+    e = (rel_err_rows(yhat[:, :T].cpu().numpy(), g["yhat"]), rel_err(xT.cpu().numpy(), g["xT"]), rel_err(nll.cpu().numpy(), g["nll"]))
     print(f"stream fp64 {kern} {tag}: yhat {e[0]:.2e} x {e[1]:.2e} nll {e[2]:.2e}")
     assert max(e) < FP64_TIGHT and max(e) < FP64_TOL
 
@@ -235,7 +235,7 @@ def test_stream_vs_golden_fp32(env, kern, tag):
     x = torch.from_numpy(g["x0"]).float().cuda()
     yhat, xT, nll = bank.filter(Ty, T=T, x=x)
     torch.cuda.synchronize()
-    e = (rel_err(yhat[:, :T].cpu().numpy(), g["yhat"]), rel_err(xT.cpu().numpy(), g["xT"]), rel_err(nll.cpu().numpy(), g["nll"]))
+    e = (rel_err_rows(yhat[:, :T].cpu().numpy(), g["yhat"]), rel_err(xT.cpu().numpy(), g["xT"]), rel_err(nll.cpu().numpy(), g["nll"]))
     print(f"stream fp32 {kern} {tag}: yhat {e[0]:.2e} x {e[1]:.2e} nll {e[2]:.2e}")
     assert max(e) < FP32_TOL
 
@@ -262,7 +262,7 @@ def test_stream_ragged_shapes_vs_oracle(env, dtype, L, T):
     yhat, xT, nll = bank.filter(Tyd, T=T, x=torch.from_numpy(x0).to(dtype).cuda(), yhat=yh)
     torch.cuda.synchronize()
     tol = FP64_TIGHT if dtype == torch.float64 else FP32_TOL
-    assert rel_err(yhat[:, :T].cpu().numpy(), o["yhat"]) < tol
+    assert rel_err_rows(yhat[:, :T].cpu().numpy(), o["yhat"]) < tol
     assert rel_err(xT.cpu().numpy(), o["x"]) < tol
     assert rel_err(nll.cpu().numpy(), o["nll_per_latent"]) < tol
     # nll-only and yhat-only variants agree with the fused one
@@ -316,7 +316,7 @@ def test_full_size_properties(env, dtype, L, T):
     torch.cuda.synchronize()
     sub = np.sort(rng.choice(L, size=64, replace=False))
     o = env["cref"].filter_stream(env["cref"].ihgp_array("Matern52", 0.1, prm[sub]), np.ascontiguousarray(Ty[sub]), nthreads=4)
-    e = (rel_err(yhat[sub][:, :T].cpu().numpy(), o["yhat"]), rel_err(xT[sub].cpu().numpy(), o["x"]), rel_err(nll[sub].cpu().numpy(), o["nll_per_latent"]))
+    e = (rel_err_rows(yhat[sub][:, :T].cpu().numpy(), o["yhat"]), rel_err(xT[sub].cpu().numpy(), o["x"]), rel_err(nll[sub].cpu().numpy(), o["nll_per_latent"]))
     print(f"full-size {dtype} L={L}: subset vs oracle yhat {e[0]:.2e} x {e[1]:.2e} nll {e[2]:.2e}")
     assert max(e) < (FP64_TOL if dtype == torch.float64 else FP32_TOL)
     # linearity (zero initial state): f(a y1 + b y2) = a f(y1) + b f(y2)
@@ -349,7 +349,7 @@ def test_gradstream_vs_golden(env, kern, dtype):
                   dx=torch.from_numpy(g["dx0"]).to(dtype).cuda(), want_yhat=True)
     torch.cuda.synchronize()
     tol = FP64_TIGHT if dtype == torch.float64 else FP32_TOL
-    assert rel_err(r["yhat"][:, :T].cpu().numpy(), g["yhat"]) < tol
+    assert rel_err_rows(r["yhat"][:, :T].cpu().numpy(), g["yhat"]) < tol
     assert rel_err(r["x"].cpu().numpy(), g["xT"]) < tol and rel_err(r["dx"].cpu().numpy(), g["dxT"]) < tol * 10
     assert rel_err(r["nll"].cpu().numpy(), g["nll"]) < tol and rel_err(r["grad"].cpu().numpy(), g["grad"]) < tol * 10
 
@@ -410,7 +410,7 @@ def test_time_split_matches_unsplit(env, dtype, L, T, nan, monkeypatch):
         torch.cuda.synchronize()
         res[split] = (yhat[:, :T].cpu().numpy(), xT.cpu().numpy(), nll.cpu().numpy())
         tol = FP64_TIGHT if dtype == torch.float64 else FP32_TOL
-        assert rel_err(res[split][0], o["yhat"]) < tol and rel_err(res[split][1], o["x"]) < tol
+        assert rel_err_rows(res[split][0], o["yhat"]) < tol and rel_err(res[split][1], o["x"]) < tol
         assert rel_err(res[split][2], o["nll_per_latent"]) < tol
         assert rel_err(xT2.cpu().numpy(), o["x"]) < tol
     tight = 1e-11 if dtype == torch.float64 else 2e-4
@@ -466,7 +466,7 @@ def test_gradstream_vs_oracle(env, dtype, kern, L, T, nan):
     r = bank.grad(to_dev(Ty, dtype), T=T, x=torch.from_numpy(x0).to(dtype).cuda(), dx=torch.from_numpy(dx0).to(dtype).cuda(), want_yhat=True)
     torch.cuda.synchronize()
     tol = 1e-9 if dtype == torch.float64 else FP32_TOL
-    assert rel_err(r["yhat"][:, :T].cpu().numpy(), o["yhat"]) < tol
+    assert rel_err_rows(r["yhat"][:, :T].cpu().numpy(), o["yhat"]) < tol
     assert rel_err(r["x"].cpu().numpy(), o["x"]) < tol and rel_err(r["dx"].cpu().numpy(), o["dx"]) < tol * 10
     assert rel_err(r["nll"].cpu().numpy(), o["nll_per_latent"]) < tol
     assert rel_err(r["grad"].cpu().numpy(), o["grad"]) < tol * 10
@@ -493,7 +493,7 @@ def test_gradstream_segment_boundaries_of_the_long_stream_kernels(env, dtype, ke
     r = bank.grad(to_dev(Ty, dtype), T=T, x=torch.from_numpy(x0).to(dtype).cuda(), dx=torch.from_numpy(dx0).to(dtype).cuda(), want_yhat=True)
     torch.cuda.synchronize()
     tol = 1e-9 if dtype == torch.float64 else FP32_TOL
-    assert rel_err(r["yhat"][:, :T].cpu().numpy(), o["yhat"]) < tol
+    assert rel_err_rows(r["yhat"][:, :T].cpu().numpy(), o["yhat"]) < tol
     assert rel_err(r["x"].cpu().numpy(), o["x"]) < tol and rel_err(r["dx"].cpu().numpy(), o["dx"]) < tol * 10
     assert rel_err(r["nll"].cpu().numpy(), o["nll_per_latent"]) < tol
     assert rel_err(r["grad"].cpu().numpy(), o["grad"]) < tol * 10
@@ -655,7 +655,7 @@ def test_stacked_vs_golden(env, kern):
         for dtype, tol in ((torch.float64, FP64_TIGHT), (torch.float32, FP32_TOL)):
             yhat, xT, nll = bank.filter(to_dev(g[f"{tag}_Ty"], dtype), T=T, x=torch.from_numpy(g[f"{tag}_x0"]).to(dtype).cuda())
             torch.cuda.synchronize()
-            e = (rel_err(yhat[:, :T].cpu().numpy(), g[f"{tag}_yhat"]), rel_err(xT.cpu().numpy(), g[f"{tag}_xT"]), rel_err(nll.cpu().numpy(), g[f"{tag}_nll"]))
+            e = (rel_err_rows(yhat[:, :T].cpu().numpy(), g[f"{tag}_yhat"]), rel_err(xT.cpu().numpy(), g[f"{tag}_xT"]), rel_err(nll.cpu().numpy(), g[f"{tag}_nll"]))
             assert max(e) < tol, (kern, tag, dtype, e)
 
 
@@ -800,7 +800,7 @@ def test_stacked_full_size_properties(env, kern, dtype, L, T):
     torch.cuda.synchronize()
     sub = np.sort(rng.choice(L, size=48, replace=False))
     o = env["cref"].filter_stream(env["cref"].ihgp_array(kern, 0.1, prm[sub]), np.ascontiguousarray(Ty[sub]), nthreads=4)
-    e = (rel_err(yhat[sub][:, :T].cpu().numpy(), o["yhat"]), rel_err(xT[sub].cpu().numpy(), o["x"]), rel_err(nll[sub].cpu().numpy(), o["nll_per_latent"]))
+    e = (rel_err_rows(yhat[sub][:, :T].cpu().numpy(), o["yhat"]), rel_err(xT[sub].cpu().numpy(), o["x"]), rel_err(nll[sub].cpu().numpy(), o["nll_per_latent"]))
     print(f"stacked full-size {kern} {dtype} L={L}: subset vs oracle yhat {e[0]:.2e} x {e[1]:.2e} nll {e[2]:.2e}")
     assert max(e) < (FP64_TOL if dtype == torch.float64 else FP32_TOL)
     Y2 = to_dev(synth(L, T, rng), dtype)
