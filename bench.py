@@ -295,7 +295,8 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    from multioutputihgp_amd.sharded import allreduce_nll, allreduce_nll_async, allreduce_total, allreduce_total_async, shard_bounds
+    from multioutputihgp_amd.sharded import (allreduce_nll, allreduce_nll_async, allreduce_total, allreduce_total_async, max_over_ranks,
+                                             run_pipelined, shard_bounds)
     from multioutputihgp_amd.streams import LatentBank
 
     if args.config == "c1":
@@ -358,31 +359,19 @@ def main():
     else:
         # every pass still ends in its own all-reduce of the NLL scalar, but the exchange of pass k runs on the communicator's
         # stream while pass k+1 sweeps (two in flight at most); all of them are complete before the clock stops
-        pending = []
-        for k in range(args.steps):
-            try:
-                pending.append(one_pass(reduce=allreduce_nll_async))
-            except RuntimeError as e:              # a communicator without async collectives: finish in the ordered form
-                sys.stderr.write(f"async all-reduce unavailable ({e}); continuing stream-ordered\n")
-                for p_ in pending:
-                    total = p_.wait()
-                pending = []
-                for _ in range(k, args.steps):
-                    total = one_pass()
-                break
-            if len(pending) > 2:
-                total = pending.pop(0).wait()
-        for p_ in pending:
-            total = p_.wait()
+        # (sharded.run_pipelined: the same loop the 8-rank gloo test drives on the CPU)
+        try:
+            total = run_pipelined(args.steps, lambda: one_pass(reduce=allreduce_nll_async), max_in_flight=2)[-1]
+        except RuntimeError as e:                  # a communicator without async collectives: the ordered form
+            sys.stderr.write(f"async all-reduce unavailable ({e}); continuing stream-ordered\n")
+            for k in range(args.steps):
+                total = one_pass()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else device)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = tmax.item()
+    elapsed = max_over_ranks(elapsed, device="cpu" if rehearsal else device)
     kern_samples = bank.profile_read()
     kern_ms = float(np.mean(kern_samples))                          # mean over the sampled launches of the timed region
 

@@ -71,6 +71,34 @@ def allreduce_nll_async(nll_local: torch.Tensor, group=None) -> PendingSum:
     return allreduce_total_async(nll_local.sum(dtype=torch.float64).reshape(1), group)
 
 
+def run_pipelined(steps: int, one_pass_async, max_in_flight: int = 2):
+    """The timed loop of the N-GPU bench (bench.py): every pass ends in its own all-reduce of the NLL scalar, but the exchange of pass k
+    runs while pass k + 1 sweeps -- at most `max_in_flight` reductions outstanding, all of them complete on return.
+    `one_pass_async()` launches one pass and returns a PendingSum.  Returns the list of reduced totals in pass order."""
+    pending, totals = [], []
+    for _ in range(steps):
+        pending.append(one_pass_async())
+        if len(pending) > max_in_flight:
+            totals.append(pending.pop(0).wait().clone())     # (the caller's ring slot is reused by a later pass)
+    for p_ in pending:
+        totals.append(p_.wait().clone())
+    return totals
+
+
+def max_over_ranks(seconds: float, device="cpu", group=None) -> float:
+    """Wall time of the slowest rank (the bench contract: barrier + synchronize on both sides, then the MAX over ranks)."""
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t.item())
+
+
+def time_slice_bounds(T: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Ticks [lo, hi) of the prediction stream a rank keeps after the reduce-scatter form of the un-projection (same balanced partition
+    as shard_bounds, over time instead of latents)."""
+    return shard_bounds(T, world_size, rank)
+
+
 def gather_latent_grads(grad_local: torch.Tensor, L: int, group=None) -> torch.Tensor:
     """Per-latent gradients are disjoint across shards: all-gather [L_r, P] blocks into [L, P]
     (mode G only; moihgp.h:608-609 packs them latent-major)."""
@@ -102,14 +130,20 @@ class ShardedMOIHGP:
     of the same shape; they are evaluated from the already reduced quantities on every rank.
     """
 
-    def __init__(self, dt, num_output, num_latent, kernel="Matern52ss", group=None):
+    def __init__(self, dt, num_output, num_latent, kernel="Matern52ss", group=None, seed=20260101):
+        from ._lib import load_library
         from .pywrapper import MOIHGP
         self.group = group
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
+        if self.world > num_latent:
+            raise ValueError(f"ShardedMOIHGP: {self.world} ranks for {num_latent} latents -- every rank needs at least one latent")
         self.M, self.L = num_output, num_latent
         self.lo, self.hi = shard_bounds(num_latent, self.world, self.rank)
         self._full = MOIHGP(dt, num_output, num_latent, kernel=kernel)          # polar factor + bookkeeping of all parameters
+        # the constructor draws U from std::random_device (moihgp.h:105-113): re-draw it from a fixed seed so that every rank
+        # holds the SAME orthonormal factor before the first update() (a filter() on freshly built objects is then consistent)
+        load_library().moihgp_reseed_U(self._full.handle, int(seed))
         self._shard = MOIHGP(dt, num_output, self.hi - self.lo, kernel=kernel)  # this rank's latent columns
         self._sync_shard()
 
@@ -125,7 +159,7 @@ class ShardedMOIHGP:
         Ss = np.ascontiguousarray(p[M * L + self.lo:M * L + self.hi])
         self.sigma = float(p[M * L + L])
         self.S = p[M * L:M * L + L].copy()
-        igp = np.ascontiguousarray(p[M * L + L + 1:].reshape(L, 3)[self.lo:self.hi])
+        igp = np.ascontiguousarray(p[M * L + L + 1:].reshape(L, self._full.num_igp_param)[self.lo:self.hi])
         if lib.moihgp_set_mixing(self._shard.handle, Us.ctypes.data_as(c_double_p), Ss.ctypes.data_as(c_double_p), C.c_double(self.sigma)):
             raise RuntimeError("moihgp_set_mixing failed")
         if lib.moihgp_update_latents(self._shard.handle, igp.ctypes.data_as(c_double_p)):
@@ -149,21 +183,55 @@ class ShardedMOIHGP:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
-    def filter(self, Y: torch.Tensor):
-        """Y [T, M] (CUDA, fp32/fp64, replicated on every rank).  Returns (Yhat [T, M], nll_total) where nll_total is the sum
-        over ticks of MOIHGP::negLogLikelihood(x, y) (moihgp.h:614-688) along the filtered trajectory."""
+    def _reduce_scatter_rows(self, t):
+        """[2, T, M] partial slabs -> this rank's time slice [2, T_r, M] of their sum over ranks.  RCCL: one reduce-scatter (half the
+        bytes of an all-reduce on the xGMI ring: every rank receives only the rows it keeps); gloo (CPU rehearsal of the host logic)
+        has no reduce-scatter: all-reduce, then slice."""
+        T = t.shape[1]
+        lo, hi = time_slice_bounds(T, self.world, self.rank)
+        if self.world == 1:
+            return t
+        if dist.get_backend(self.group) == "gloo":
+            c = t.cpu() if t.is_cuda else t
+            dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group)
+            return c[:, lo:hi].to(t.device)
+        # equal blocks for reduce_scatter_tensor: pad the time axis to world * ceil(T / world) rows (rows past T are zero in every rank)
+        per = (T + self.world - 1) // self.world
+        pad = torch.zeros((self.world, 2, per, t.shape[2]), dtype=t.dtype, device=t.device)
+        for r in range(self.world):
+            a, b = time_slice_bounds(T, self.world, r)
+            pad[r, :, :b - a] = t[:, a:b]
+        out = torch.empty((2, per, t.shape[2]), dtype=t.dtype, device=t.device)
+        dist.reduce_scatter_tensor(out, pad, op=dist.ReduceOp.SUM, group=self.group)
+        return out[:, :hi - lo]
+
+    def filter(self, Y: torch.Tensor, scatter: bool = False):
+        """Y [T, M] (CUDA, fp32/fp64, replicated on every rank).  Returns (Yhat, nll_total) where nll_total is the sum over ticks of
+        MOIHGP::negLogLikelihood(x, y) (moihgp.h:614-688) along the filtered trajectory.
+        scatter=False: Yhat [T, M] on every rank (one all-reduce of the 2 T M partial elements).
+        scatter=True : Yhat [T_r, M], this rank's time slice `time_slice_bounds(T, world, rank)` only -- the partial predictions are
+                       combined by a reduce-scatter (half the ring traffic of the all-reduce) and the residual term of moihgp.h:651 is
+                       formed on the local rows, then summed with the NLL scalar."""
         from .streams import LatentBank, project_stream, unproject_stream
+        import math
         T = Y.shape[0]
         Ty = project_stream(self._shard, Y)
         bank = LatentBank.from_handle(self._shard)
         yhat_lat, _, nll = bank.filter(Ty, T=T)
         part = unproject_stream(self._shard, yhat_lat, T)                 # this rank's partial prediction
         uuty = unproject_stream(self._shard, Ty, T)                       # this rank's part of U U^T y (same GEMM shape)
-        both = self._allreduce(torch.stack([part, uuty]))                 # one collective for both [T, M] slabs
-        Yhat, UUty = both[0], both[1]
-        nll_lat = allreduce_nll(nll, self.group)
-        resid = (Y - UUty).double().norm(dim=1)                           # ||(I - U U^T) y_t||, un-squared (moihgp.h:651)
         m_n = max(float(self.M - self.L), 0.0)
-        import math
-        glob = T * (0.5 * math.log(float(self.S.sum())) + 0.5 * m_n * math.log(self.sigma)) + 0.5 * float(resid.sum()) / self.sigma
-        return Yhat, float(nll_lat.item()) + glob
+        glob_const = T * (0.5 * math.log(float(self.S.sum())) + 0.5 * m_n * math.log(self.sigma))
+        if not scatter:
+            both = self._allreduce(torch.stack([part, uuty]))             # one collective for both [T, M] slabs
+            Yhat, UUty = both[0], both[1]
+            nll_lat = allreduce_nll(nll, self.group)
+            resid = (Y - UUty).double().norm(dim=1)                       # ||(I - U U^T) y_t||, un-squared (moihgp.h:651)
+            return Yhat, float(nll_lat.item()) + glob_const + 0.5 * float(resid.sum()) / self.sigma
+        lo, hi = time_slice_bounds(T, self.world, self.rank)
+        both = self._reduce_scatter_rows(torch.stack([part, uuty]))
+        Yhat, UUty = both[0], both[1]
+        resid_local = (Y[lo:hi] - UUty).double().norm(dim=1).sum()
+        scal = nll.sum(dtype=torch.float64).reshape(1) + 0.5 * resid_local.reshape(1) / self.sigma   # per-latent NLLs + this slice's residual term
+        tot = allreduce_total(scal, self.group)
+        return Yhat, float(tot.item()) + glob_const

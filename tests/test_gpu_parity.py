@@ -549,9 +549,15 @@ def _sharded_worker(rank, world, port, M, L, T, q):
     Y = rng.standard_normal((T, M))
     sh = ShardedMOIHGP(0.1, M, L, kernel="Matern32")
     sh.update(params)
-    Yhat, nll = sh.filter(torch.from_numpy(Y).cuda())
+    Yd = torch.from_numpy(Y).cuda()
+    Yhat, nll = sh.filter(Yd)
+    # reduce-scatter form: every rank keeps its time slice of the prediction, the residual term is formed on the local rows
+    Ys, nll_s = sh.filter(Yd, scatter=True)
+    # freshly constructed objects (no update()): the constructor's random U is re-drawn from a fixed seed, so the ranks agree
+    sh0 = ShardedMOIHGP(0.1, M, L, kernel="Matern32")
+    Y0, nll0 = sh0.filter(Yd)
     torch.cuda.synchronize()
-    q.put((rank, Yhat.cpu().numpy(), nll, params, Y))
+    q.put((rank, Yhat.cpu().numpy(), nll, params, Y, Ys.cpu().numpy(), nll_s, sh0.params.copy(), Y0.cpu().numpy(), nll0))
     dist.destroy_process_group()
 
 
@@ -568,8 +574,13 @@ def test_sharded_pipeline_two_ranks_vs_oracle(env, M, L, T):
     for p in procs: p.start()
     res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
     for p in procs: p.join(timeout=60)
-    (_, Yhat0, nll0, params, Y), (_, Yhat1, nll1, _, _) = res
+    (_, Yhat0, nll0, params, Y, Ys0, nlls0, p00, Y00, n00), (_, Yhat1, nll1, _, _, Ys1, nlls1, p01, Y01, n01) = res
     assert np.array_equal(Yhat0, Yhat1) and nll0 == nll1
+    from multioutputihgp_amd.sharded import time_slice_bounds
+    a0, b0 = time_slice_bounds(T, 2, 0); a1, b1 = time_slice_bounds(T, 2, 1)
+    assert Ys0.shape == (b0 - a0, M) and Ys1.shape == (b1 - a1, M)
+    assert rel_err(np.concatenate([Ys0, Ys1]), Yhat0) < 1e-13 and nlls0 == nlls1 and abs(nlls0 - nll0) < 1e-12 * abs(nll0)
+    assert np.array_equal(p00, p01) and np.array_equal(Y00, Y01) and n00 == n01      # same seeded U on both ranks before any update()
     ref = env["cref"].GP(0.1, M, L, "Matern32"); ref.update(params)
     x = np.zeros((L, 2)); yh = np.zeros((T, M)); nll = 0.0
     for t in range(T):

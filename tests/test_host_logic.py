@@ -64,3 +64,67 @@ def test_nll_allreduce_and_grad_gather_gloo_world2(L):
     res = [q.get(timeout=120) for _ in procs]
     for p in procs: p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+# ------------------------------------------------------------------------------------------ 8 ranks: the host logic of `bench.py --gpus 8 --config c4`
+def _worker8(rank, ws, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    from multioutputihgp_amd.sharded import (ShardedMOIHGP, allreduce_total_async, max_over_ranks, run_pipelined, time_slice_bounds)
+    ok = True
+    # (1) shard bounds of configs[3]: 32768 latents over 8 ranks -> 4096 each, contiguous
+    lo, hi = shard_bounds(32768, ws, rank)
+    ok &= (lo, hi) == (4096 * rank, 4096 * (rank + 1))
+    # (2) the pipelined loop of the timed region: pass k of rank r contributes (k + 1) * (r + 1); two reductions in flight at most
+    passes, in_flight_max = [0], [0]
+    ring = [torch.zeros(1, dtype=torch.float64) for _ in range(4)]      # NLL totals of the passes in flight (bench.py tot_ring)
+
+    def one_pass_async():
+        k = passes[0]; passes[0] += 1
+        tot = ring[k % len(ring)]
+        tot.fill_((k + 1) * (rank + 1))
+        return allreduce_total_async(tot)
+
+    totals = run_pipelined(7, one_pass_async, max_in_flight=2)
+    ok &= passes[0] == 7 and [float(t.item()) for t in totals] == [(k + 1) * ws * (ws + 1) / 2 for k in range(7)]
+    # (3) max-over-ranks timing: every rank reports the slowest rank's wall time
+    ok &= abs(max_over_ranks(0.001 * (rank + 1)) - 0.001 * ws) < 1e-12
+    # (4) per-latent gradients of disjoint shards gather into [L, P] in latent order, uneven shards included
+    L = 37
+    g_all = np.arange(L * 3, dtype=np.float64).reshape(L, 3)
+    a, b = shard_bounds(L, ws, rank)
+    ok &= np.array_equal(gather_latent_grads(torch.from_numpy(g_all[a:b].copy()), L).numpy(), g_all)
+    # (5) reduce-scatter form of the un-projection (N1): the partial predictions of all ranks summed, every rank keeping its time slice
+    T, M = 21, 5
+    sh = ShardedMOIHGP.__new__(ShardedMOIHGP)
+    sh.group, sh.world, sh.rank = None, ws, rank
+    rng = np.random.default_rng(7)
+    parts = rng.standard_normal((ws, 2, T, M))                          # identical on every rank (same seed): rank r contributes parts[r]
+    mine = sh._reduce_scatter_rows(torch.from_numpy(parts[rank].copy()))
+    t_lo, t_hi = time_slice_bounds(T, ws, rank)
+    ok &= mine.shape == (2, t_hi - t_lo, M) and np.allclose(mine.numpy(), parts.sum(axis=0)[:, t_lo:t_hi], rtol=0, atol=1e-12)
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_eight_rank_host_logic_gloo():
+    """No 8-GPU node is available to this build: the N = 8 path (shard bounds, pipelined NLL totals with two all-reduces in flight,
+    max-over-ranks timing, gradient gather, reduce-scatter un-projection) is exercised on 8 CPU processes over gloo."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs: p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs: p.join(timeout=60)
+    assert sorted(res) == [(r, True) for r in range(8)]
+
+
+def test_sharded_rejects_more_ranks_than_latents(monkeypatch):
+    from multioutputihgp_amd import sharded
+    monkeypatch.setattr(sharded.dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(sharded.dist, "get_world_size", lambda group=None: 4)
+    monkeypatch.setattr(sharded.dist, "get_rank", lambda group=None: 3)
+    with pytest.raises(ValueError, match="at least one latent"):
+        sharded.ShardedMOIHGP(0.1, 8, 3)
