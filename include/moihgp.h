@@ -12,8 +12,12 @@
  *                               (moihgp.h:93, :431-457, :721-738)
  * All arithmetic behind these symbols runs in HIP kernels on the current device; there is no
  * CPU fallback.  If no usable GPU is present `*_new` returns NULL and moihgp_last_error()
- * says why; any later HIP failure prints the error and aborts (the reference ABI has no
- * status channel, wrapper.cpp:31-326).
+ * says why.  A later HIP failure (a launch, copy or allocation that fails) inside one of the
+ * reference entries prints the error and aborts -- they are all void / value returns, the
+ * reference ABI has no status channel (wrapper.cpp:31-326).  The additive entries of part 2
+ * that return int report it instead: rc 1 = invalid argument, 2 = HIP failure, 3 = unsupported
+ * input (window with NaN), 4 = host memory; moihgp_last_error() holds the text.  Nothing ever
+ * unwinds across the ABI.
  *
  * Part 2 is additive: batched entry points over whole time streams (the per-tick ABI costs one
  * FFI crossing + several launches per tick and cannot amortise them), taking DEVICE pointers.
@@ -175,6 +179,14 @@ int moihgp_filter_stream(moihgp_gp* gp, int dtype, const void* Ty, size_t T, siz
  * (moihgp.h:684), added in a fixed order by a one-wavefront kernel queued right behind the sweep. */
 int moihgp_filter_stream_io(moihgp_gp* gp, int dtype, const void* Ty, size_t T, size_t ld,
                             const void* x_in, void* x, void* yhat, double* nll, double* nll_total, void* stream);
+
+/* The same sweep with a row stride of its own for yhat (ld_out, same rules as ld: a multiple of 16 bytes, >= T rounded up), so that the
+ * filtered means can land in a buffer shaped differently from the stream -- a compact [L][T'] array next to a column slice of a wider
+ * slab, say.  The two entries above hand yhat the stream's stride, which the library cannot check against the caller's allocation: an
+ * output buffer narrower than the stream's rows is then written out of bounds.  Prefer this entry whenever Ty and yhat are not
+ * allocated alike.  yhat may be NULL (ld_out is then ignored). */
+int moihgp_filter_stream_v2(moihgp_gp* gp, int dtype, const void* Ty, size_t T, size_t ld_in,
+                            const void* x_in, void* x, void* yhat, size_t ld_out, double* nll, double* nll_total, void* stream);
 
 /* As above plus the hyper-parameter sensitivities (ihgp.h:54) and the per-latent NLL gradient
  * (ihgp.h:216-220), summed over ticks:

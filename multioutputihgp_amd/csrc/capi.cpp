@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <random>
 #include <vector>
 
@@ -28,10 +29,8 @@ void set_last_error(const char* fmt, ...) {
 }
 
 [[noreturn]] void fatal_hip(hipError_t e, const char* what, const char* file, int line) {
-    // The reference ABI has no status channel (all void / value returns, wrapper.cpp:31-326), so a
-    // device failure cannot be reported to the caller: say what happened and stop.
-    std::fprintf(stderr, "libmoihgp: HIP error %d (%s) at %s:%d: %s\n", (int)e, hipGetErrorString(e), file, line, what);
-    std::abort();
+    (void)hipGetLastError();                   // clear the sticky error: the next call of an entry with a return code starts clean
+    throw HipFailure{e, what, file, line};
 }
 
 template <typename T>
@@ -203,6 +202,7 @@ static moihgp_gp* gp_create(int kernel, double dt, size_t M, size_t L, bool late
         return nullptr;
     }
     moihgp_gp* g = new moihgp_gp();
+    try {
     g->kernel = kernel; g->dt = dt; g->M = M; g->L = L; g->latents_only = latents_only;
     g->threading = (L < 2) ? false : threading;                          // moihgp.h:128-135
     { const char* fl = std::getenv("MOIHGP_LIK1_FULL_LOSS"); g->lik1_full = fl && fl[0] == '1'; }
@@ -257,6 +257,7 @@ static moihgp_gp* gp_create(int kernel, double dt, size_t M, size_t L, bool late
         upload_mixing(g);
     }
     run_ihgp_update(g);                                                  // moihgp.h:86-90 -> ihgp.h:33
+    } catch (...) { gp_free(g); throw; }                                 // (an allocation or launch failed: release what exists, report upstream)
     return g;
 }
 
@@ -427,29 +428,64 @@ static int gp52_kernel() {
     return (e && e[0] == '1') ? MOIHGP_MATERN52 : MOIHGP_MATERN32;
 }
 
+// The reference ABI has no status channel (all void / value returns, wrapper.cpp:31-326), so a device failure cannot be reported to
+// the caller of a gpXX_* entry: say what happened and stop.
+[[noreturn]] static void abort_on(const HipFailure& f) {
+    std::fprintf(stderr, "libmoihgp: HIP error %d (%s) at %s:%d: %s\n", (int)f.err, hipGetErrorString(f.err), f.file, f.line, f.what);
+    std::abort();
+}
+// body of a reference-ABI entry: nothing may unwind through extern "C"
+template <typename F>
+static auto guard_abort(F&& body) -> decltype(body()) {
+    try { return body(); }
+    catch (const HipFailure& f) { abort_on(f); }
+    catch (const std::exception& e) { std::fprintf(stderr, "libmoihgp: %s\n", e.what()); std::abort(); }
+}
+// body of an additive entry with an int return code: failures become rc 2 (HIP) / 4 (host memory) + moihgp_last_error()
+template <typename F>
+static int guard_rc(F&& body) {
+    try { return body(); }
+    catch (const HipFailure& f) {
+        set_last_error("HIP error %d (%s) at %s:%d: %s", (int)f.err, hipGetErrorString(f.err), f.file, f.line, f.what);
+        return 2;
+    }
+    catch (const std::exception& e) { set_last_error("%s", e.what()); return 4; }
+}
+// constructors: NULL + moihgp_last_error() (the reference's ctor cannot fail short of std::bad_alloc)
+template <typename F>
+static moihgp_gp* guard_new(F&& body) {
+    try { return body(); }
+    catch (const HipFailure& f) {
+        set_last_error("HIP error %d (%s) at %s:%d: %s", (int)f.err, hipGetErrorString(f.err), f.file, f.line, f.what);
+        std::fprintf(stderr, "libmoihgp: %s\n", g_last_error);
+        return nullptr;
+    }
+    catch (const std::exception& e) { set_last_error("%s", e.what()); return nullptr; }
+}
+
 extern "C" {
 
 #define MOIHGP_DEFINE_REFERENCE_ABI(PFX, KERNEL_EXPR)                                                                   \
     moihgp_gp* PFX##_new(double dt, size_t num_output, size_t num_latent, bool threading) {                             \
-        return gp_create((KERNEL_EXPR), dt, num_output, num_latent, false, nullptr, threading);                          \
+        return guard_new([&] { return gp_create((KERNEL_EXPR), dt, num_output, num_latent, false, nullptr, threading); }); \
     }                                                                                                                    \
     void PFX##_del(moihgp_gp* gp) { gp_free(gp); }                                                                       \
     void PFX##_step1(moihgp_gp* gp, double* x, double* y, double* dx, double* xnew, double* yhat, double* dxnew) {       \
-        do_step(gp, x, y, dx, xnew, yhat, dxnew);                                                                        \
+        guard_abort([&] { do_step(gp, x, y, dx, xnew, yhat, dxnew); });                                                  \
     }                                                                                                                    \
     void PFX##_step2(moihgp_gp* gp, double* x, double* y, double* dx, double* xnew, double* dxnew) {                     \
-        do_step(gp, x, y, dx, xnew, nullptr, dxnew);                                                                     \
+        guard_abort([&] { do_step(gp, x, y, dx, xnew, nullptr, dxnew); });                                               \
     }                                                                                                                    \
     void PFX##_step3(moihgp_gp* gp, double* x, double* y, double* xnew, double* yhat) {                                  \
-        do_step(gp, x, y, nullptr, xnew, yhat, nullptr);                                                                 \
+        guard_abort([&] { do_step(gp, x, y, nullptr, xnew, yhat, nullptr); });                                           \
     }                                                                                                                    \
     void PFX##_step4(moihgp_gp* gp, double* x, double* xnew, double* yhat) {                                             \
-        do_step(gp, x, nullptr, nullptr, xnew, yhat, nullptr);                                                           \
+        guard_abort([&] { do_step(gp, x, nullptr, nullptr, xnew, yhat, nullptr); });                                     \
     }                                                                                                                    \
-    void PFX##_update(moihgp_gp* gp, double* params) { do_update(gp, params); }                                          \
-    double PFX##_lik1(moihgp_gp* gp, double* x, double* y, double* dx, double* grad) { return do_lik(gp, x, y, dx, grad); } \
-    double PFX##_lik2(moihgp_gp* gp, double* x, double* y) { return do_lik(gp, x, y, nullptr, nullptr); }                \
-    void PFX##_get_params(moihgp_gp* gp, double* params) { do_get_params(gp, params); }                                  \
+    void PFX##_update(moihgp_gp* gp, double* params) { guard_abort([&] { do_update(gp, params); }); }                    \
+    double PFX##_lik1(moihgp_gp* gp, double* x, double* y, double* dx, double* grad) { return guard_abort([&] { return do_lik(gp, x, y, dx, grad); }); } \
+    double PFX##_lik2(moihgp_gp* gp, double* x, double* y) { return guard_abort([&] { return do_lik(gp, x, y, nullptr, nullptr); }); } \
+    void PFX##_get_params(moihgp_gp* gp, double* params) { guard_abort([&] { do_get_params(gp, params); }); }            \
     size_t PFX##_igp_dim(moihgp_gp* gp) { return (size_t)gp->d; }                                                        \
     size_t PFX##_num_param(moihgp_gp* gp) { return gp->num_param; }                                                      \
     size_t PFX##_num_igp_param(moihgp_gp* gp) { return (size_t)gp->P; }
@@ -468,7 +504,7 @@ int moihgp_device_count(void) {
 int moihgp_version(void) { return 100; }
 
 moihgp_gp* moihgp_new(int kernel, double dt, size_t num_output, size_t num_latent) {
-    return gp_create(kernel, dt, num_output, num_latent, false, nullptr);
+    return guard_new([&] { return gp_create(kernel, dt, num_output, num_latent, false, nullptr); });
 }
 void moihgp_del(moihgp_gp* gp) { gp_free(gp); }
 size_t moihgp_num_output(moihgp_gp* gp) { return gp->M; }
@@ -476,18 +512,20 @@ size_t moihgp_num_latent(moihgp_gp* gp) { return gp->L; }
 void moihgp_set_threading(moihgp_gp* gp, int threading) { if (gp) gp->threading = (gp->L < 2) ? false : (threading != 0); }   // moihgp.h:128-135
 int moihgp_get_threading(moihgp_gp* gp) { return gp && gp->threading ? 1 : 0; }
 
-void moihgp_reseed_U(moihgp_gp* gp, unsigned long long seed) {
-    if (gp->latents_only) return;
-    draw_U(gp, seed, true);
-    upload_mixing(gp);
-    MOIHGP_HIP_FATAL(hipStreamSynchronize(gp->stream));
+void moihgp_reseed_U(moihgp_gp* gp, unsigned long long seed) {           // (void like the constructor it re-runs: a device failure aborts)
+    if (!gp || gp->latents_only) return;
+    guard_abort([&] {
+        draw_U(gp, seed, true);
+        upload_mixing(gp);
+        MOIHGP_HIP_FATAL(hipStreamSynchronize(gp->stream));
+    });
 }
 
 moihgp_gp* moihgp_new_latents(int kernel, double dt, size_t nl, const double* params_LP) {
-    return gp_create(kernel, dt, 0, nl, true, params_LP);
+    return guard_new([&] { return gp_create(kernel, dt, 0, nl, true, params_LP); });
 }
 
-int moihgp_set_mixing(moihgp_gp* gp, const double* U, const double* S, double sigma) {
+static int set_mixing_impl(moihgp_gp* gp, const double* U, const double* S, double sigma) {
     if (!gp || gp->latents_only || !U || !S) { set_last_error("set_mixing: needs a full MOIHGP object and non-null U, S"); return 1; }
     std::memcpy(gp->U.data(), U, sizeof(double) * gp->M * gp->L);
     std::memcpy(gp->S.data(), S, sizeof(double) * gp->L);
@@ -498,14 +536,22 @@ int moihgp_set_mixing(moihgp_gp* gp, const double* U, const double* S, double si
     return 0;
 }
 
-int moihgp_update_latents(moihgp_gp* gp, const double* params_LP) {
+int moihgp_set_mixing(moihgp_gp* gp, const double* U, const double* S, double sigma) {
+    return guard_rc([&] { return set_mixing_impl(gp, U, S, sigma); });
+}
+
+static int update_latents_impl(moihgp_gp* gp, const double* params_LP) {
     if (!gp || !params_LP) { set_last_error("update_latents: null argument"); return 1; }
     for (size_t i = 0; i < gp->L * (size_t)gp->P; i++) gp->igp[i] = params_LP[i];
     run_ihgp_update(gp);
     return 0;
 }
 
-int moihgp_get_latent(moihgp_gp* gp, size_t l, double* A, double* K, double* S, double* HA, double* AKHA, double* dA,
+int moihgp_update_latents(moihgp_gp* gp, const double* params_LP) {
+    return guard_rc([&] { return update_latents_impl(gp, params_LP); });
+}
+
+static int get_latent_impl(moihgp_gp* gp, size_t l, double* A, double* K, double* S, double* HA, double* AKHA, double* dA,
                       double* dS, double* dK, double* dAKHA, double* HdA, int* iters) {
     if (!gp || l >= gp->L) { set_last_error("get_latent: bad latent index"); return 1; }
     const int d = gp->d, P = gp->P;
@@ -549,6 +595,11 @@ int moihgp_get_latent(moihgp_gp* gp, size_t l, double* A, double* K, double* S, 
     return 0;
 }
 
+int moihgp_get_latent(moihgp_gp* gp, size_t l, double* A, double* K, double* S, double* HA, double* AKHA, double* dA,
+                      double* dS, double* dK, double* dAKHA, double* HdA, int* iters) {
+    return guard_rc([&] { return get_latent_impl(gp, l, A, K, S, HA, AKHA, dA, dS, dK, dAKHA, HdA, iters); });
+}
+
 static int check_stream_args(moihgp_gp* gp, int dtype, const void* Ty, size_t T, size_t ld, const void* x) {
     if (!gp) { set_last_error("null handle"); return 1; }
     if (dtype != MOIHGP_F64 && dtype != MOIHGP_F32) { set_last_error("dtype must be MOIHGP_F64 or MOIHGP_F32"); return 1; }
@@ -563,14 +614,22 @@ int moihgp_filter_stream(moihgp_gp* gp, int dtype, const void* Ty, size_t T, siz
     return moihgp_filter_stream_io(gp, dtype, Ty, T, ld, x, x, yhat, nll, nullptr, stream);
 }
 
-int moihgp_filter_stream_io(moihgp_gp* gp, int dtype, const void* Ty, size_t T, size_t ld, const void* x_in, void* x, void* yhat, double* nll,
-                            double* nll_total, void* stream) {
+static int filter_stream_io_impl(moihgp_gp* gp, int dtype, const void* Ty, size_t T, size_t ld, const void* x_in, void* x, void* yhat, double* nll,
+                            double* nll_total, void* stream, size_t ld_out = 0) {
     if (int rc = check_stream_args(gp, dtype, Ty, T, ld, x)) return rc;
     if (!x_in) { set_last_error("null start state"); return 1; }
     note_user_stream(gp, (hipStream_t)stream);
     if (nll_total && !nll) { set_last_error("nll_total needs the per-latent nll buffer"); return 1; }
     if (nll_total && T == 0) MOIHGP_HIP_FATAL(hipMemsetAsync(nll_total, 0, sizeof(double), (hipStream_t)stream));
     if (yhat && ((uintptr_t)yhat & 15) != 0) { set_last_error("yhat base must be 16-byte aligned"); return 1; }
+    if (ld_out == 0) ld_out = ld;
+    {
+        const size_t epv = dtype == MOIHGP_F64 ? 2 : 4;
+        if (yhat && (ld_out % epv != 0 || ld_out < (T + epv - 1) / epv * epv)) {
+            set_last_error("ld_out (%zu) must be a multiple of %zu and >= T rounded up to it", ld_out, epv);
+            return 1;
+        }
+    }
     const char* ve = std::getenv("MOIHGP_FILTER_VARIANT");   // tuning hook: kernel tiling variant
     const int variant = ve ? std::atoi(ve) : 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -584,7 +643,7 @@ int moihgp_filter_stream_io(moihgp_gp* gp, int dtype, const void* Ty, size_t T, 
         if (slen && !gp->dxscratch) gp->dxscratch = dev_alloc<double>(slen);
         const char* fs = std::getenv("MOIHGP_FILTER_SPLIT");            // tuning / test hook, as for the reference models: 1 = off, n = slices
         int rc = launch_filter_stream_x(gp->kernel, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cb32, x_in, x, yhat, nll, (hipStream_t)stream, e0, e1,
-                                        gp->dxscratch, slen, fs ? std::atoi(fs) : 0);
+                                        gp->dxscratch, slen, fs ? std::atoi(fs) : 0, ld_out);
         if (rc == 0 && nll_total) launch_nll_total(nll, gp->L, nll_total, (hipStream_t)stream);
         return rc;
     }
@@ -602,10 +661,15 @@ int moihgp_filter_stream_io(moihgp_gp* gp, int dtype, const void* Ty, size_t T, 
         }
     }
     return launch_filter_stream(gp->d, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cb32, x_in, x, yhat, nll, (hipStream_t)stream, variant, e0, e1,
-                                nsplit, Tslice, gp->n_unstable[dtype == MOIHGP_F64 ? 0 : 1], nll_total, nbig);
+                                nsplit, Tslice, gp->n_unstable[dtype == MOIHGP_F64 ? 0 : 1], nll_total, nbig, ld_out);
 }
 
-int moihgp_profile_enable(moihgp_gp* gp, int max_launches) {
+int moihgp_filter_stream_io(moihgp_gp* gp, int dtype, const void* Ty, size_t T, size_t ld, const void* x_in, void* x, void* yhat, double* nll,
+                            double* nll_total, void* stream) {
+    return guard_rc([&] { return filter_stream_io_impl(gp, dtype, Ty, T, ld, x_in, x, yhat, nll, nll_total, stream); });
+}
+
+static int profile_enable_impl(moihgp_gp* gp, int max_launches) {
     if (!gp) { set_last_error("null handle"); return 1; }
     for (hipEvent_t e : gp->prof_ev) (void)hipEventDestroy(e);
     gp->prof_ev.clear();
@@ -619,26 +683,42 @@ int moihgp_profile_enable(moihgp_gp* gp, int max_launches) {
     return 0;
 }
 
-int moihgp_profile_stride(moihgp_gp* gp, int stride) {
+int moihgp_profile_enable(moihgp_gp* gp, int max_launches) {
+    return guard_rc([&] { return profile_enable_impl(gp, max_launches); });
+}
+
+static int profile_stride_impl(moihgp_gp* gp, int stride) {
     if (!gp || stride < 1) { set_last_error("profile_stride: null handle or stride < 1"); return 1; }
     gp->prof_stride = (unsigned)stride;
     gp->prof_seen = 0;
     return 0;
 }
 
+int moihgp_profile_stride(moihgp_gp* gp, int stride) {
+    return guard_rc([&] { return profile_stride_impl(gp, stride); });
+}
+
 int moihgp_profile_read(moihgp_gp* gp, float* ms, int n) {
     if (!gp) { set_last_error("null handle"); return -1; }
     int cnt = gp->prof_n < n ? gp->prof_n : n;
-    for (int i = 0; i < cnt; i++) {
-        MOIHGP_HIP_FATAL(hipEventSynchronize(gp->prof_ev[2 * i + 1]));
-        MOIHGP_HIP_FATAL(hipEventElapsedTime(&ms[i], gp->prof_ev[2 * i], gp->prof_ev[2 * i + 1]));
-    }
+    const int rc = guard_rc([&] {
+        for (int i = 0; i < cnt; i++) {
+            MOIHGP_HIP_FATAL(hipEventSynchronize(gp->prof_ev[2 * i + 1]));
+            MOIHGP_HIP_FATAL(hipEventElapsedTime(&ms[i], gp->prof_ev[2 * i], gp->prof_ev[2 * i + 1]));
+        }
+        return 0;
+    });
     gp->prof_n = 0;
     gp->prof_seen = 0;
-    return cnt;
+    return rc ? -1 : cnt;
 }
 
-int moihgp_grad_stream(moihgp_gp* gp, int dtype, const void* Ty, size_t T, size_t ld, void* x, void* dx, void* yhat, double* nll,
+int moihgp_filter_stream_v2(moihgp_gp* gp, int dtype, const void* Ty, size_t T, size_t ld_in, const void* x_in, void* x, void* yhat, size_t ld_out,
+                            double* nll, double* nll_total, void* stream) {
+    return guard_rc([&] { return filter_stream_io_impl(gp, dtype, Ty, T, ld_in, x_in, x, yhat, nll, nll_total, stream, ld_out); });
+}
+
+static int grad_stream_impl(moihgp_gp* gp, int dtype, const void* Ty, size_t T, size_t ld, void* x, void* dx, void* yhat, double* nll,
                        double* grad, void* stream) {
     if (int rc = check_stream_args(gp, dtype, Ty, T, ld, x)) return rc;
     if (!dx || !grad) { set_last_error("grad_stream: dx and grad are required"); return 1; }
@@ -647,6 +727,11 @@ int moihgp_grad_stream(moihgp_gp* gp, int dtype, const void* Ty, size_t T, size_
     if (kernel_stack(gp->kernel))
         return launch_grad_stream_x(gp->kernel, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cbd64, x, dx, yhat, nll, grad, (hipStream_t)stream);
     return launch_grad_stream(gp->d, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cb32, x, dx, yhat, nll, grad, gp->dfallback, (hipStream_t)stream);
+}
+
+int moihgp_grad_stream(moihgp_gp* gp, int dtype, const void* Ty, size_t T, size_t ld, void* x, void* dx, void* yhat, double* nll,
+                       double* grad, void* stream) {
+    return guard_rc([&] { return grad_stream_impl(gp, dtype, Ty, T, ld, x, dx, yhat, nll, grad, stream); });
 }
 
 // fp32 image of the mixing matrix: allocated and built (on the handle's stream, synchronised) the first time an fp32 stream product
@@ -661,7 +746,7 @@ static const float* mixing_f32(moihgp_gp* gp) {
     return gp->dU32;
 }
 
-int moihgp_project_stream(moihgp_gp* gp, int dtype, const void* Y, size_t T, void* Ty, size_t ld, void* stream) {
+static int project_stream_impl(moihgp_gp* gp, int dtype, const void* Y, size_t T, void* Ty, size_t ld, void* stream) {
     if (!gp || gp->latents_only) { set_last_error("project_stream needs a full MOIHGP object"); return 1; }
     if (ld < T) { set_last_error("ld < T"); return 1; }
     note_user_stream(gp, (hipStream_t)stream);
@@ -669,7 +754,11 @@ int moihgp_project_stream(moihgp_gp* gp, int dtype, const void* Y, size_t T, voi
                                  (hipStream_t)stream);
 }
 
-int moihgp_unproject_stream(moihgp_gp* gp, int dtype, const void* Tyhat, size_t T, size_t ld, void* Yhat, void* stream) {
+int moihgp_project_stream(moihgp_gp* gp, int dtype, const void* Y, size_t T, void* Ty, size_t ld, void* stream) {
+    return guard_rc([&] { return project_stream_impl(gp, dtype, Y, T, Ty, ld, stream); });
+}
+
+static int unproject_stream_impl(moihgp_gp* gp, int dtype, const void* Tyhat, size_t T, size_t ld, void* Yhat, void* stream) {
     if (!gp || gp->latents_only) { set_last_error("unproject_stream needs a full MOIHGP object"); return 1; }
     if (ld < T) { set_last_error("ld < T"); return 1; }
     note_user_stream(gp, (hipStream_t)stream);
@@ -677,7 +766,11 @@ int moihgp_unproject_stream(moihgp_gp* gp, int dtype, const void* Tyhat, size_t 
                                    (hipStream_t)stream);
 }
 
-int moihgp_window_set(moihgp_gp* gp, const double* Y, size_t W) {
+int moihgp_unproject_stream(moihgp_gp* gp, int dtype, const void* Tyhat, size_t T, size_t ld, void* Yhat, void* stream) {
+    return guard_rc([&] { return unproject_stream_impl(gp, dtype, Tyhat, T, ld, Yhat, stream); });
+}
+
+static int window_set_impl(moihgp_gp* gp, const double* Y, size_t W) {
     if (!gp || gp->latents_only) { set_last_error("window_set needs a full MOIHGP object"); return 1; }
     if (!Y || W == 0) { set_last_error("window_set: empty window"); return 1; }
     const size_t M = gp->M, L = gp->L, d = gp->d, P = gp->P, ldw = (W + 1) / 2 * 2;
@@ -701,7 +794,11 @@ int moihgp_window_set(moihgp_gp* gp, const double* Y, size_t W) {
     return 0;
 }
 
-int moihgp_window_eval(moihgp_gp* gp, const double* x, const double* dx, double* loss, double* grad, double* xnew, double* dxnew) {
+int moihgp_window_set(moihgp_gp* gp, const double* Y, size_t W) {
+    return guard_rc([&] { return window_set_impl(gp, Y, W); });
+}
+
+static int window_eval_impl(moihgp_gp* gp, const double* x, const double* dx, double* loss, double* grad, double* xnew, double* dxnew) {
     if (!gp || gp->latents_only || gp->win.W == 0) { set_last_error("window_eval: call moihgp_window_set first"); return 1; }
     if (!x || !dx || !loss || !grad) { set_last_error("window_eval: null argument"); return 1; }
     const size_t L = gp->L, d = gp->d, P = gp->P;
@@ -717,12 +814,20 @@ int moihgp_window_eval(moihgp_gp* gp, const double* x, const double* dx, double*
     return 0;
 }
 
-int moihgp_pin_host_buffer(moihgp_gp* gp, void* ptr, size_t bytes) {
+int moihgp_window_eval(moihgp_gp* gp, const double* x, const double* dx, double* loss, double* grad, double* xnew, double* dxnew) {
+    return guard_rc([&] { return window_eval_impl(gp, x, dx, loss, grad, xnew, dxnew); });
+}
+
+static int pin_host_buffer_impl(moihgp_gp* gp, void* ptr, size_t bytes) {
     if (!gp || !ptr || bytes == 0) { set_last_error("pin_host_buffer: bad argument"); return 1; }
     hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterDefault);
     if (e != hipSuccess) { (void)hipGetLastError(); set_last_error("hipHostRegister: %s", hipGetErrorString(e)); return 2; }
     gp->pinned.push_back(ptr);
     return 0;
+}
+
+int moihgp_pin_host_buffer(moihgp_gp* gp, void* ptr, size_t bytes) {
+    return guard_rc([&] { return pin_host_buffer_impl(gp, ptr, bytes); });
 }
 
 int moihgp_stream_sync(void* stream) {

@@ -94,6 +94,15 @@ inline int kernel_base(int kernel) { return kernel & 15; }
 inline int kernel_stack(int kernel) { return kernel >> 4; }
 
 // ---- error handling -------------------------------------------------------------------------
+// A failing HIP call anywhere below the C ABI raises HipFailure; it never crosses the ABI: every extern "C" entry catches it
+// (capi.cpp).  The additive entries (part 2 of include/moihgp.h, which have return codes) turn it into rc = 2 + moihgp_last_error();
+// the reference entries (gpXX_*: all void / value returns, wrapper.cpp:31-326, no status channel) print it and abort.
+struct HipFailure {
+    hipError_t err;
+    const char* what;
+    const char* file;
+    int line;
+};
 void set_last_error(const char* fmt, ...);
 [[noreturn]] void fatal_hip(hipError_t e, const char* what, const char* file, int line);
 
@@ -116,7 +125,7 @@ void launch_stack_update(int kernel, double dt, const double* params_dev, size_t
 int launch_filter_stream_x(int kernel, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* cb64, const float* cb32,
                            const void* xin, void* x, void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
                            double* scratch = nullptr /* [scratch_len] per-slice NLL partials of the time split */, size_t scratch_len = 0,
-                           int force_slices = 0 /* tuning / test hook: 1 = no split, n > 1 = n slices */);
+                           int force_slices = 0 /* tuning / test hook: 1 = no split, n > 1 = n slices */, size_t ld_out = 0 /* row stride of yhat; 0 = ld */);
 
 // grad_x.hip: sensitivity / gradient sweep of the stacked models (needs the XD blocks).
 int launch_grad_stream_x(int kernel, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* cb64, const double* cbd64,
@@ -128,7 +137,8 @@ int launch_filter_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, 
                          void* yhat, double* nll,
                          hipStream_t stream, int variant = 0, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
                          int nsplit = 1, size_t Tslice = 0, int n_unstable = 0 /* latents with SCANOK == 0 in this dtype's blocks */,
-                         double* total = nullptr /* device scalar: sum of nll[] (optional) */, int nbig = 0 /* see filter_split_plan; 0 = all slices alike */);
+                         double* total = nullptr /* device scalar: sum of nll[] (optional) */, int nbig = 0 /* see filter_split_plan; 0 = all slices alike */,
+                         size_t ld_out = 0 /* row stride of yhat; 0 = ld */);
 void launch_nll_total(const double* nll, size_t L, double* total, hipStream_t stream);
 // Time split for small L (slices of one latent = wavefronts of one workgroup): nsplit == 1 means none.
 void filter_split_plan(int dtype, size_t T, size_t L, int* nsplit, size_t* Tslice, int* nbig /* leading slices of Tslice ticks; the rest hold one segment less */);

@@ -393,7 +393,8 @@ __global__ void __launch_bounds__(SPLIT ? 64 * kMaxSplit : 64 * kWavesPerBlock, 
 filter_scan_kernel(const T* __restrict__ Ty, size_t Ttot, size_t ld, size_t L, const T* __restrict__ cbT,
                    const double* __restrict__ cb64, const T* xin0 /* start state */, T* x /* end state; may be the same buffer */,
                    T* __restrict__ yhat, double* __restrict__ nll, int nsplit, size_t Tslice,
-                   int nbig /* split: slices [0, nbig) hold Tslice ticks, the later ones one segment less (nbig == nsplit: all alike) */) {
+                   int nbig /* split: slices [0, nbig) hold Tslice ticks, the later ones one segment less (nbig == nsplit: all alike) */,
+                   size_t ldo /* row stride of yhat (the stream's own is ld) */) {
     using V = typename VecOf<T>::type;
     using Lay = CB<D>;
     constexpr int EPV = 16 / sizeof(T);
@@ -441,7 +442,7 @@ filter_scan_kernel(const T* __restrict__ Ty, size_t Ttot, size_t ld, size_t L, c
     // Uniform over the wave, and over the workgroup in split mode (one latent per workgroup), and ahead of any barrier.
     if (cb[Lay::SCANOK] == T(0)) return;
     const T* row = Ty + l * ld + toff;
-    T* orow = WRITE ? yhat + l * ld + toff : nullptr;
+    T* orow = WRITE ? yhat + l * ldo + toff : nullptr;
     T xin[D];
     double acc = 0.0;          // per-lane sum of v^2 over observed ticks
     unsigned nobs = 0;         // per-lane count of observed ticks (tail / generic segments)
@@ -554,7 +555,7 @@ __global__ void __launch_bounds__(1024) nll_total_kernel(const double* __restric
 template <typename T, int D>
 __global__ void __launch_bounds__(64)
 filter_seq_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, const T* __restrict__ cbT, const double* __restrict__ cb64,
-                  const T* xin0, T* x, T* __restrict__ yhat, double* __restrict__ nll) {
+                  const T* xin0, T* x, T* __restrict__ yhat, double* __restrict__ nll, size_t ldo) {
     using V = typename VecOf<T>::type;
     using Lay = CB<D>;
     constexpr int EPV = 16 / sizeof(T);
@@ -585,7 +586,7 @@ filter_seq_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, co
                 xn[i] = s;
             }
             for (int i = 0; i < D; i++) xs[i] = xn[i];
-            if (yhat) yhat[l * ld + tb + e] = xs[0];
+            if (yhat) yhat[l * ldo + tb + e] = xs[0];
         }
     }
     for (int i = 0; i < D; i++) x[l * D + i] = xs[i];
@@ -595,7 +596,7 @@ filter_seq_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, co
 template <typename T, int D, int CK, int MINW, bool SPLIT>
 int launch_filter_t(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, const double* cb64, const void* xin, void* x,
                     void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, int nsplit, size_t Tslice, int n_unstable,
-                    double* total, int nbig) {
+                    double* total, int nbig, size_t ldo) {
     dim3 block(SPLIT ? 64 * nsplit : 64 * kWavesPerBlock);
     dim3 grid(SPLIT ? (unsigned)L : (unsigned)((L + kWavesPerBlock - 1) / kWavesPerBlock));
     constexpr size_t tile = 64 * (CK / (16 / sizeof(T)) + 1) * 16;                    // padded LDS tile per wave
@@ -607,15 +608,15 @@ int launch_filter_t(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* c
     T* yh = static_cast<T*>(yhat);
     // hipExtLaunchKernelGGL attaches the (optional) events to the dispatch itself: kernel-exact timing
     if (yhat && nll)
-        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, true, true, MINW, SPLIT>), grid, block, smem, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nsplit, Tslice, nbig);
+        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, true, true, MINW, SPLIT>), grid, block, smem, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nsplit, Tslice, nbig, ldo);
     else if (yhat)
-        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, true, false, MINW, SPLIT>), grid, block, smem, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nsplit, Tslice, nbig);
+        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, true, false, MINW, SPLIT>), grid, block, smem, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nsplit, Tslice, nbig, ldo);
     else if (nll)
-        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, false, true, MINW, SPLIT>), grid, block, smem, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nsplit, Tslice, nbig);
+        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, false, true, MINW, SPLIT>), grid, block, smem, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nsplit, Tslice, nbig, ldo);
     else
-        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, false, false, MINW, SPLIT>), grid, block, smem, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nsplit, Tslice, nbig);
+        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, false, false, MINW, SPLIT>), grid, block, smem, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nsplit, Tslice, nbig, ldo);
     if (n_unstable > 0)
-        hipLaunchKernelGGL((filter_seq_kernel<T, D>), dim3((unsigned)((L + 63) / 64)), dim3(64), 0, stream, ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll);
+        hipLaunchKernelGGL((filter_seq_kernel<T, D>), dim3((unsigned)((L + 63) / 64)), dim3(64), 0, stream, ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, ldo);
     if (total && nll) hipLaunchKernelGGL(nll_total_kernel, dim3(1), dim3(1024), 0, stream, nll, L, total);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_last_error("filter_scan_kernel launch: %s", hipGetErrorString(e)); return 2; }
@@ -649,14 +650,15 @@ void filter_split_plan(int dtype, size_t T, size_t L, int* nsplit, size_t* Tslic
 
 int launch_filter_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* cb64,
                          const float* cb32, const void* xin, void* x, void* yhat, double* nll, hipStream_t stream, int variant,
-                         hipEvent_t ev0, hipEvent_t ev1, int nsplit, size_t Tslice, int n_unstable, double* total, int nbig) {
+                         hipEvent_t ev0, hipEvent_t ev1, int nsplit, size_t Tslice, int n_unstable, double* total, int nbig, size_t ldo) {
     if (L == 0) return 0;
+    if (ldo == 0) ldo = ld;
     if (nsplit > kMaxSplit) { set_last_error("nsplit > %d", kMaxSplit); return 1; }
     if (nbig <= 0 || nbig > nsplit) nbig = nsplit;
 #define MOIHGP_FILTER_CASE(TT, DD, CKK, MW, CB)                                                                                   \
     do {                                                                                                                          \
-        if (nsplit > 1) return launch_filter_t<TT, DD, CKK, 1, true>(Ty, T, ld, L, CB, cb64, xin, x, yhat, nll, stream, ev0, ev1, nsplit, Tslice, n_unstable, total, nbig); \
-        return launch_filter_t<TT, DD, CKK, MW, false>(Ty, T, ld, L, CB, cb64, xin, x, yhat, nll, stream, ev0, ev1, 1, T, n_unstable, total, 1);             \
+        if (nsplit > 1) return launch_filter_t<TT, DD, CKK, 1, true>(Ty, T, ld, L, CB, cb64, xin, x, yhat, nll, stream, ev0, ev1, nsplit, Tslice, n_unstable, total, nbig, ldo); \
+        return launch_filter_t<TT, DD, CKK, MW, false>(Ty, T, ld, L, CB, cb64, xin, x, yhat, nll, stream, ev0, ev1, 1, T, n_unstable, total, 1, ldo);        \
     } while (0)
     // register caps: fp32 <= 128 VGPRs (4 waves/SIMD: all 4096 wavefronts of a 4096-latent shard resident),
     // fp64 uncapped (188 VGPRs, 2 waves/SIMD: capping it to 168 spills and is 35 % slower)
@@ -669,15 +671,15 @@ int launch_filter_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, 
     if (variant == 2 || variant == 4 || variant == 6) {   // tuning probes: plain stores (2), nontemporal loads (4), both (6)
         dim3 block(64 * kWavesPerBlock), grid((unsigned)((L + kWavesPerBlock - 1) / kWavesPerBlock));
         const size_t sm = (size_t)kWavesPerBlock * (64 * 5 * 16 + 36 * 4);
-        if (variant == 2) hipExtLaunchKernelGGL((filter_scan_kernel<float, 3, kChunk32, true, true, 4, false, 2>), grid, block, sm, stream, ev0, ev1, 0, (const float*)Ty, T, ld, L, cb32, cb64, (const float*)xin, (float*)x, (float*)yhat, nll, 1, T, 1);
-        else if (variant == 4) hipExtLaunchKernelGGL((filter_scan_kernel<float, 3, kChunk32, true, true, 4, false, 4>), grid, block, sm, stream, ev0, ev1, 0, (const float*)Ty, T, ld, L, cb32, cb64, (const float*)xin, (float*)x, (float*)yhat, nll, 1, T, 1);
-        else hipExtLaunchKernelGGL((filter_scan_kernel<float, 3, kChunk32, true, true, 4, false, 6>), grid, block, sm, stream, ev0, ev1, 0, (const float*)Ty, T, ld, L, cb32, cb64, (const float*)xin, (float*)x, (float*)yhat, nll, 1, T, 1);
+        if (variant == 2) hipExtLaunchKernelGGL((filter_scan_kernel<float, 3, kChunk32, true, true, 4, false, 2>), grid, block, sm, stream, ev0, ev1, 0, (const float*)Ty, T, ld, L, cb32, cb64, (const float*)xin, (float*)x, (float*)yhat, nll, 1, T, 1, ldo);
+        else if (variant == 4) hipExtLaunchKernelGGL((filter_scan_kernel<float, 3, kChunk32, true, true, 4, false, 4>), grid, block, sm, stream, ev0, ev1, 0, (const float*)Ty, T, ld, L, cb32, cb64, (const float*)xin, (float*)x, (float*)yhat, nll, 1, T, 1, ldo);
+        else hipExtLaunchKernelGGL((filter_scan_kernel<float, 3, kChunk32, true, true, 4, false, 6>), grid, block, sm, stream, ev0, ev1, 0, (const float*)Ty, T, ld, L, cb32, cb64, (const float*)xin, (float*)x, (float*)yhat, nll, 1, T, 1, ldo);
         return 0;
     }
     if (variant == 9) {   // tuning probe (staging only)
         dim3 block(64 * kWavesPerBlock), grid((unsigned)((L + kWavesPerBlock - 1) / kWavesPerBlock));
         hipExtLaunchKernelGGL((filter_scan_kernel<float, 3, kChunk32, true, true, 1, false, 1>), grid, block, (size_t)kWavesPerBlock * (64 * 5 * 16 + 36 * 4), stream, ev0, ev1, 0,
-                              (const float*)Ty, T, ld, L, cb32, cb64, (const float*)xin, (float*)x, (float*)yhat, nll, 1, T, 1);
+                              (const float*)Ty, T, ld, L, cb32, cb64, (const float*)xin, (float*)x, (float*)yhat, nll, 1, T, 1, ldo);
         return 0;
     }
     if (variant == 1) MOIHGP_FILTER_CASE(float, 3, kChunk32, 1, cb32);

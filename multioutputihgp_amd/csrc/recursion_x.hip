@@ -187,7 +187,7 @@ template <typename T, int DB, int J, bool WRITE, bool NLL, int WPB, bool SPLIT>
 __global__ void __launch_bounds__(64 * WPB)
 filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, const T* __restrict__ cbT, const double* __restrict__ cb64,
                 const T* xin0 /* start state */, T* x /* end state; may be the same buffer */, T* __restrict__ yhat, double* __restrict__ nll,
-                int nslice, int segs_per_slice, double* __restrict__ nll_part) {
+                int nslice, int segs_per_slice, double* __restrict__ nll_part, size_t ldo /* row stride of yhat */) {
     constexpr int D = DB * J;
     using V = typename VecOf<T>::type;
     using Lay = XC<D>;
@@ -203,7 +203,7 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
     T* tile = tiles[wave];
     T* tile_lane = tile + lane * STRIDE;
     const T* row = Ty + l * ld;
-    T* orow = WRITE ? yhat + l * ld : nullptr;
+    T* orow = WRITE ? yhat + l * ldo : nullptr;
     T xc[D];
 #pragma unroll
     for (int i = 0; i < D; i++) xc[i] = xin0[l * D + i];
@@ -403,14 +403,14 @@ __global__ void __launch_bounds__(256) sum_slices_kernel(const double* __restric
 
 template <typename T, int DB, int J, int WPB, bool SPLIT>
 int launch_x(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, const double* cb64, const void* xin, void* x, void* yhat, double* nll,
-             hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, int nslice, int segs_per_slice, double* nll_part) {
+             hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, int nslice, int segs_per_slice, double* nll_part, size_t ldo) {
     dim3 block(64 * WPB), grid(SPLIT ? (unsigned)L : (unsigned)((L + WPB - 1) / WPB), SPLIT ? (unsigned)nslice : 1u);
     const T* ty = static_cast<const T*>(Ty);
     const T* xi = static_cast<const T*>(xin);
     T* xs = static_cast<T*>(x);
     T* yh = static_cast<T*>(yhat);
 #define MOIHGP_X_LAUNCH(W_, N_) hipExtLaunchKernelGGL((filter_x_kernel<T, DB, J, W_, N_, WPB, SPLIT>), grid, block, 0, stream, ev0, ev1, 0, \
-                                                      ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nslice, segs_per_slice, nll_part)
+                                                      ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nslice, segs_per_slice, nll_part, ldo)
     if (yhat && nll) MOIHGP_X_LAUNCH(true, true);
     else if (yhat) MOIHGP_X_LAUNCH(true, false);
     else if (nll) MOIHGP_X_LAUNCH(false, true);
@@ -424,9 +424,9 @@ int launch_x(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, con
 
 template <typename T, int DB, int J>
 int launch_xd(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, const double* cb64, const void* xin, void* x, void* yhat, double* nll,
-              hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, double* scratch, size_t scratch_len, int force_slices) {
+              hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, double* scratch, size_t scratch_len, int force_slices, size_t ldo) {
     constexpr size_t SEG = 64 * (size_t)kChunkX;
-    if (L >= 1024) return launch_x<T, DB, J, 4, false>(Ty, Tlen, ld, L, cbT, cb64, xin, x, yhat, nll, stream, ev0, ev1, 1, 0, nullptr);
+    if (L >= 1024) return launch_x<T, DB, J, 4, false>(Ty, Tlen, ld, L, cbT, cb64, xin, x, yhat, nll, stream, ev0, ev1, 1, 0, nullptr, ldo);
     // few latents: one wavefront per workgroup, and the stream cut into time slices (one wavefront each) while that adds
     // wavefronts the chip can still use
     const size_t nseg = (Tlen + SEG - 1) / SEG;
@@ -435,20 +435,21 @@ int launch_xd(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, co
     if (want * L > scratch_len) want = scratch_len / L;
     if (want < 1) want = 1;                                            // (one slice = the whole stream: same kernel)
     const size_t per = nseg ? (nseg + want - 1) / want : 1, n = nseg ? (nseg + per - 1) / per : 1;
-    return launch_x<T, DB, J, 1, true>(Ty, Tlen, ld, L, cbT, cb64, xin, x, yhat, nll, stream, ev0, ev1, (int)n, (int)per, scratch);
+    return launch_x<T, DB, J, 1, true>(Ty, Tlen, ld, L, cbT, cb64, xin, x, yhat, nll, stream, ev0, ev1, (int)n, (int)per, scratch, ldo);
 }
 
 }  // namespace
 
 int launch_filter_stream_x(int kernel, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* cb64, const float* cb32,
                            const void* xin, void* x, void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1,
-                           double* scratch, size_t scratch_len, int force_slices) {
+                           double* scratch, size_t scratch_len, int force_slices, size_t ldo) {
     if (L == 0) return 0;
+    if (ldo == 0) ldo = ld;
     const int base = kernel_base(kernel), J = kernel_stack(kernel);
 #define MOIHGP_X_CASE(DBB, JJ)                                                                                        \
     if (base == (DBB == 2 ? 0 : 1) && J == JJ)                                                                        \
-        return dtype == 0 ? launch_xd<double, DBB, JJ>(Ty, T, ld, L, cb64, cb64, xin, x, yhat, nll, stream, ev0, ev1, scratch, scratch_len, force_slices)      \
-                          : launch_xd<float, DBB, JJ>(Ty, T, ld, L, cb32, cb64, xin, x, yhat, nll, stream, ev0, ev1, scratch, scratch_len, force_slices)
+        return dtype == 0 ? launch_xd<double, DBB, JJ>(Ty, T, ld, L, cb64, cb64, xin, x, yhat, nll, stream, ev0, ev1, scratch, scratch_len, force_slices, ldo) \
+                          : launch_xd<float, DBB, JJ>(Ty, T, ld, L, cb32, cb64, xin, x, yhat, nll, stream, ev0, ev1, scratch, scratch_len, force_slices, ldo)
     MOIHGP_X_CASE(2, 2); MOIHGP_X_CASE(2, 3); MOIHGP_X_CASE(2, 4);
     MOIHGP_X_CASE(3, 2); MOIHGP_X_CASE(3, 3); MOIHGP_X_CASE(3, 4);
 #undef MOIHGP_X_CASE

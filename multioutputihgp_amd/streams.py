@@ -155,18 +155,20 @@ class LatentBank:
             if yhat is None:
                 yhat = self._like_stream(Ty)
             elif (not yhat.is_cuda or yhat.dtype != Ty.dtype or yhat.dim() != 2 or yhat.stride(1) != 1
-                  or yhat.stride(0) != ld or yhat.shape[0] != self.L or yhat.shape[1] < T):
-                raise ValueError("yhat must match Ty: same dtype, [L, >=T], same row stride (the C ABI has one ld)")
+                  or yhat.shape[0] != self.L or yhat.shape[1] < T or (self.L > 1 and yhat.stride(0) < padded_len(T, Ty.dtype))
+                  or yhat.stride(0) % (2 if Ty.dtype == torch.float64 else 4) != 0):
+                raise ValueError("yhat must be a CUDA tensor [L, >=T] of the stream's dtype, unit stride along time, row stride a multiple of "
+                                 "16 bytes and >= T rounded up to it (it need not equal the stream's: moihgp_filter_stream_v2 takes both)")
         if x.dtype != Ty.dtype or not x.is_contiguous() or tuple(x.shape) != (self.L, self.d):
             raise ValueError("x must be a contiguous [L, d] tensor of the stream dtype")
         if want_nll and nll is None:
             nll = torch.empty((self.L,), dtype=torch.float64, device=Ty.device)
         if x_start is not None and (x_start.dtype != Ty.dtype or not x_start.is_contiguous() or tuple(x_start.shape) != (self.L, self.d)):
             raise ValueError("x_start must be a contiguous [L, d] tensor of the stream dtype")
-        rc = self._lib.moihgp_filter_stream_io(
+        rc = self._lib.moihgp_filter_stream_v2(
             self._h, _DT[Ty.dtype], C.c_void_p(Ty.data_ptr()), T, ld, C.c_void_p((x if x_start is None else x_start).data_ptr()),
             C.c_void_p(x.data_ptr()),
-            C.c_void_p(yhat.data_ptr()) if want_yhat else None,
+            C.c_void_p(yhat.data_ptr()) if want_yhat else None, ((yhat.stride(0) if self.L > 1 else padded_len(T, Ty.dtype)) if want_yhat else 0),
             C.c_void_p(nll.data_ptr()) if want_nll else None,
             C.c_void_p(nll_total.data_ptr()) if (nll_total is not None and want_nll) else None, _stream_ptr(stream))
         _check(rc, self._lib)

@@ -1141,3 +1141,66 @@ def test_update_waits_for_sweeps_in_flight(env, kernel, J):
     torch.cuda.synchronize()
     assert torch.equal(y_new[:, :T], y_f[:, :T]) and torch.equal(nll_new, nll_f)
     assert not torch.equal(nll_new, nll_ref)
+
+
+# ------------------------------------------------------------------------------------------ additive ABI: output stride, return codes
+def test_filtered_means_into_a_buffer_shaped_unlike_the_stream(env):
+    """moihgp_filter_stream_v2: yhat has its own row stride.  A column slice of a wide slab as input, a compact array as output (the
+    shape that wrote out of bounds through the single-ld entries in round 1), and the other way round."""
+    rng = np.random.default_rng(12)
+    L, Tw, T0, T = 37, 3000, 1000, 1536
+    prm = synth_params(L, rng)
+    bank = env["streams"].LatentBank(0.1, prm, kernel="Matern52ss")
+    wide = to_dev(synth(L, Tw, rng), torch.float32)
+    src = wide[:, T0:T0 + T]                                   # row stride 3000, 16-byte aligned start
+    guard = torch.full((L * T + 4096,), 777.0, dtype=torch.float32, device="cuda")
+    compact = guard[:L * T].view(L, T)                         # row stride T: the tail of `guard` must stay untouched
+    y1, x1, n1 = bank.filter(src, T=T, yhat=compact)
+    ref_y, ref_x, ref_n = bank.filter(src.contiguous(), T=T)
+    torch.cuda.synchronize()
+    assert torch.equal(y1, ref_y[:, :T]) and torch.equal(n1, ref_n) and torch.equal(x1, ref_x)
+    assert bool((guard[L * T:] == 777.0).all())
+    out_wide = torch.full((L, Tw), 555.0, dtype=torch.float32, device="cuda")
+    y2, _, _ = bank.filter(src.contiguous(), T=T, yhat=out_wide[:, 500:500 + T])
+    torch.cuda.synchronize()
+    assert torch.equal(y2, ref_y[:, :T]) and bool((out_wide[:, :500] == 555.0).all()) and bool((out_wide[:, 500 + T:] == 555.0).all())
+    # stacked kernels take the same entry
+    Ls = 9
+    prm_s = np.column_stack([rng.uniform(0.5, 2, Ls), rng.uniform(0.5, 2, Ls), rng.uniform(0.5, 2, Ls), rng.uniform(0.5, 2, Ls), rng.uniform(0.05, 0.2, Ls)])
+    bs = env["streams"].LatentBank(0.1, prm_s, kernel="Matern52x2")
+    wide_s = to_dev(synth(Ls, Tw, rng), torch.float64)
+    src_s = wide_s[:, 1000:1000 + T]
+    comp_s = torch.empty((Ls, T), dtype=torch.float64, device="cuda")
+    ya, _, na = bs.filter(src_s, T=T, yhat=comp_s)
+    yb, _, nb = bs.filter(src_s.contiguous(), T=T)
+    torch.cuda.synchronize()
+    assert torch.equal(ya, yb[:, :T]) and torch.equal(na, nb)
+
+
+def test_additive_entries_report_instead_of_aborting(env):
+    """Part 2 of include/moihgp.h returns codes: 1 invalid argument, 2 HIP failure, 3 unsupported input; constructors return NULL.
+    moihgp_last_error() holds the text.  (The reference entries have no channel and abort, wrapper.cpp:31-326.)"""
+    import ctypes as C
+    from multioutputihgp_amd._lib import c_double_p, last_error
+    lib = env["lib"]
+    bank = env["streams"].LatentBank(0.1, [[1, 1, 0.1]] * 8, kernel="Matern32")
+    Ty = torch.zeros((8, 64), dtype=torch.float32, device="cuda"); x = torch.zeros((8, 2), dtype=torch.float32, device="cuda")
+    yh = torch.zeros((8, 64), dtype=torch.float32, device="cuda")
+    args = lambda ld_out: (bank._h, 1, C.c_void_p(Ty.data_ptr()), 64, 64, C.c_void_p(x.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(yh.data_ptr()), ld_out, None, None, None)
+    assert lib.moihgp_filter_stream_v2(*args(62)) == 1 and "ld_out" in last_error(lib)          # not a multiple of 16 bytes
+    assert lib.moihgp_filter_stream_v2(*args(32)) == 1 and "ld_out" in last_error(lib)          # shorter than T
+    assert lib.moihgp_filter_stream_v2(*args(64)) == 0
+    gp = env["MOIHGP"](0.1, 4, 2, kernel="Matern32")
+    z = np.zeros(64)
+    assert lib.moihgp_window_eval(gp.handle, z.ctypes.data_as(c_double_p), z.ctypes.data_as(c_double_p), z.ctypes.data_as(c_double_p),
+                                  z.ctypes.data_as(c_double_p), None, None) == 1                 # no window set
+    Yn = np.full((3, 4), np.nan)
+    assert lib.moihgp_window_set(gp.handle, Yn.ctypes.data_as(c_double_p), 3) == 3
+    assert lib.moihgp_pin_host_buffer(gp.handle, C.c_void_p(8), 1 << 20) == 2                    # HIP refuses: reported, not fatal
+    # a device allocation that cannot succeed (2^27 latents: 375 GB of constant blocks): NULL + message, the process lives
+    h = lib.moihgp_new_latents(1, C.c_double(0.1), C.c_size_t(1 << 27), None)
+    assert not h and "HIP error" in last_error(lib)
+    torch.cuda.synchronize()
+    yb, _, _ = bank.filter(Ty, T=64)                                                             # and the library still works
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(yb).all())
