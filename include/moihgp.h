@@ -199,10 +199,12 @@ int moihgp_grad_stream(moihgp_gp* gp, int dtype, const void* Ty, size_t T, size_
  * example.py:40-42); the projected stream comes out series-major [L][ld] ready for the recursion:
  *     Ty[l][t] = S_l^-1/2 * sum_m U[m][l] Y[t][m]                 (moihgp.h:181)
  * and back:  Yhat[t][m] = sum_l U[m][l] S_l^1/2 Tyhat[l][t]       (moihgp.h:222-225)
- * Ticks whose observation vector contains NaN are NOT re-projected here (the reference switches those
- * ticks to a least-squares projection over the observed rows, moihgp.h:167-178): the NaN propagates
- * into Ty[:, t], i.e. the whole tick is treated as missing by the recursion.  Use the per-tick ABI
- * (gp32_step*) for partially observed ticks. */
+ * A tick whose observation vector holds NaN (missing outputs) is projected as the reference does it, by least squares over the observed
+ * rows (moihgp.h:167-178): Ty[:, t] = S^-1/2 (U0^T U0)^-1 U0^T y_obs -- evaluated through the k x k system of the k missing rows
+ * (U^T U = I for the polar factor update() installs: U0^T U0 = I - U_miss^T U_miss), the same vector to rounding.  It needs
+ * orthonormal columns (checked when the mixing comes from moihgp_set_mixing), at most 64 missing outputs in the tick and at least L
+ * observed ones; otherwise the NaN propagates into Ty[:, t], i.e. the recursion treats the whole tick as missing (use the per-tick ABI
+ * for such ticks). */
 int moihgp_project_stream(moihgp_gp* gp, int dtype, const void* Y, size_t T, void* Ty, size_t ld, void* stream);
 int moihgp_unproject_stream(moihgp_gp* gp, int dtype, const void* Tyhat, size_t T, size_t ld, void* Yhat, void* stream);
 

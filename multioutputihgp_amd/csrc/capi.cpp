@@ -77,6 +77,7 @@ struct moihgp_gp {
     double* cbd64 = nullptr;     // stacked kernels: sensitivity blocks (XD), fp64; filled once somebody asks for gradients
     bool sens_wanted = false, sens_valid = false;
     bool U_host_stale = false; // the device holds a newer U than the host mirror (fetched on getParams)
+    bool mix_ortho = true;     // U^T U = I to 1e-9 (always after update() / the constructor: a polar factor; checked after moihgp_set_mixing)
     double *hin = nullptr, *hout = nullptr, *hgrad = nullptr;   // page-locked, device-mapped per-tick staging
     unsigned long long* hflag = nullptr;                        // mapped completion word of the fused small-model step
     unsigned long long seq = 0;
@@ -384,6 +385,7 @@ static bool compute_polar(moihgp_gp* g, const double* Uparam) {
     }
     if (its < 0) return false;
     g->U_host_stale = true;                      // 8*M*L bytes over PCIe only when somebody asks (getParams)
+    g->mix_ortho = true;                         // a polar factor
     return true;
 }
 
@@ -532,7 +534,17 @@ static int set_mixing_impl(moihgp_gp* gp, const double* U, const double* S, doub
     gp->sigma = sigma;
     gp->U_host_stale = false;
     upload_mixing(gp);
-    MOIHGP_HIP_FATAL(hipStreamSynchronize(gp->stream));
+    {   // are the columns orthonormal (a column slice of a polar factor is)?  moihgp_project_stream's least-squares path for partially
+        // observed ticks relies on U^T U = I; measured on the device: Gram matrix (MFMA), then max |G - I|
+        const size_t L = gp->L;
+        if (!gp->dwork) gp->dwork = dev_alloc<double>(L * L + L);
+        if (int rc = launch_gram(gp->dU, gp->M, L, gp->dwork, gp->stream)) return rc;
+        launch_ortho_defect(gp->dwork, L, gp->dloss, gp->stream);
+        double defect = 0.0;
+        MOIHGP_HIP_FATAL(hipMemcpyAsync(&defect, gp->dloss, sizeof(double), hipMemcpyDeviceToHost, gp->stream));
+        MOIHGP_HIP_FATAL(hipStreamSynchronize(gp->stream));
+        gp->mix_ortho = defect < 1e-9;
+    }
     return 0;
 }
 
@@ -750,8 +762,11 @@ static int project_stream_impl(moihgp_gp* gp, int dtype, const void* Y, size_t T
     if (!gp || gp->latents_only) { set_last_error("project_stream needs a full MOIHGP object"); return 1; }
     if (ld < T) { set_last_error("ld < T"); return 1; }
     note_user_stream(gp, (hipStream_t)stream);
-    return launch_project_stream(dtype, Y, T, gp->M, gp->L, gp->dU, dtype == MOIHGP_F64 ? nullptr : mixing_f32(gp), gp->dinvsqrtS, Ty, ld,
-                                 (hipStream_t)stream);
+    if (int rc = launch_project_stream(dtype, Y, T, gp->M, gp->L, gp->dU, dtype == MOIHGP_F64 ? nullptr : mixing_f32(gp), gp->dinvsqrtS, Ty, ld,
+                                       (hipStream_t)stream)) return rc;
+    // partially observed ticks: least squares over the observed rows (moihgp.h:167-178), one workgroup per tick behind the GEMM
+    if (gp->mix_ortho && gp->L <= 16384) return launch_project_stream_missing(dtype, Y, T, gp->M, gp->L, gp->dU, gp->dinvsqrtS, Ty, ld, (hipStream_t)stream);
+    return 0;
 }
 
 int moihgp_project_stream(moihgp_gp* gp, int dtype, const void* Y, size_t T, void* Ty, size_t ld, void* stream) {

@@ -162,6 +162,11 @@ struct TickArgs {
 };
 void launch_project_tick(const TickArgs& a, const double* y, double* Ty, double* Uty, double* part /* [32][L] scratch or NULL */, hipStream_t s);
 void launch_project_tick_missing(const TickArgs& a, const double* y, double* Ty, double* work /*L*L+L*/, hipStream_t s);
+// whole streams: re-project the ticks whose observation vector holds NaN by least squares over the observed rows (moihgp.h:167-178),
+// behind launch_project_stream; needs U^T U = I (a polar factor).  Y [T][M], Ty [L][ld] of `dtype`.
+int launch_project_stream_missing(int dtype, const void* Y, size_t T, size_t M, size_t L, const double* U, const double* invsqrtS, void* Ty, size_t ld,
+                                   hipStream_t s);
+void launch_ortho_defect(const double* G /* L x L */, size_t L, double* out /* device scalar: max |G - I| */, hipStream_t s);
 void launch_step_tick(const TickArgs& a, const double* x, const double* Ty /*NULL: predict only*/, const double* dx,
                       double* xnew, double* Tyhat, double* dxnew, hipStream_t s);
 void launch_unproject_tick(const TickArgs& a, const double* Tyhat, double* yhat, hipStream_t s);

@@ -255,6 +255,87 @@ __global__ void ugrad_kernel(size_t M, size_t L, const double* __restrict__ S, c
     grad[idx] = y[r] * (pv[c] * (1.0 / sqrt(S[c])) - Uty[c] / *sigma_p);
 }
 
+
+// ---- whole streams: ticks with missing outputs (moihgp.h:167-178) ----------------------------------------------------------------------
+// The stream projection (gemm_mfma.hip) computes S^-1/2 U^T y_t for every tick; a tick whose observation vector holds NaN comes out
+// as a NaN column.  This kernel, queued behind it, re-projects exactly those ticks the way the reference does, by least squares over
+// the observed rows:  a = (U0^T U0)^-1 U0^T y_obs,  Ty_t = S^-1/2 a.  U is a polar factor (moihgp.h:438-446): U^T U = I, so with
+// U_miss the k rows of the missing outputs  U0^T U0 = I - U_miss^T U_miss  and (Woodbury)
+//     a = r + U_miss^T (I_k - U_miss U_miss^T)^-1 U_miss r,      r = U0^T y_obs = U^T (y with its NaNs set to 0):
+// a k x k solve (k = number of missing outputs of the tick) instead of the reference's L x L LDLT, the same vector to rounding.
+// One workgroup per tick; a tick without NaN costs one pass over its M observations and leaves at once.  fp64 inside whatever the
+// stream type.  k > kLsMaxMissing or fewer observed outputs than latents: the column stays NaN (the recursion then treats the tick as
+// missing; the reference would factor a singular matrix there).
+constexpr int kLsMaxMissing = 64;
+
+template <typename T>
+__global__ void __launch_bounds__(256) ls_project_kernel(const T* __restrict__ Y, size_t Tn, size_t M, size_t L, const double* __restrict__ U,
+                                                         const double* __restrict__ invsqrtS, T* __restrict__ Ty, size_t ld) {
+    extern __shared__ double lsm[];
+    double* r = lsm;                                   // [L]
+    double* G = r + L;                                 // [k][k+1] augmented system (I - U_miss U_miss^T | U_miss r)
+    __shared__ int miss[kLsMaxMissing];
+    __shared__ int kcount;
+    const size_t t = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const T* y = Y + t * M;
+    if (tid == 0) kcount = 0;
+    __syncthreads();
+    for (size_t m = tid; m < M; m += 256) {
+        const T v = y[m];
+        if (v != v) { const int slot = atomicAdd(&kcount, 1); if (slot < kLsMaxMissing) miss[slot] = (int)m; }
+    }
+    __syncthreads();
+    const int k = kcount;
+    if (k == 0) return;                                // fully observed tick: the GEMM's column stands
+    if (k > kLsMaxMissing || M - (size_t)k < L) return;   // not solvable here: the NaN column stands (tick treated as missing)
+    if (tid == 0) {                                    // deterministic order of the missing rows (the atomics arrive in any order)
+        for (int i = 1; i < k; i++) { const int v = miss[i]; int j = i - 1; while (j >= 0 && miss[j] > v) { miss[j + 1] = miss[j]; j--; } miss[j + 1] = v; }
+    }
+    // r = U^T y0: lanes over latents (coalesced rows of U), NaN observations skipped (moihgp.h:171-176)
+    for (size_t l = tid; l < L; l += 256) {
+        double sacc = 0.0;
+        for (size_t m = 0; m < M; m++) { const double v = (double)y[m]; if (v == v) sacc = fma(U[m * L + l], v, sacc); }
+        r[l] = sacc;
+    }
+    __syncthreads();
+    // augmented k x (k+1) system: entry (i, j) = delta_ij - u_i . u_j, entry (i, k) = u_i . r; one wave per entry, butterfly sum
+    const int kk = k + 1;
+    for (int e = wave; e < k * kk; e += 4) {
+        const int i = e / kk, j = e % kk;
+        const double* ui = U + (size_t)miss[i] * L;
+        double sacc = 0.0;
+        if (j < k) { const double* uj = U + (size_t)miss[j] * L; for (size_t l = lane; l < L; l += 64) sacc = fma(ui[l], uj[l], sacc); }
+        else for (size_t l = lane; l < L; l += 64) sacc = fma(ui[l], r[l], sacc);
+        for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o);
+        if (lane == 0) G[i * kk + j] = (j < k) ? ((i == j ? 1.0 : 0.0) - sacc) : sacc;
+    }
+    __syncthreads();
+    if (wave == 0) {                                   // (I - G) c = w: symmetric positive definite, elimination without pivoting, lane = row
+        for (int p = 0; p < k; p++) {
+            const double piv = G[p * kk + p];
+            if (lane > p && lane < k) {
+                const double f = G[lane * kk + p] / piv;
+                for (int j = p; j < kk; j++) G[lane * kk + j] -= f * G[p * kk + j];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (lane == 0) {
+            for (int i = k - 1; i >= 0; i--) {
+                double sacc = G[i * kk + k];
+                for (int j = i + 1; j < k; j++) sacc -= G[i * kk + j] * G[j * kk + k];
+                G[i * kk + k] = sacc / G[i * kk + i];
+            }
+        }
+    }
+    __syncthreads();
+    // a = r + U_miss^T c;  Ty[l][t] = S_l^-1/2 a_l  (moihgp.h:177)
+    for (size_t l = tid; l < L; l += 256) {
+        double a = r[l];
+        for (int i = 0; i < k; i++) a = fma(U[(size_t)miss[i] * L + l], G[i * kk + k], a);
+        Ty[l * ld + t] = (T)(invsqrtS[l] * a);
+    }
+}
 }  // namespace
 
 static inline unsigned nblk(size_t n, unsigned b) { return (unsigned)((n + b - 1) / b); }
@@ -279,6 +360,44 @@ void launch_project_tick_missing(const TickArgs& a, const double* y, double* Ty,
     hipLaunchKernelGGL(normal_eq_kernel, dim3(nblk(a.L * a.L, 128)), dim3(128), 0, s, a.M, a.L, a.U, y, N, r);
     hipLaunchKernelGGL(spd_solve_kernel, dim3(1), dim3(256), 0, s, a.L, N, r, a.S, Ty);
     MOIHGP_HIP_FATAL(hipGetLastError());
+}
+
+// max |G - I| over an L x L matrix (G = U^T U from launch_gram): how far the mixing is from orthonormal columns
+__global__ void __launch_bounds__(1024) ortho_defect_kernel(const double* __restrict__ G, size_t L, double* __restrict__ out) {
+    __shared__ double red[16];
+    double mx = 0.0;
+    for (size_t i = threadIdx.x; i < L * L; i += 1024) {
+        const double d = fabs(G[i] - ((i / L == i % L) ? 1.0 : 0.0));
+        mx = (d > mx || d != d) ? d : mx;               // (NaN sticks)
+    }
+    for (int o = 32; o > 0; o >>= 1) { const double v = __shfl_xor(mx, o); mx = (v > mx || v != v) ? v : mx; }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m2 = 0.0;
+        for (int w = 0; w < 16; w++) m2 = (red[w] > m2 || red[w] != red[w]) ? red[w] : m2;
+        *out = m2;
+    }
+}
+void launch_ortho_defect(const double* G, size_t L, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(ortho_defect_kernel, dim3(1), dim3(1024), 0, s, G, L, out);
+    MOIHGP_HIP_FATAL(hipGetLastError());
+}
+
+int launch_project_stream_missing(int dtype, const void* Y, size_t T, size_t M, size_t L, const double* U, const double* invsqrtS, void* Ty, size_t ld,
+                                   hipStream_t s) {
+    if (T == 0 || L == 0) return 0;
+    const size_t smem = (L + (size_t)kLsMaxMissing * (kLsMaxMissing + 1)) * sizeof(double);
+    if (smem > 150 * 1024) { set_last_error("project_stream: %zu latents exceed the least-squares kernel's LDS", L); return 1; }
+    if (dtype == 0) {
+        if (smem > 48 * 1024) MOIHGP_HIP_FATAL(hipFuncSetAttribute(reinterpret_cast<const void*>(ls_project_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(ls_project_kernel<double>, dim3((unsigned)T), dim3(256), smem, s, (const double*)Y, T, M, L, U, invsqrtS, (double*)Ty, ld);
+    } else {
+        if (smem > 48 * 1024) MOIHGP_HIP_FATAL(hipFuncSetAttribute(reinterpret_cast<const void*>(ls_project_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(ls_project_kernel<float>, dim3((unsigned)T), dim3(256), smem, s, (const float*)Y, T, M, L, U, invsqrtS, (float*)Ty, ld);
+    }
+    MOIHGP_HIP_FATAL(hipGetLastError());
+    return 0;
 }
 
 void launch_step_tick(const TickArgs& a, const double* x, const double* Ty, const double* dx, double* xnew,

@@ -215,6 +215,11 @@ class ShardedMOIHGP:
         from .streams import LatentBank, project_stream, unproject_stream
         import math
         T = Y.shape[0]
+        if self.world > 1 and bool(torch.isnan(Y).any()):
+            # the least-squares projection of a partially observed tick (moihgp.h:167-178) couples ALL latents through (U0^T U0)^-1: a
+            # rank's column slice alone gives a different vector.  (The k x k system of the missing rows would need its Gram matrix and
+            # right-hand side summed over the ranks: one more small all-reduce per affected tick -- not built yet.)
+            raise NotImplementedError("ShardedMOIHGP.filter: observation vectors with missing outputs (NaN) need the unsharded path")
         Ty = project_stream(self._shard, Y)
         bank = LatentBank.from_handle(self._shard)
         yhat_lat, _, nll = bank.filter(Ty, T=T)

@@ -1204,3 +1204,70 @@ def test_additive_entries_report_instead_of_aborting(env):
     yb, _, _ = bank.filter(Ty, T=64)                                                             # and the library still works
     torch.cuda.synchronize()
     assert bool(torch.isfinite(yb).all())
+
+
+# ------------------------------------------------------------------------------------------ N1: partially observed ticks on the batched path
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("kern,M,L,T", [("Matern32", 8, 4, 60), ("Matern52", 96, 64, 300), ("Matern52", 700, 300, 128)])
+def test_project_stream_with_missing_outputs(env, dtype, kern, M, L, T):
+    """moihgp.h:167-178: a tick with missing outputs (NaN) is projected by least squares over the observed rows.  The stream
+    projection does it per affected tick behind its GEMM; checked against the oracle's per-tick projection and, end to end, against
+    the per-tick ABI (project -> sweep -> unproject == a loop of gp.step(x, y) with the same NaNs)."""
+    rng = np.random.default_rng(M + L + T)
+    gp = env["MOIHGP"](0.1, M, L, kernel=KMAP[kern])
+    ref = env["cref"].GP(0.1, M, L, kern)
+    params = np.concatenate([(np.eye(M, L) + 0.2 * rng.standard_normal((M, L))).ravel(), rng.uniform(0.5, 2, L), [0.04], synth_params(L, rng).ravel()])
+    gp.update(params); ref.update(params)
+    Y = rng.standard_normal((T, M))
+    hit = rng.choice(T, size=T // 4, replace=False)
+    for t in hit:                                              # 1 .. min(M - L, 40) missing outputs per affected tick
+        k = int(rng.integers(1, max(2, min(M - L, 40)) + 1)) if M - L >= 2 else 1
+        Y[t, rng.choice(M, size=min(k, M - L), replace=False)] = np.nan
+    Yd = torch.from_numpy(Y).to(dtype).cuda()
+    Ty = env["streams"].project_stream(gp, Yd)
+    torch.cuda.synchronize()
+    want = np.stack([ref.project(Y[t]) for t in range(T)], axis=1)            # [L, T]
+    got = Ty[:, :T].double().cpu().numpy()
+    assert np.isfinite(got).all()
+    tol = 1e-9 if dtype == torch.float64 else 2e-4
+    assert rel_err(got, want) < tol
+    assert rel_err(got[:, hit], want[:, hit]) < tol
+    if dtype == torch.float64:
+        bank = env["streams"].LatentBank.from_handle(gp)
+        yl, xT, _ = bank.filter(Ty, T=T)
+        Yhat = env["streams"].unproject_stream(gp, yl, T)
+        torch.cuda.synchronize()
+        x = np.zeros((L, gp.igp_dim)); out = np.empty((T, M))
+        for t in range(min(T, 80)):
+            x, out[t] = gp.step(x, Y[t])
+        assert rel_err(Yhat[:min(T, 80)].cpu().numpy(), out[:min(T, 80)]) < 1e-9
+
+
+def test_project_stream_missing_outputs_beyond_the_least_squares_path(env):
+    """More than 64 missing outputs, or fewer observed outputs than latents: the column stays NaN (the tick is then a missing tick for the
+    recursion); a mixing without orthonormal columns (moihgp_set_mixing with an arbitrary matrix) switches the path off."""
+    import ctypes as C
+    from multioutputihgp_amd._lib import c_double_p
+    rng = np.random.default_rng(3)
+    M, L, T = 200, 100, 10
+    gp = env["MOIHGP"](0.1, M, L, kernel="Matern32")
+    Y = rng.standard_normal((T, M))
+    Y[2, :70] = np.nan                                         # 70 missing > 64
+    Y[5, :101] = np.nan                                        # 99 observed < L
+    Y[7, 3] = np.nan
+    Ty = env["streams"].project_stream(gp, torch.from_numpy(Y).cuda())
+    torch.cuda.synchronize()
+    bad = torch.isnan(Ty[:, :T]).all(dim=0).cpu().numpy()
+    assert list(np.nonzero(bad)[0]) == [2, 5] and bool(torch.isfinite(Ty[:, 7]).all())
+    U = np.ascontiguousarray(np.eye(M, L) + 0.3 * rng.standard_normal((M, L))); S = np.ones(L)
+    assert env["lib"].moihgp_set_mixing(gp.handle, U.ctypes.data_as(c_double_p), S.ctypes.data_as(c_double_p), C.c_double(0.01)) == 0
+    Ty2 = env["streams"].project_stream(gp, torch.from_numpy(Y).cuda())
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(Ty2[:, 7]).all())                  # not orthonormal: NaN propagates as documented
+    Q, _ = np.linalg.qr(U); Q = np.ascontiguousarray(Q)
+    assert env["lib"].moihgp_set_mixing(gp.handle, Q.ctypes.data_as(c_double_p), S.ctypes.data_as(c_double_p), C.c_double(0.01)) == 0
+    Ty3 = env["streams"].project_stream(gp, torch.from_numpy(Y).cuda())
+    torch.cuda.synchronize()
+    y7 = Y[7].copy(); obs = ~np.isnan(y7)
+    a = np.linalg.solve(Q[obs].T @ Q[obs], Q[obs].T @ y7[obs])
+    assert rel_err(Ty3[:, 7].cpu().numpy(), a) < 1e-10
