@@ -97,9 +97,11 @@ enum { MOIHGP_F64 = 0, MOIHGP_F32 = 1 };
  * d = 6 / d = 12 shapes).  The reference ships no such model; it is what its IHGP<StateSpace> template (ihgp.h:17-35)
  * computes for a StateSpace with F, Pinf block-diagonal in the reference's component models and H = [H_1 .. H_J].
  * J in {2, 3, 4}.  Hyper-parameters per latent: [magnitude_1, lengthscale_1, .., magnitude_J, lengthscale_J, noise]
- * (P = 2J + 1).  Accepted by moihgp_new_latents / moihgp_update_latents / moihgp_filter_stream / moihgp_grad_stream /
- * moihgp_get_latent (latent banks; the full-object entries -- mixing, per-tick ABI, window objective -- refuse it).  The
- * sensitivities of IHGP::update (ihgp.h:136-200) are computed from the first call that needs them on. */
+ * (P = 2J + 1).  Accepted everywhere a kernel id is: latent banks (moihgp_new_latents / moihgp_update_latents /
+ * moihgp_filter_stream / moihgp_grad_stream / moihgp_get_latent) and full objects (moihgp_new: OILMM mixing, the gpXX_* per-tick
+ * entries on the handle, moihgp_project_stream / moihgp_unproject_stream, the window objective), with params / grad laid out as
+ * [U row-major | S | sigma | P values per latent] (moihgp.h:93 with num_igp_param = 2J + 1).  The sensitivities of IHGP::update
+ * (ihgp.h:136-200) are computed from the first call that needs them on. */
 #define MOIHGP_STACK(base, J) ((base) | ((J) << 4))
 
 /* Thread-local message of the last failure ("" if none). */

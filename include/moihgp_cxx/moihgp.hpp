@@ -26,6 +26,11 @@ namespace moihgp {
 // Tags standing in for the reference's StateSpace template arguments (matern32ss.h:13, matern52ss.h:13).
 struct Matern32StateSpace { static constexpr int kernel_id = MOIHGP_MATERN32; };
 struct Matern52StateSpace { static constexpr int kernel_id = MOIHGP_MATERN52; };
+// Stacked state: the sum of J (2, 3 or 4) Matern components behind one output, state dim 2J / 3J, 2J + 1 hyper-parameters per latent
+// (BASELINE.json's d = 6 / d = 12 shapes; not a model the reference ships -- what its IHGP<StateSpace> template computes for a
+// block-diagonal StateSpace built from its own component models, include/moihgp.h MOIHGP_STACK).
+template <int J> struct StackedMatern32StateSpace { static constexpr int kernel_id = MOIHGP_STACK(MOIHGP_MATERN32, J); };
+template <int J> struct StackedMatern52StateSpace { static constexpr int kernel_id = MOIHGP_STACK(MOIHGP_MATERN52, J); };
 
 template <typename StateSpace>
 class MOIHGP {

@@ -97,7 +97,7 @@ struct moihgp_gp {
     std::vector<hipEvent_t> prof_ev;
     int prof_n = 0;
 
-    TickArgs tick() const { return TickArgs{d, M, L, cb64, dU, dS, dsqrtS, dinvsqrtS, dsigma, (threading || lik1_full) ? 1 : 0}; }
+    TickArgs tick() const { return TickArgs{d, M, L, cb64, dU, dS, dsqrtS, dinvsqrtS, dsigma, (threading || lik1_full) ? 1 : 0, P, cbd64}; }
 };
 
 static void gp_free(moihgp_gp* g) {
@@ -192,10 +192,6 @@ static moihgp_gp* gp_create(int kernel, double dt, size_t M, size_t L, bool late
     }
     const int kbase = kernel_base(kernel), kstack = kernel_stack(kernel);
     if ((kbase != MOIHGP_MATERN32 && kbase != MOIHGP_MATERN52) || kstack == 1 || kstack > 4) { set_last_error("unknown kernel id %d", kernel); return nullptr; }
-    if (kstack && !latents_only) {
-        set_last_error("stacked kernels are filter-mode latent banks (moihgp_new_latents); the mixing of a full object does not depend on the kernel");
-        return nullptr;
-    }
     if (L == 0) { set_last_error("num_latent must be >= 1"); return nullptr; }
     if (!latents_only && M < L) {
         // moihgp.h:510 indexes y(idx) for idx < num_latent and the thin SVD needs full column rank
@@ -243,7 +239,7 @@ static moihgp_gp* gp_create(int kernel, double dt, size_t M, size_t L, bool late
             g->ddx = g->dy + M;
             MOIHGP_HIP_FATAL(hipHostMalloc((void**)&g->hin, sizeof(double) * nin, hipHostMallocMapped));
             const char* fe = std::getenv("MOIHGP_TICK_FUSED");            // 0: always take the multi-kernel path
-            g->fused_ok = fused_step_fits(M, L) && !(fe && fe[0] == '0');
+            g->fused_ok = !kstack && fused_step_fits(M, L) && !(fe && fe[0] == '0');     // (the one-workgroup kernels are built for the reference's two models)
             MOIHGP_HIP_FATAL(hipHostMalloc((void**)&g->hout, sizeof(double) * (nin + 8), hipHostMallocMapped));
             if (g->num_param * sizeof(double) <= (size_t)1 << 20)
                 MOIHGP_HIP_FATAL(hipHostMalloc((void**)&g->hgrad, sizeof(double) * g->num_param, hipHostMallocMapped));
@@ -304,6 +300,7 @@ static void wait_flag(moihgp_gp* g, unsigned long long seq) {
 static void do_step(moihgp_gp* g, const double* x, const double* y, const double* dx, double* xnew, double* yhat, double* dxnew) {
     if (g->latents_only) { set_last_error("per-tick ABI needs a full MOIHGP object"); std::fprintf(stderr, "%s\n", g_last_error); std::abort(); }
     const size_t L = g->L, d = g->d, P = g->P, M = g->M;
+    if (dx) ensure_sensitivities(g);             // (stacked kernels compute dAKHA, dK, .. from the first call that needs them on)
     double* o_x = g->hout;                       // mapped host block: [xnew | yhat | dxnew | loss]
     double* o_y = o_x + L * d;
     double* o_dx = o_y + M;
@@ -336,6 +333,7 @@ static void do_step(moihgp_gp* g, const double* x, const double* y, const double
 static double do_lik(moihgp_gp* g, const double* x, const double* y, const double* dx, double* grad) {
     if (g->latents_only) { set_last_error("per-tick ABI needs a full MOIHGP object"); std::fprintf(stderr, "%s\n", g_last_error); std::abort(); }
     const size_t L = g->L, d = g->d, P = g->P, M = g->M;
+    if (dx) ensure_sensitivities(g);
     double* o_loss = g->hout + L * d + M + L * P * d;
     const bool small_grad = g->hgrad != nullptr;                         // gradient written straight to mapped host memory
     if (g->fused_ok && small_grad && fused_lik_fits(M, L) && !has_nan(y, M)) {
@@ -820,7 +818,8 @@ static int window_eval_impl(moihgp_gp* gp, const double* x, const double* dx, do
     WindowBufs& w = gp->win;
     MOIHGP_HIP_FATAL(hipMemcpyAsync(w.x, x, sizeof(double) * L * d, hipMemcpyHostToDevice, gp->stream));
     MOIHGP_HIP_FATAL(hipMemcpyAsync(w.dx, dx, sizeof(double) * L * P * d, hipMemcpyHostToDevice, gp->stream));
-    if (int rc = launch_window_objective(gp->tick(), gp->cb64, gp->cb32, w, gp->dfallback, gp->dloss, gp->dgrad, gp->stream)) return rc;
+    ensure_sensitivities(gp);
+    if (int rc = launch_window_objective(gp->tick(), gp->cb64, gp->cb32, w, gp->dfallback, gp->dloss, gp->dgrad, gp->stream, gp->kernel)) return rc;
     MOIHGP_HIP_FATAL(hipMemcpyAsync(loss, gp->dloss, sizeof(double), hipMemcpyDeviceToHost, gp->stream));
     MOIHGP_HIP_FATAL(hipMemcpyAsync(grad, gp->dgrad, sizeof(double) * gp->num_param, hipMemcpyDeviceToHost, gp->stream));
     if (xnew) MOIHGP_HIP_FATAL(hipMemcpyAsync(xnew, w.x, sizeof(double) * L * d, hipMemcpyDeviceToHost, gp->stream));

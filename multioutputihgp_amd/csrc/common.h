@@ -129,7 +129,8 @@ int launch_filter_stream_x(int kernel, int dtype, const void* Ty, size_t T, size
 
 // grad_x.hip: sensitivity / gradient sweep of the stacked models (needs the XD blocks).
 int launch_grad_stream_x(int kernel, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* cb64, const double* cbd64,
-                         void* x, void* dx, void* yhat, double* nll, double* grad, hipStream_t stream);
+                         void* x, void* dx, void* yhat, double* nll, double* grad, hipStream_t stream,
+                         int out_mode = 1 /* 1: yhat holds filtered means, 2: predicted means HA x_t (pre-step state) */);
 
 // recursion.hip: batched sweeps over series-major streams.
 int launch_filter_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, size_t L,
@@ -159,6 +160,10 @@ struct TickArgs {
     // moihgp.h:565-607: the gradient overload of negLogLikelihood adds the per-latent losses in its threaded branch (:590) and drops
     // them in the serial one (:597-607); 1 = add them (threading on, or MOIHGP_LIK1_FULL_LOSS=1), 0 = the serial branch's value.
     int lik1_latent_loss;
+    // stacked kernels (MOIHGP_STACK: state dim 4..12, P = 2J + 1 hyper-parameters): the per-latent matrices live in an XC block (cb64)
+    // and an XD sensitivity block (cbd64) instead of one CB block; P = 3 and cbd64 = NULL for the reference's two models
+    int P = kNumIgpParam;
+    const double* cbd64 = nullptr;
 };
 void launch_project_tick(const TickArgs& a, const double* y, double* Ty, double* Uty, double* part /* [32][L] scratch or NULL */, hipStream_t s);
 void launch_project_tick_missing(const TickArgs& a, const double* y, double* Ty, double* work /*L*L+L*/, hipStream_t s);
@@ -219,6 +224,7 @@ struct WindowBufs {
     double* dx;               // [L][P][d]
 };
 int launch_window_objective(const TickArgs& a, const double* cb64, const float* cb32, const WindowBufs& w, int* fallback,
-                            double* loss /* device scalar */, double* grad /* device [M*L+L+1+L*P] */, hipStream_t s);
+                            double* loss /* device scalar */, double* grad /* device [M*L+L+1+L*P] */, hipStream_t s,
+                            int kernel = 0 /* kernel id: a stacked one takes the stacked sweep */);
 
 }  // namespace moihgp

@@ -18,7 +18,7 @@ namespace {
 template <typename T, int DB, int J>
 __global__ void __launch_bounds__(64)
 grad_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, const double* __restrict__ cb64, const double* __restrict__ cbd64,
-              T* __restrict__ x, T* __restrict__ dx, T* __restrict__ yhat, double* __restrict__ nll, double* __restrict__ grad) {
+              T* __restrict__ x, T* __restrict__ dx, T* __restrict__ yhat, double* __restrict__ nll, double* __restrict__ grad, int out_mode) {
     constexpr int D = DB * J, NN = D * D, P = 2 * J + 1, NE = (P + 1) * D;
     using Lc = XC<D>;
     using Ld = XD<D, P>;
@@ -72,6 +72,11 @@ grad_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, const 
                 g += (v * dv - 0.5 * (v * v / S - 1) * sdS[lane]) / S;
                 if (lane == 0) acc += 0.5 * (v * v / S + logS);
             }
+            if (out_mode == 2 && lane == 0) {                          // predicted mean HA x_t of the pre-step state (window objective: pv of moihgp.h:510)
+                double hx = 0.0;
+                for (int j = 0; j < D; j++) hx += sHA[j] * st[j];
+                syh[k] = hx;
+            }
             const double* Mx = miss ? sA : sAKHA;
 #pragma unroll
             for (int q = 0; q < 2; q++) {
@@ -91,7 +96,7 @@ grad_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, const 
                         if (!miss) v += sdK[p * D + i] * y;          // ihgp.h:45 / :54
                     }
                     sn[e] = v;
-                    if (e == 0) syh[k] = v;                          // ihgp.h:51 `yhat = xnew(0, 0)`
+                    if (e == 0 && out_mode != 2) syh[k] = v;         // ihgp.h:51 `yhat = xnew(0, 0)`
                 }
             }
             wave_lds_fence();
@@ -111,11 +116,11 @@ grad_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, const 
 
 template <typename T, int DB, int J>
 int launch_gx(const void* Ty, size_t Tlen, size_t ld, size_t L, const double* cb64, const double* cbd64, void* x, void* dx, void* yhat,
-              double* nll, double* grad, hipStream_t stream) {
+              double* nll, double* grad, hipStream_t stream, int out_mode) {
     constexpr int D = DB * J, NN = D * D, P = 2 * J + 1, NE = (P + 1) * D;
     const size_t smem = (size_t)(2 * NN + 2 * P * NN + 2 * D + 2 * P * D + P + 2 * NE + 128) * sizeof(double);
     hipLaunchKernelGGL((grad_x_kernel<T, DB, J>), dim3((unsigned)L), dim3(64), smem, stream, (const T*)Ty, Tlen, ld, L, cb64, cbd64,
-                       (T*)x, (T*)dx, (T*)yhat, nll, grad);
+                       (T*)x, (T*)dx, (T*)yhat, nll, grad, out_mode);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_last_error("grad_x_kernel launch: %s", hipGetErrorString(e)); return 2; }
     return 0;
@@ -124,13 +129,13 @@ int launch_gx(const void* Ty, size_t Tlen, size_t ld, size_t L, const double* cb
 }  // namespace
 
 int launch_grad_stream_x(int kernel, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* cb64, const double* cbd64,
-                         void* x, void* dx, void* yhat, double* nll, double* grad, hipStream_t stream) {
+                         void* x, void* dx, void* yhat, double* nll, double* grad, hipStream_t stream, int out_mode) {
     if (L == 0) return 0;
     const int base = kernel_base(kernel), J = kernel_stack(kernel);
 #define MOIHGP_GX_CASE(DBB, JJ)                                                                                          \
     if (base == (DBB == 2 ? 0 : 1) && J == JJ)                                                                           \
-        return dtype == 0 ? launch_gx<double, DBB, JJ>(Ty, T, ld, L, cb64, cbd64, x, dx, yhat, nll, grad, stream)        \
-                          : launch_gx<float, DBB, JJ>(Ty, T, ld, L, cb64, cbd64, x, dx, yhat, nll, grad, stream)
+        return dtype == 0 ? launch_gx<double, DBB, JJ>(Ty, T, ld, L, cb64, cbd64, x, dx, yhat, nll, grad, stream, out_mode) \
+                          : launch_gx<float, DBB, JJ>(Ty, T, ld, L, cb64, cbd64, x, dx, yhat, nll, grad, stream, out_mode)
     MOIHGP_GX_CASE(2, 2); MOIHGP_GX_CASE(2, 3); MOIHGP_GX_CASE(2, 4);
     MOIHGP_GX_CASE(3, 2); MOIHGP_GX_CASE(3, 3); MOIHGP_GX_CASE(3, 4);
 #undef MOIHGP_GX_CASE

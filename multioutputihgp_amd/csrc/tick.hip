@@ -176,6 +176,81 @@ __global__ void igp_nll_kernel(size_t L, const double* __restrict__ cb, const do
     igp_nll_one<D>(cb + l * CB<D>::SIZE, x + l * D, yraw[l], Ty[l], dx ? dx + l * P * D : nullptr, lossv + l, pv + l, igrad + l * P);
 }
 
+// ---- stacked kernels (MOIHGP_STACK: d = 4 .. 12, P = 2J + 1 = 5 .. 9) behind the per-tick ABI ---------------------------------------------
+// Same one-tick arithmetic as the kernels above (ihgp.h:37-100, :204-222) with the state dimension and the parameter count as run-time
+// values and the matrices read from the stacked layout: XC block (AKHA, K, A, HA, S) + XD sensitivity block (dAKHA, dK, dA, HdA, dS).
+// These calls are launch-latency bound (one FFI crossing per tick); nothing here is worth unrolling.
+constexpr int kGenD = kMaxStackDim, kGenP = 9;
+struct XBlk {
+    const double *AKHA, *K, *A, *HA, *DAKHA, *DK, *DA, *HDA, *DS;
+    double S;
+};
+__device__ inline XBlk xblk(const double* cb64, const double* cbd64, size_t l, int d, int P) {
+    const double* c = cb64 + l * (size_t)xc_size(d);
+    XBlk b;
+    b.AKHA = c; b.K = c + d * d; b.A = b.K + d; b.HA = b.A + d * d; b.S = b.HA[d];                 // XC<D>: AKHA, K, A, HA, S
+    if (cbd64) {
+        const double* x = cbd64 + l * (size_t)xd_size(d, P);
+        b.DAKHA = x; b.DK = x + P * d * d; b.DA = b.DK + P * d; b.HDA = b.DA + P * d * d; b.DS = b.HDA + P * d;   // XD<D, P>
+    } else { b.DAKHA = b.DK = b.DA = b.HDA = b.DS = nullptr; }
+    return b;
+}
+
+__global__ void step_tick_x_kernel(size_t L, int d, int P, const double* __restrict__ cb64, const double* __restrict__ cbd64,
+                                   const double* __restrict__ x, const double* __restrict__ Ty, const double* __restrict__ dx,
+                                   double* __restrict__ xnew, double* __restrict__ Tyhat, double* __restrict__ dxnew) {
+    size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= L) return;
+    const XBlk b = xblk(cb64, cbd64, l, d, P);
+    double xs[kGenD], xn[kGenD];
+    for (int i = 0; i < d; i++) xs[i] = x[l * d + i];
+    const bool has_y = (Ty != nullptr);
+    const double y = has_y ? Ty[l] : 0.0;
+    const bool miss = !has_y || (y != y);                                // ihgp.h:39 / :96
+    const double* Mx = miss ? b.A : b.AKHA;
+    for (int i = 0; i < d; i++) {
+        double sacc = 0.0;
+        for (int k = 0; k < d; k++) sacc += Mx[i * d + k] * xs[k];
+        xn[i] = miss ? sacc : sacc + b.K[i] * y;                         // ihgp.h:41 / :50
+    }
+    for (int i = 0; i < d; i++) xnew[l * d + i] = xn[i];
+    if (Tyhat) Tyhat[l] = xn[0];                                         // ihgp.h:42 / :51
+    if (dx && dxnew) {
+        for (int p = 0; p < P; p++) {
+            const double* dM = (miss ? b.DA : b.DAKHA) + p * d * d;
+            for (int i = 0; i < d; i++) {
+                double a = 0.0, c2 = 0.0;
+                for (int k = 0; k < d; k++) { a += dM[i * d + k] * xs[k]; c2 += Mx[i * d + k] * dx[(l * P + p) * d + k]; }
+                double v = a + c2;
+                if (!miss) v += b.DK[p * d + i] * y;                     // ihgp.h:45 / :54
+                dxnew[(l * P + p) * d + i] = v;
+            }
+        }
+    }
+}
+
+__global__ void igp_nll_x_kernel(size_t L, int d, int P, const double* __restrict__ cb64, const double* __restrict__ cbd64,
+                                 const double* __restrict__ x, const double* __restrict__ yraw, const double* __restrict__ Ty,
+                                 const double* __restrict__ dx, double* __restrict__ lossv, double* __restrict__ pv, double* __restrict__ igrad) {
+    size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= L) return;
+    const XBlk b = xblk(cb64, dx ? cbd64 : nullptr, l, d, P);
+    const double* xl = x + l * d;
+    double hx = 0.0, hak = 0.0;
+    for (int i = 0; i < d; i++) { hx += b.HA[i] * xl[i]; hak += b.HA[i] * b.K[i]; }
+    const double v = Ty[l] - hx;
+    lossv[l] = 0.5 * (v * v / b.S + log(b.S));                           // ihgp.h:207
+    if (dx) {
+        pv[l] = (yraw[l] - hx) * (1 - hak) / b.S;                        // moihgp.h:510-511 (raw y(idx), sic)
+        for (int p = 0; p < P; p++) {
+            double a = 0.0, c2 = 0.0;
+            for (int i = 0; i < d; i++) { a += b.HDA[p * d + i] * xl[i]; c2 += b.HA[i] * dx[(l * P + p) * d + i]; }
+            const double dv = -a - c2;                                   // ihgp.h:218
+            igrad[l * P + p] = (v * dv - 0.5 * (v * v / b.S - 1) * b.DS[p]) / b.S;   // ihgp.h:219
+        }
+    } else pv[l] = 0.0;
+}
+
 // resid2[m] = (y - U U^T y)_m^2  (moihgp.h:501 / :651): one wave per output row.
 __global__ void __launch_bounds__(256) resid_kernel(size_t M, size_t L, const double* __restrict__ U,
                                                     const double* __restrict__ y, const double* __restrict__ Uty,
@@ -205,7 +280,7 @@ __device__ double block_sum(double v, double* red) {
 // loss and the S / sigma / per-latent gradient entries (moihgp.h:503, :553-563, :598-609): one workgroup.
 __device__ inline void nll_finalize_body(size_t M, size_t L, const double* __restrict__ S, double sigma, const double* Uty,
                                          const double* lossv, const double* pv, const double* igrad, const double* resid2,
-                                         double* __restrict__ loss, double* __restrict__ grad, double* red, bool add_latent_loss) {
+                                         double* __restrict__ loss, double* __restrict__ grad, double* red, bool add_latent_loss, int Pn = kNumIgpParam) {
     const int tid = threadIdx.x, nt = blockDim.x;
     double a = 0.0, b = 0.0, c = 0.0;
     for (size_t l = tid; l < L; l += nt) { a += S[l]; c += lossv[l]; }
@@ -223,12 +298,12 @@ __device__ inline void nll_finalize_body(size_t M, size_t L, const double* __res
     double gs = 0.0;
     for (size_t l = tid; l < L; l += nt) {
         const double Sl = S[l], sq = sqrt(Sl);
-        const double dn = igrad[l * P + (P - 1)];
+        const double dn = igrad[l * Pn + (Pn - 1)];
         double g = 0.5 / Sl + pv[l] * (-0.5 * (1.0 / sq / sq / sq) * Uty[l]);   // moihgp.h:555-561
         g -= dn * sigma / Sl / Sl;                                       // moihgp.h:604
         grad[sizeU + l] = g;
         gs += dn / Sl;                                                   // moihgp.h:605
-        for (int p = 0; p < P; p++) grad[sizeU + L + 1 + l * P + p] = igrad[l * P + p];   // moihgp.h:608-609
+        for (int p = 0; p < Pn; p++) grad[sizeU + L + 1 + l * Pn + p] = igrad[l * Pn + p];   // moihgp.h:608-609
     }
     const double gsum = block_sum(gs, red);
     if (tid == 0) grad[sizeU + L] = 0.5 * (m_n - nrm / sigma) / sigma + gsum;   // moihgp.h:563
@@ -238,9 +313,9 @@ __global__ void __launch_bounds__(256) nll_finalize_kernel(size_t M, size_t L, c
                                                            const double* __restrict__ sigma_p, const double* __restrict__ Uty,
                                                            const double* __restrict__ lossv, const double* __restrict__ pv,
                                                            const double* __restrict__ igrad, const double* __restrict__ resid2,
-                                                           double* __restrict__ loss, double* __restrict__ grad, int add_latent_loss) {
+                                                           double* __restrict__ loss, double* __restrict__ grad, int add_latent_loss, int Pn) {
     __shared__ double red[256];
-    nll_finalize_body(M, L, S, *sigma_p, Uty, lossv, pv, igrad, resid2, loss, grad, red, add_latent_loss != 0);
+    nll_finalize_body(M, L, S, *sigma_p, Uty, lossv, pv, igrad, resid2, loss, grad, red, add_latent_loss != 0, Pn);
 }
 
 // U-gradient (moihgp.h:538-552).  U is a polar factor (moihgp.h:438-446) so its singular values are
@@ -403,7 +478,9 @@ int launch_project_stream_missing(int dtype, const void* Y, size_t T, size_t M, 
 void launch_step_tick(const TickArgs& a, const double* x, const double* Ty, const double* dx, double* xnew,
                       double* Tyhat, double* dxnew, hipStream_t s) {
     dim3 grid(nblk(a.L, 64)), block(64);
-    if (a.d == 2)
+    if (a.d > 3)
+        hipLaunchKernelGGL(step_tick_x_kernel, grid, block, 0, s, a.L, a.d, a.P, a.cb64, a.cbd64, x, Ty, dx, xnew, Tyhat, dxnew);
+    else if (a.d == 2)
         hipLaunchKernelGGL(step_tick_kernel<2>, grid, block, 0, s, a.L, a.cb64, x, Ty, dx, xnew, Tyhat, dxnew);
     else
         hipLaunchKernelGGL(step_tick_kernel<3>, grid, block, 0, s, a.L, a.cb64, x, Ty, dx, xnew, Tyhat, dxnew);
@@ -564,15 +641,17 @@ void launch_nll_tick(const TickArgs& a, const double* x, const double* y, const 
     double* lossv = scratch;                 // [L]
     double* pv = lossv + a.L;                // [L]
     double* igrad = pv + a.L;                // [L][P]
-    double* resid2 = igrad + a.L * P;        // [M]
+    double* resid2 = igrad + a.L * a.P;      // [M]
     dim3 grid(nblk(a.L, 64)), block(64);
-    if (a.d == 2)
+    if (a.d > 3)
+        hipLaunchKernelGGL(igp_nll_x_kernel, grid, block, 0, s, a.L, a.d, a.P, a.cb64, a.cbd64, x, y, Ty, dx, lossv, pv, igrad);
+    else if (a.d == 2)
         hipLaunchKernelGGL(igp_nll_kernel<2>, grid, block, 0, s, a.L, a.cb64, x, y, Ty, dx, lossv, pv, igrad);
     else
         hipLaunchKernelGGL(igp_nll_kernel<3>, grid, block, 0, s, a.L, a.cb64, x, y, Ty, dx, lossv, pv, igrad);
     hipLaunchKernelGGL(resid_kernel, dim3(nblk(a.M, 4)), dim3(256), 0, s, a.M, a.L, a.U, y, Uty, resid2);
     hipLaunchKernelGGL(nll_finalize_kernel, dim3(1), dim3(256), 0, s, a.M, a.L, a.S, a.sigma, Uty, lossv, pv, igrad,
-                       resid2, loss, dx ? grad : nullptr, (!dx || a.lik1_latent_loss) ? 1 : 0);
+                       resid2, loss, dx ? grad : nullptr, (!dx || a.lik1_latent_loss) ? 1 : 0, a.P);
     if (dx && grad)
         hipLaunchKernelGGL(ugrad_kernel, dim3(nblk(a.M * a.L, 256)), dim3(256), 0, s, a.M, a.L, a.S, a.sigma, y, Uty, pv, grad);
     MOIHGP_HIP_FATAL(hipGetLastError());

@@ -46,6 +46,31 @@ __global__ void __launch_bounds__(256) window_z_kernel(size_t M, size_t L, size_
     if (lane == 0) spu[l] = acc;
 }
 
+// the same for a stacked kernel (run-time state dim; HA, K, S from the XC block)
+__global__ void __launch_bounds__(256) window_z_x_kernel(size_t M, size_t L, size_t W, size_t ldw, int d, const double* __restrict__ cb,
+                                                         const double* __restrict__ S, const double* __restrict__ sigma_p,
+                                                         const double* __restrict__ Y, const double* __restrict__ Ty,
+                                                         const double* __restrict__ hx, double* __restrict__ Z, double* __restrict__ spu) {
+    const int lane = threadIdx.x & 63;
+    const size_t l = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (l >= L) return;
+    const double* c = cb + l * (size_t)xc_size(d);
+    const double* Kp = c + d * d;
+    const double* HAp = Kp + d + d * d;
+    double hak = 0.0;
+    for (int i = 0; i < d; i++) hak += HAp[i] * Kp[i];
+    const double Sl = S[l], sq = sqrt(Sl), sigma = *sigma_p, f = (1 - hak) / HAp[d];
+    double acc = 0.0;
+    for (size_t t = lane; t < W; t += 64) {
+        const double pv = (Y[t * M + l] - hx[l * ldw + t]) * f;          // moihgp.h:510-511
+        const double uty = Ty[l * ldw + t] * sq;
+        Z[l * ldw + t] = pv * (1.0 / sq) - uty / sigma;
+        acc += pv * uty;
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) spu[l] = acc;
+}
+
 // one wave per tick: r_t = || y_t - U U^T y_t ||   (moihgp.h:501, un-squared norm)
 __global__ void __launch_bounds__(256) window_resid_kernel(size_t M, size_t W, const double* __restrict__ Y, const double* __restrict__ UU,
                                                            double* __restrict__ rt) {
@@ -75,12 +100,12 @@ __global__ void __launch_bounds__(256) window_finalize_kernel(size_t M, size_t L
                                                               const double* __restrict__ sigma_p, const double* __restrict__ rt,
                                                               const double* __restrict__ spu, const double* __restrict__ nll,
                                                               const double* __restrict__ gl, double* __restrict__ loss,
-                                                              double* __restrict__ grad, int add_latent_loss) {
+                                                              double* __restrict__ grad, int add_latent_loss, int Pn) {
     __shared__ double red[256];
     const int tid = threadIdx.x, nt = blockDim.x;
     const double sigma = *sigma_p;
     double a = 0.0, b = 0.0, c = 0.0, gs = 0.0;
-    for (size_t l = tid; l < L; l += nt) { a += S[l]; c += nll[l]; gs += gl[l * P + (P - 1)] / S[l]; }
+    for (size_t l = tid; l < L; l += nt) { a += S[l]; c += nll[l]; gs += gl[l * Pn + (Pn - 1)] / S[l]; }
     for (size_t t = tid; t < W; t += nt) b += rt[t];
     const double Ssum = wg_sum(a, red), rsum = wg_sum(b, red), lsum = wg_sum(c, red), gsum = wg_sum(gs, red);
     double m_n = (double)M - (double)L;
@@ -93,27 +118,30 @@ __global__ void __launch_bounds__(256) window_finalize_kernel(size_t M, size_t L
     }
     for (size_t l = tid; l < L; l += nt) {
         const double Sl = S[l], sq = sqrt(Sl);
-        grad[M * L + l] = Wd * 0.5 / Sl - 0.5 * (1.0 / sq / sq / sq) * spu[l] - gl[l * P + (P - 1)] * sigma / Sl / Sl;   // moihgp.h:555-561, :604
-        for (int p = 0; p < P; p++) grad[M * L + L + 1 + l * P + p] = gl[l * P + p];                          // moihgp.h:608-609
+        grad[M * L + l] = Wd * 0.5 / Sl - 0.5 * (1.0 / sq / sq / sq) * spu[l] - gl[l * Pn + (Pn - 1)] * sigma / Sl / Sl;   // moihgp.h:555-561, :604
+        for (int p = 0; p < Pn; p++) grad[M * L + L + 1 + l * Pn + p] = gl[l * Pn + p];                          // moihgp.h:608-609
     }
 }
 
 }  // namespace
 
 int launch_window_objective(const TickArgs& a, const double* cb64, const float* cb32, const WindowBufs& w, int* fallback, double* loss,
-                            double* grad, hipStream_t s) {
+                            double* grad, hipStream_t s, int kernel) {
     int rc;
     if ((rc = launch_project_stream(0, w.Y, w.W, a.M, a.L, a.U, nullptr, a.invsqrtS, w.Ty, w.ldw, s))) return rc;
-    if ((rc = launch_grad_stream(a.d, 0, w.Ty, w.W, w.ldw, a.L, cb64, cb32, w.x, w.dx, w.hx, w.nll, w.gl, fallback, s, /*out_mode=*/2))) return rc;
+    if (a.d > 3) { if ((rc = launch_grad_stream_x(kernel, 0, w.Ty, w.W, w.ldw, a.L, cb64, a.cbd64, w.x, w.dx, w.hx, w.nll, w.gl, s, /*out_mode=*/2))) return rc; }
+    else if ((rc = launch_grad_stream(a.d, 0, w.Ty, w.W, w.ldw, a.L, cb64, cb32, w.x, w.dx, w.hx, w.nll, w.gl, fallback, s, /*out_mode=*/2))) return rc;
     dim3 b256(256);
-    if (a.d == 2)
+    if (a.d > 3)
+        hipLaunchKernelGGL(window_z_x_kernel, dim3((unsigned)((a.L + 3) / 4)), b256, 0, s, a.M, a.L, w.W, w.ldw, a.d, cb64, a.S, a.sigma, w.Y, w.Ty, w.hx, w.Z, w.spu);
+    else if (a.d == 2)
         hipLaunchKernelGGL(window_z_kernel<2>, dim3((unsigned)((a.L + 3) / 4)), b256, 0, s, a.M, a.L, w.W, w.ldw, cb64, a.S, a.sigma, w.Y, w.Ty, w.hx, w.Z, w.spu);
     else
         hipLaunchKernelGGL(window_z_kernel<3>, dim3((unsigned)((a.L + 3) / 4)), b256, 0, s, a.M, a.L, w.W, w.ldw, cb64, a.S, a.sigma, w.Y, w.Ty, w.hx, w.Z, w.spu);
     if ((rc = launch_ugrad_gemm(w.Y, w.W, a.M, w.Z, w.ldw, a.L, grad, s))) return rc;                         // grad[0 .. M*L) = U-gradient
     if ((rc = launch_unproject_stream(0, w.Ty, w.W, w.ldw, a.M, a.L, a.U, nullptr, a.sqrtS, w.UU, s))) return rc;           // U (U^T y_t)
     hipLaunchKernelGGL(window_resid_kernel, dim3((unsigned)((w.W + 3) / 4)), b256, 0, s, a.M, w.W, w.Y, w.UU, w.rt);
-    hipLaunchKernelGGL(window_finalize_kernel, dim3(1), b256, 0, s, a.M, a.L, w.W, a.S, a.sigma, w.rt, w.spu, w.nll, w.gl, loss, grad, a.lik1_latent_loss);
+    hipLaunchKernelGGL(window_finalize_kernel, dim3(1), b256, 0, s, a.M, a.L, w.W, a.S, a.sigma, w.rt, w.spu, w.nll, w.gl, loss, grad, a.lik1_latent_loss, a.P);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_last_error("window objective launch: %s", hipGetErrorString(e)); return 2; }
     return 0;

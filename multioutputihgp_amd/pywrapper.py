@@ -23,6 +23,10 @@ import numpy as np
 from ._lib import MoihgpError, c_double_p, last_error, load_library
 
 
+# stacked kernels (sum of J Matern components behind one output; not models of the reference): "<base>x<J>"
+_STACKED = {"%sx%d" % (b, j): (i | (j << 4)) for i, b in enumerate(("Matern32", "Matern52")) for j in (2, 3, 4)}
+
+
 class MOIHGP(object):
 
     def __init__(self, dt, num_output, num_latent, kernel="Matern32", threading=False):
@@ -40,6 +44,11 @@ class MOIHGP(object):
         elif kernel == "Matern52ss":
             pfx = "gp52"     # same entry points; object built with the true Matern-5/2 state space
             self.__obj = lib.moihgp_new(1, c_double(dt), c_size_t(num_output), c_size_t(num_latent))
+            if self.__obj:
+                lib.moihgp_set_threading(self.__obj, int(bool(threading)))
+        elif kernel in _STACKED:
+            pfx = "gp32"     # the entry points dispatch on the handle; the object carries the stacked state space (include/moihgp.h MOIHGP_STACK)
+            self.__obj = lib.moihgp_new(_STACKED[kernel], c_double(dt), c_size_t(num_output), c_size_t(num_latent))
             if self.__obj:
                 lib.moihgp_set_threading(self.__obj, int(bool(threading)))
         else:
@@ -181,6 +190,8 @@ class MOIHGP(object):
     @property
     def covariance(self):
         """pywrapper.py:256-270."""
+        if self.num_igp_param != 3:
+            raise NotImplementedError("covariance: the reference's formula (pywrapper.py:256-270) is written for its 3-parameter Matern models")
         params = self.params.copy()
         M, L = self.num_output, self.num_latent
         U = np.reshape(params[:M * L], (M, L))

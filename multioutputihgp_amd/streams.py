@@ -82,7 +82,7 @@ class LatentBank:
         self.d = gp.igp_dim
         self.P = gp.num_igp_param
         self.kernel = None
-        self.stacked = False
+        self.stacked = gp.igp_dim > 3
         self.device = torch.device("cuda", torch.cuda.current_device())
         return self
 

@@ -217,7 +217,7 @@ class GP:
     """Mirror of the reference ctypes class (pywrapper.py:10-270) over the C oracle."""
 
     def __init__(self, dt, num_output, num_latent, kernel="Matern32", threading=False):
-        self._L = lib()
+        self._L = lib(wide=is_wide(kernel))           # stacked kernels need the wide build
         self.M, self.L = num_output, num_latent
         # `threading` (pywrapper.py:12, moihgp.h:81,128-135) changes the VALUE negLogLikelihood(x, y, dx) returns: moihgp.h:590 vs :597-607
         self._h = self._L.orc_gp_new_t(KERNEL_ID[kernel], float(dt), num_output, num_latent, int(bool(threading)))

@@ -480,7 +480,12 @@ orc_gp* orc_gp_new(int kernel, double dt, size_t M, size_t L) {
     orc_gp* gp = (orc_gp*)calloc(1, sizeof(orc_gp));
     gp->kernel = kernel; gp->dt = dt; gp->M = M; gp->L = L;
     gp->igp = (orc_ihgp*)calloc(L, sizeof(orc_ihgp));
-    const double def[3] = {1.0, 1.0, 0.1};                            /* matern32ss.h:34-36 */
+    double def[ORC_PMAX > 3 ? ORC_PMAX : 3] = {1.0, 1.0, 0.1};        /* matern32ss.h:34-36 */
+    if (kernel >> 4) {                                                /* stacked: (magnitude 1, lengthscale j + 1) per component, noise 0.1 */
+        int J = kernel >> 4;
+        for (int j = 0; j < J && 2 * j + 1 < (int)(sizeof(def) / sizeof(def[0])); j++) { def[2 * j] = 1.0; def[2 * j + 1] = (double)(j + 1); }
+        if (2 * J < (int)(sizeof(def) / sizeof(def[0]))) def[2 * J] = 0.1;
+    }
     for (size_t l = 0; l < L; l++) orc_ihgp_update(&gp->igp[l], kernel, dt, def);   /* moihgp.h:86-90 */
     gp->d = gp->igp[0].d; gp->P = gp->igp[0].P;
     gp->num_param = M * L + L + 1 + L * gp->P;                        /* :93 */

@@ -790,10 +790,64 @@ def test_stacked_missing_data_and_slabs(env, kern):
     assert rel_err((na + nb).cpu().numpy(), o["nll_per_latent"]) < FP64_TIGHT and rel_err(xb.cpu().numpy(), o["x"]) < FP64_TIGHT
 
 
-def test_stacked_full_objects_are_refused(env):
-    # a full MOIHGP object (mixing + per-tick ABI + gradients) with a stacked kernel is refused, with a message
-    assert not env["lib"].moihgp_new(1 | (2 << 4), 0.1, 4, 2)
-    assert b"stacked" in env["lib"].moihgp_last_error()
+@pytest.mark.parametrize("kern,M,L", [("Matern32x2", 6, 3), ("Matern52x2", 8, 8), ("Matern52x4", 9, 4), ("Matern52x3", 150, 70)])
+def test_stacked_full_objects_vs_oracle(env, kern, M, L):
+    """BASELINE.json's d = 6 / d = 12 configurations behind the whole MOIHGP surface: a stacked StateSpace in the template slot of
+    moihgp::MOIHGP<SS> (moihgp.h:76): update / getParams with P = 2J + 1 per-latent parameters, the four step overloads, both
+    negLogLikelihood overloads (gradient incl. the per-latent block), missing outputs, and the windowed objective."""
+    rng = np.random.default_rng(M * 31 + L)
+    J = int(kern[-1]); P = 2 * J + 1
+    gp = env["MOIHGP"](0.1, M, L, kernel=kern)
+    ref = env["cref"].GP(0.1, M, L, kern); ref.set_literal_ugrad(0)
+    d = gp.igp_dim
+    assert d == (2 if kern.startswith("Matern32") else 3) * J and gp.num_igp_param == P and gp.num_param == M * L + L + 1 + L * P
+    assert ref.igp_dim == d and ref.num_igp_param == P
+    assert rel_err(gp.params[M * L:], ref.params[M * L:]) < 1e-15        # constructor state: S = 1, sigma = 1e-2, default per-latent parameters
+    igp = synth_params_stacked(L, J, rng)
+    params = np.concatenate([(np.eye(M, L) + 0.2 * rng.standard_normal((M, L))).ravel(), rng.uniform(0.5, 2, L), [0.04], igp.ravel()])
+    gp.update(params); ref.update(params)
+    assert rel_err(gp.params, ref.params) < FP64_TIGHT
+    x, dx = 0.3 * rng.standard_normal((L, d)), 0.1 * rng.standard_normal((L, P, d))
+    for it in range(3):
+        y = rng.standard_normal(M)
+        l2a, l2b = gp.negLogLikelihood(x, y), ref.negLogLikelihood(x, y)
+        assert abs(l2a - l2b) < FP64_TIGHT * max(1.0, abs(l2b))
+        l1a, g1a = gp.negLogLikelihood(x, y, dx); l1b, g1b = ref.negLogLikelihood(x, y, dx)
+        assert abs(l1a - l1b) < FP64_TIGHT * max(1.0, abs(l1b)) and rel_err(g1a, g1b) < 1e-8
+        a3, b3 = gp.step(x, y), ref.step(x, y)
+        a4, b4 = gp.step(x), ref.step(x)
+        a2, b2 = gp.step_no_yhat(x, y, dx), ref.step2(x, y, dx)
+        a1, b1 = gp.step(x, y, dx), ref.step(x, y, dx)
+        for u, v in list(zip(a3, b3)) + list(zip(a4, b4)) + list(zip(a2, b2)) + list(zip(a1, b1)):
+            assert rel_err(u, v) < FP64_TIGHT
+        x, dx = a1[0], a1[2]
+    if M > L:                                                   # least-squares projection over the observed rows (moihgp.h:167-178)
+        ym = rng.standard_normal(M); ym[rng.choice(M, size=max(1, (M - L) // 2), replace=False)] = np.nan
+        a, b = gp.step(x, ym), ref.step(x, ym)
+        assert rel_err(a[0], b[0]) < FP64_TIGHT and rel_err(a[1], b[1]) < FP64_TIGHT
+    # the learners' window loop as one device call
+    W = 7
+    Y = 0.5 * rng.standard_normal((W, M))
+    loss, grad, xT, dxT = gp.window_objective(Y, x, dx)
+    xr, dxr, lref, gref = x, dx, 0.0, np.zeros(gp.num_param)
+    for t in range(W):
+        l1, g1 = ref.negLogLikelihood(xr, Y[t], dxr)
+        xr, _, dxr = ref.step(xr, Y[t], dxr)
+        lref += l1; gref += g1
+    assert abs(loss - lref) < 1e-9 * max(1.0, abs(lref)) and rel_err(grad, gref) < 1e-8
+    assert rel_err(xT, xr) < 1e-9 and rel_err(dxT, dxr) < 1e-8
+    # whole streams through the same object: project -> stacked filter -> unproject == the tick loop
+    T = 50
+    Ys = rng.standard_normal((T, M))
+    Ty = env["streams"].project_stream(gp, torch.from_numpy(Ys).cuda())
+    bank = env["streams"].LatentBank.from_handle(gp)
+    yl, _, _ = bank.filter(Ty, T=T)
+    Yhat = env["streams"].unproject_stream(gp, yl, T)
+    torch.cuda.synchronize()
+    xr = np.zeros((L, d)); out = np.empty((T, M))
+    for t in range(T):
+        xr, out[t] = ref.step(xr, Ys[t])
+    assert rel_err(Yhat.cpu().numpy(), out) < 1e-9
 
 
 @pytest.mark.parametrize("kern,dtype,L,T", [("Matern52x2", torch.float64, 256, 10000), ("Matern52x4", torch.float64, 4096, 10000),
