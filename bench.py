@@ -272,6 +272,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS) + ["c1", "c3learn"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / parity leg")
+    ap.add_argument("--no-cold", action="store_true", help="skip the cold-stream leg (roofline.frac_cold): profiled runs, so that a kernel trace holds the timed launches only")
     ap.add_argument("--sync-allreduce", action="store_true", help="N > 1: make every pass wait for its own NLL all-reduce (no overlap with the next sweep)")
     args = ap.parse_args()
 
@@ -403,7 +404,7 @@ def main():
                          "vector_alu": valu_side(bank.d, dtype, L * min(slab, T) / (kern_ms * 1e-3))},
             "nll_total": float(total.item()),
         }
-        if world == 1 and nslab == 1:
+        if world == 1 and nslab == 1 and not args.no_cold:
             # Cold-stream figure: the timed passes above sweep ONE resident stream, so between passes part of its input is served by the
             # 256 MiB Infinity Cache (and FETCH_SIZE counts those hits): roofline.frac is cache-assisted whenever the input fits.  Here the
             # same launch rotates over enough distinct (input, output) pairs that nothing it reads can still be on chip.

@@ -11,7 +11,7 @@ for c in c3 c2 c3f64 c2d6 c5 c4 c1 c3learn; do
   echo "bench $c done"
 done
 for c in c3 c5 c2 c2d6; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_$c/kt" -o out -- python3 bench.py --config $c --steps 50 --warmup 5 --no-cpu > "$out/${tag}_${c}_bench_under_rocprof.json" 2> "$out/prof_$c.err"
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_$c/kt" -o out -- python3 bench.py --config $c --steps 50 --warmup 5 --no-cpu --no-cold > "$out/${tag}_${c}_bench_under_rocprof.json" 2> "$out/prof_$c.err"
   python3 profiles/summarize.py "$out/prof_$c" "$out" "${tag}_$c" $([ $c = c5 -o $c = c2d6 ] && echo filter_x_kernel || echo filter_scan_kernel) > /dev/null
   echo "rocprof $c done"
 done

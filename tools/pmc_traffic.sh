@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 mkdir -p "$out"
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$out/pmc_$c" -o out -- python3 bench.py --config $cfg --steps 5 --warmup 1 --no-cpu > /dev/null 2> "$out/pmc_$c.err"
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$out/pmc_$c" -o out -- python3 bench.py --config $cfg --steps 5 --warmup 1 --no-cpu --no-cold > /dev/null 2> "$out/pmc_$c.err"
 done
 python3 - "$out" <<'PY'
 import csv, glob, json, sys
