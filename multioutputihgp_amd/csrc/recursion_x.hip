@@ -226,8 +226,15 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
     if (SPLIT) {
         const bool split_ok = scan_ok && nlev <= 5;                  // M^(2^nlev) is in the table and negligible
         if (split_ok) {
-            t_begin = (size_t)slice * segs_per_slice * SEG;
-            t_end = t_begin + (size_t)segs_per_slice * SEG < Tlen ? t_begin + (size_t)segs_per_slice * SEG : Tlen;
+            // Slice 0 owns its segs_per_slice whole segments; a later slice owns that many ticks MINUS its warm-up, so that warm-up + own
+            // ticks are exactly segs_per_slice segment passes (a slice that owned whole segments and started its warm-up in the segment
+            // before them paid one more pass, 64 lanes wide, for a few hundred warm-up ticks: two passes instead of one at one segment
+            // per slice).  The warm-up length is this latent's own (nlev), so the slices of different latents differ; the grid holds
+            // enough slices for the longest warm-up, the surplus ones of a fast-decaying latent find nothing to do.
+            const size_t span = (size_t)segs_per_slice * SEG, own = span - ((size_t)CK << nlev);
+            t_begin = slice == 0 ? 0 : span + (size_t)(slice - 1) * own;
+            const size_t stop = slice == 0 ? span : t_begin + own;
+            t_end = stop < Tlen ? stop : Tlen;
         }
         if ((!split_ok && slice > 0) || t_begin >= t_end) {          // nothing to do for this slice
             if (NLL && lane == 0) nll_part[l * nslice + slice] = 0.0;
@@ -434,7 +441,15 @@ int launch_xd(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, co
     if (want > nseg) want = nseg;
     if (want * L > scratch_len) want = scratch_len / L;
     if (want < 1) want = 1;                                            // (one slice = the whole stream: same kernel)
-    const size_t per = nseg ? (nseg + want - 1) / want : 1, n = nseg ? (nseg + per - 1) / per : 1;
+    const size_t per = nseg ? (nseg + want - 1) / want : 1;
+    // slices after the first own per * SEG ticks minus their warm-up (at most CK * 32 ticks: filter_x_kernel): enough of them for the
+    // longest warm-up, within the scratch the caller provided
+    size_t n = 1;
+    if (Tlen > per * SEG) {
+        const size_t own_min = per * SEG - (size_t)kChunkX * 32;
+        n = 1 + (Tlen - per * SEG + own_min - 1) / own_min;
+    }
+    if (n * L > scratch_len) return launch_x<T, DB, J, 1, true>(Ty, Tlen, ld, L, cbT, cb64, xin, x, yhat, nll, stream, ev0, ev1, 1, (int)nseg, scratch, ldo);
     return launch_x<T, DB, J, 1, true>(Ty, Tlen, ld, L, cbT, cb64, xin, x, yhat, nll, stream, ev0, ev1, (int)n, (int)per, scratch, ldo);
 }
 
