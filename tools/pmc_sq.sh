@@ -8,7 +8,7 @@ mkdir -p "$out"
 i=0
 for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_VMEM SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_SALU"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$out/g$i" -o out -- python3 bench.py --config $cfg --steps 3 --warmup 1 --no-cpu > /dev/null 2> "$out/g$i.err"
+  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$out/g$i" -o out -- python3 bench.py --config $cfg --steps 3 --warmup 1 --no-cpu --no-cold > /dev/null 2> "$out/g$i.err"
 done
 python3 - "$out" <<'PY'
 import csv, glob, json, sys, collections
