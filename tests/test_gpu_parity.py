@@ -977,6 +977,40 @@ def test_filter_fuzz_vs_oracle(env, kern, L, T, nanf, dt_, seed):
         assert np.abs(nll.cpu().numpy()[ntame] - o["nll_per_latent"][ntame]).max() / nscale < tol * 10
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("kern", ["Matern32", "Matern52"])
+@pytest.mark.parametrize("T,gaps", [(2600, [0]), (2600, [1300]), (2600, [2599]), (2600, [511, 512, 1023, 1024]), (3072, [100, 2000, 3071]),
+                                    (4100, list(range(1030, 1100))), (1500, [7, 1400]), (5000, "dense")])
+def test_gradstream_gaps_in_chosen_segments(env, dtype, kern, T, gaps):
+    """Long streams (several 512- / 1024-tick segments) with missing ticks at chosen places: the second pass of the gradient sweep
+    walks only the segments that hold a gap tick by tick (ihgp.h:37-48) and scans the others, so the carried (x, dx), the split
+    gradient sums and the means written from either path must join: first tick, last tick, both sides of a segment boundary, a run
+    of gaps, the ragged tail, a gap in every segment.  Latent 0 stays clean (first pass only), latent 1 has every tick missing."""
+    L = 5
+    rng = np.random.default_rng(T * 3 + (1 if kern == "Matern52" else 0) + (len(gaps) if gaps != "dense" else 99))
+    prm = synth_params(L, rng)
+    bank = env["streams"].LatentBank(0.1, prm, kernel=KMAP[kern])
+    d = bank.d
+    Ty = synth(L, T, rng)
+    if gaps == "dense":
+        Ty[2:, ::97] = np.nan
+    else:
+        Ty[2:, gaps] = np.nan
+    Ty[1, :] = np.nan
+    x0 = 0.2 * rng.standard_normal((L, d)); dx0 = 0.05 * rng.standard_normal((L, 3, d))
+    o = env["cref"].grad_stream(env["cref"].ihgp_array(kern, 0.1, prm), Ty, x0=x0, dx0=dx0)
+    tol = 1e-9 if dtype == torch.float64 else FP32_TOL
+    for want in (True, False):
+        r = bank.grad(to_dev(Ty, dtype), T=T, x=torch.from_numpy(x0).to(dtype).cuda(), dx=torch.from_numpy(dx0).to(dtype).cuda(), want_yhat=want)
+        torch.cuda.synchronize()
+        if want:
+            assert rel_err_rows(r["yhat"][:, :T].cpu().numpy(), o["yhat"]) < tol
+        assert rel_err(r["x"].cpu().numpy(), o["x"]) < tol and rel_err(r["dx"].cpu().numpy(), o["dx"]) < tol * 10
+        assert rel_err(r["nll"].cpu().numpy(), o["nll_per_latent"]) < tol
+        assert rel_err(r["grad"].cpu().numpy(), o["grad"]) < tol * 10
+    assert float(r["nll"][1]) == 0.0 and float(r["grad"][1].abs().max()) == 0.0      # nothing observed: no loss, no gradient
+
+
 def _grad_fuzz_cases(n, seed):
     rng = np.random.default_rng(seed)
     out = []
