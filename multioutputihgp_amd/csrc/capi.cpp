@@ -735,7 +735,7 @@ static int grad_stream_impl(moihgp_gp* gp, int dtype, const void* Ty, size_t T, 
     ensure_sensitivities(gp);
     note_user_stream(gp, (hipStream_t)stream);
     if (kernel_stack(gp->kernel))
-        return launch_grad_stream_x(gp->kernel, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cbd64, x, dx, yhat, nll, grad, (hipStream_t)stream);
+        return launch_grad_stream_x(gp->kernel, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cbd64, x, dx, yhat, nll, grad, (hipStream_t)stream, 1, gp->dfallback);
     return launch_grad_stream(gp->d, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cb32, x, dx, yhat, nll, grad, gp->dfallback, (hipStream_t)stream);
 }
 

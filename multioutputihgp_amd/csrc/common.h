@@ -130,7 +130,12 @@ int launch_filter_stream_x(int kernel, int dtype, const void* Ty, size_t T, size
 // grad_x.hip: sensitivity / gradient sweep of the stacked models (needs the XD blocks).
 int launch_grad_stream_x(int kernel, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* cb64, const double* cbd64,
                          void* x, void* dx, void* yhat, double* nll, double* grad, hipStream_t stream,
-                         int out_mode = 1 /* 1: yhat holds filtered means, 2: predicted means HA x_t (pre-step state) */);
+                         int out_mode = 1 /* 1: yhat holds filtered means, 2: predicted means HA x_t (pre-step state) */,
+                         int* flags = nullptr /* device [L] scratch: with it (and nll), streams of >= 512 ticks take the time-parallel sweep */);
+// grad_scan_x.hip: the same sweep parallel in time over the stream's whole 32-tick chunks [0, Tpar); flags[l] = 1 marks latents left
+// untouched (missing ticks, unusable scan tables), for the others (x, dx, nll, grad) hold the state after / sums over those ticks.
+int launch_grad_scan_x(int kernel, int dtype, const void* Ty, size_t Tpar, size_t ld, size_t L, const double* cb64, const double* cbd64,
+                       void* x, void* dx, void* yhat, double* nll, double* grad, int* flags, hipStream_t stream, int out_mode);
 
 // recursion.hip: batched sweeps over series-major streams.
 int launch_filter_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, size_t L,

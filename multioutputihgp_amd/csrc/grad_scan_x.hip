@@ -1,0 +1,415 @@
+// grad_scan_x.hip -- the sensitivity / gradient sweep (ihgp.h:37-57 with :212-222, A2 + A5) for STACKED models over LONG
+// streams, parallel in time.  (grad_x.hip walks a stream tick by tick, every matrix operand through LDS: right for the learners'
+// windows, 96 ms for 4096 latents x 10^4 ticks at D = 12.)
+//
+// Mapping as in recursion_x.hip: one wavefront owns one latent, a segment is 64 lanes x 32 ticks, lane j owns chunk j;
+// wave-uniform tables are "slabs" read through DPP row broadcasts, the diagonal blocks of A sit in SGPRs.  What makes the sweep
+// affordable is the INNOVATION FORM of the sensitivity recursion.  With v = y - HA x (ihgp.h:206) the step ihgp.h:50 is
+// x' = A x + K v, and differentiating that instead of x' = AKHA x + K y gives
+//     dv_p  = -(H dA_p) x - HA dx_p                                    (ihgp.h:218)
+//     dx_p' = A dx_p + dA_p x + dK_p v + K dv_p                        (== dAKHA_p x + AKHA dx_p + dK_p y, ihgp.h:54)
+// in which A is block diagonal (J blocks of DB x DB: a stacked model is a sum of independent components) and dA_p is ONE such
+// block (p a lengthscale) or zero: about 8 D + 2 D DB multiply-adds per tick and parameter instead of the 2 D^2 + 3 D of the
+// dense form (D = 12: 170 against 324).
+//
+// Per segment (all arithmetic fp64, whatever the stream's type):
+//   1. z_j = sum_k g_k y_k, 64-lane scan with the powers of M = AKHA^32  ->  start state x_j of every chunk       (as the filter)
+//   2. replay x over the chunk: v_k, sum v^2; v replaces y in the LDS tile (everything below needs v, not y)
+//   3. r_j = sum_k v_k (HA AKHA^k)^T: what a START sensitivity of the chunk contributes to sum_k v_k HA dx(k), per unit
+//   4. for every parameter p: replay (x, dz) from dz = 0 -- dz is the chunk-LOCAL sensitivity, forced by dA_p x + dK_p v and fed
+//      back through K dv -- collecting s = sum_k v_k dv_k(local); the chunk-end dz are scanned with the SAME powers of M (the
+//      homogeneous part of the recursion is AKHA, whatever p) to the true start sensitivity dx_j of every chunk, and by
+//      linearity  sum_k v_k dv_k = s - r_j . dx_j.  No table of d(AKHA^n)/dp is needed anywhere.
+//   5. (streams of means wanted) one more replay of x writes them into the tile.
+// The kernel takes the stream's whole chunks; the last T mod 32 ticks, and whole latents whose stream holds missing ticks or
+// whose scan tables are unusable (SCANOK == 0), are left to grad_x_kernel (flags[l] = 1), which continues from the carried
+// (x, dx) and adds to nll / grad.
+//
+// Cost: about (60 + 170 P) D/12 multiply-adds per tick in the replays, 10 scans of <= 6 levels x D^2 per 32 ticks, 2 D per tick in
+// the two response sums: VALU-bound, 16 B/tick of traffic at most.  DESIGN.md 3.8.
+#include "x_common.h"
+
+namespace moihgp {
+namespace {
+
+constexpr int kGxWaves = 2;                                           // wavefronts per workgroup (LDS: 20.5 KB each)
+
+template <int D> struct GxLds {
+    static constexpr int CK = kChunkX, STRIDE = CK + 2;
+    static constexpr int HPN = (CK * D + 15) / 16 * 16;
+    double tile[64 * STRIDE];        // the segment, chunk per lane row, padded
+    double hp[HPN];                  // HA AKHA^k, [k][i]: slab table of step 3
+    double dcarry[9 * D];            // carried sensitivities dx_p between segments
+    double gacc[9];                  // sum over the stream of v dv_p
+};
+
+// z += sum_k tab[k][.] tile_lane[k]: the chunk response to a slab table [CK][D] (16-aligned, global or LDS)
+template <int D, typename Ptr>
+__device__ inline void chunk_response(Ptr tab, const double* tile_lane, int lane, double (&z)[D], bool& bad) {
+    constexpr int CK = kChunkX, NSG = (CK * D + 15) / 16, NSG0 = NSG / 2, NSG1 = NSG - NSG0;
+    double g0[NSG0], g1[NSG1];
+    load_slabs<double, NSG0>(tab, lane, g0);
+    load_slabs<double, NSG1>(tab + NSG0 * 16, lane, g1);
+    static_for<CK / 2>([&](auto kvv) {
+        constexpr int kv = decltype(kvv)::value;
+        double yv[2];
+        unpack<double>(*reinterpret_cast<const double2*>(tile_lane + kv * 2), yv);
+        static_for<2>([&](auto qq) {
+            constexpr int k = kv * 2 + decltype(qq)::value;
+            bad = bad || (yv[decltype(qq)::value] != yv[decltype(qq)::value]);
+            static_for<D>([&](auto ii) {
+                constexpr int e = k * D + decltype(ii)::value, sl = e / 16;
+                if constexpr (sl < NSG0) fmac_bc<e % 16>(z[decltype(ii)::value], g0[sl], yv[decltype(qq)::value]);
+                else fmac_bc<e % 16>(z[decltype(ii)::value], g1[sl - NSG0], yv[decltype(qq)::value]);
+            });
+        });
+        if constexpr (kv % 8 == 7) __builtin_amdgcn_sched_barrier(0);   // keep the LDS reads of the chunk from piling up in registers
+    });
+}
+
+// TS: the stream's type.  WRITE: 0 none, 1 filtered means (ihgp.h:51), 2 predicted means HA x_t.
+template <typename TS, int DB, int J, int WRITE>
+__global__ void __launch_bounds__(64 * kGxWaves)
+grad_scan_x_kernel(const TS* __restrict__ Ty, size_t Tpar /* whole chunks */, size_t ld, size_t L, const double* __restrict__ cb64,
+                   const double* __restrict__ cbd64, TS* __restrict__ x, TS* __restrict__ dx, TS* __restrict__ yhat, double* __restrict__ nll,
+                   double* __restrict__ grad, int* __restrict__ flags) {
+    constexpr int D = DB * J, P = 2 * J + 1, CK = kChunkX, SEG = 64 * CK, STRIDE = GxLds<D>::STRIDE;
+    constexpr int EPV = 16 / (int)sizeof(TS);
+    using VS = typename VecOf<TS>::type;
+    using Lc = XC<D>;
+    using Ld = XD<D, P>;
+    constexpr int NSL = Lc::LS / 16, NAB = J * DB * DB, NSA = (NAB + 15) / 16;
+    static_assert(P <= 9 && D <= 16, "table sizes");
+    __shared__ __attribute__((aligned(16))) GxLds<D> lds_all[kGxWaves];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t l = (size_t)blockIdx.x * kGxWaves + wave;
+    if (l >= L) return;                                              // no workgroup barrier below
+    GxLds<D>& sm = lds_all[wave];
+    const double* __restrict__ c = cb64 + l * Lc::SIZE;
+    const double* __restrict__ cd = cbd64 + l * Ld::SIZE;
+    double* tile_lane = sm.tile + lane * STRIDE;
+    const TS* row = Ty + l * ld;
+    TS* orow = WRITE ? yhat + l * ld : nullptr;
+    const bool scan_ok = __builtin_amdgcn_readfirstlane((int)(c[Lc::SCANOK] != 0.0)) != 0;
+    if (!scan_ok) {
+        if (lane == 0) flags[l] = 1;
+        return;
+    }
+    const int nlev = __builtin_amdgcn_readfirstlane((int)c[Lc::NLEV]);
+
+    // ---- once per latent: hp_k = HA AKHA^k, k < CK (lane j < D holds column j of AKHA and entry j of the running row) ----
+    {
+        double col[D], h = 0.0;
+        const int jc = lane < D ? lane : 0;
+#pragma unroll
+        for (int i = 0; i < D; i++) col[i] = c[Lc::AKHA + i * D + jc];
+        h = c[Lc::HA + jc];
+        for (int e = lane; e < GxLds<D>::HPN; e += 64) sm.hp[e] = 0.0;
+        wave_lds_fence();
+#pragma unroll 1
+        for (int k = 0; k < CK; k++) {
+            if (lane < D) sm.hp[k * D + lane] = h;
+            double hn = 0.0;
+#pragma unroll
+            for (int i = 0; i < D; i++) hn = fma(read_lane(h, i), col[i], hn);
+            h = hn;
+        }
+        for (int e = lane; e < P * D; e += 64) sm.dcarry[e] = (double)dx[l * P * D + e];
+        if (lane < P) sm.gacc[lane] = 0.0;
+        wave_lds_fence();
+    }
+
+    double xc[D];                                                    // carried state between segments
+#pragma unroll
+    for (int i = 0; i < D; i++) xc[i] = (double)x[l * D + i];
+    double acc = 0.0;                                                // per lane: sum of v^2
+    const double ha = c[Lc::HA16 + (lane & 15)], kk = c[Lc::K16 + (lane & 15)];
+
+    for (size_t t0 = 0; t0 < Tpar; t0 += SEG) {
+        const int n = (int)(Tpar - t0 < (size_t)SEG ? Tpar - t0 : (size_t)SEG);    // a multiple of CK
+        const int nc = n / CK;                                       // chunks (= lanes) in use
+        const bool mine = lane < nc;
+        const uptr<double> cu = launder(c);
+        // ---- stage in: coalesced 16-byte loads, chunk-major into the padded tile, zeros past the end ----
+#pragma unroll
+        for (int r = 0; r < CK / EPV; r++) {
+            const int e = (r * 64 + lane) * EPV;
+            TS vals[EPV];
+#pragma unroll
+            for (int q = 0; q < EPV; q++) vals[q] = TS(0);
+            if (e < n) unpack<TS>(nt_load(reinterpret_cast<const VS*>(row + t0 + e)), vals);
+            double* dst = sm.tile + (e / CK) * STRIDE + (e % CK);
+#pragma unroll
+            for (int q = 0; q < EPV; q += 2) *reinterpret_cast<double2*>(dst + q) = make_double2((double)vals[q], (double)vals[q + 1]);
+        }
+        double ablk[NAB];
+#pragma unroll
+        for (int i = 0; i < NAB; i++) ablk[i] = cu[Lc::AB + i];
+        wave_lds_fence();
+
+        double xs[D], rr[D];                                          // start state of the lane's chunk; r of step 3
+        // it = 0: the state itself (steps 1-3); it = p + 1: parameter p (step 4).  One loop so that the scan is instantiated once.
+#pragma unroll 1
+        for (int it = 0; it <= P; it++) {
+            const int p = it > 0 ? it - 1 : 0;
+            double z[D], s = 0.0;
+#pragma unroll
+            for (int i = 0; i < D; i++) z[i] = 0.0;
+            if (it == 0) {
+                bool bad = false;
+                chunk_response<D>(cu + Lc::G, tile_lane, lane, z, bad);
+                if (__builtin_amdgcn_ballot_w64(bad) != 0) {          // missing ticks: the whole latent goes to the tick-by-tick kernel
+                    if (lane == 0) flags[l] = 1;
+                    return;
+                }
+            } else {
+                // ---- step 4: replay (x, dz_p) over the chunk from dz = 0 ----
+                double dab[NSA], dkp, hdap;
+                {
+                    // the diagonal blocks of dA_p, packed like AB: entry e = (j, r, q) -> DA_p[(j DB + r) D + j DB + q]
+#pragma unroll
+                    for (int sidx = 0; sidx < NSA; sidx++) {
+                        const int e = sidx * 16 + (lane & 15);
+                        const int jb = e / (DB * DB), rq = e % (DB * DB);
+                        const int src = e < NAB ? (jb * DB + rq / DB) * D + jb * DB + rq % DB : 0;
+                        dab[sidx] = cd[Ld::DA + p * D * D + src];      // (entries past NAB are never broadcast; slabs must come
+                    }                                                  //  straight from a load: no VALU write ahead of a DPP read)
+                    const int i16 = (lane & 15) < D ? (lane & 15) : 0;
+                    dkp = cd[Ld::DK + p * D + i16];
+                    hdap = cd[Ld::HDA + p * D + i16];
+                }
+                double xr[D];
+#pragma unroll
+                for (int i = 0; i < D; i++) xr[i] = xs[i];
+#pragma unroll 1
+                for (int k = 0; k < CK; k++) {
+                    const double v = tile_lane[k];
+                    double d0 = 0.0, d1 = 0.0, d2 = 0.0;               // dv = -(H dA_p) x - HA dz, three partial sums
+                    static_for<D>([&](auto ii) {
+                        constexpr int i = decltype(ii)::value;
+                        fmac_bc<i>(i % 3 == 0 ? d0 : (i % 3 == 1 ? d1 : d2), hdap, xr[i]);
+                    });
+                    static_for<D>([&](auto ii) {
+                        constexpr int i = decltype(ii)::value;
+                        fmac_bc<i>(i % 3 == 0 ? d0 : (i % 3 == 1 ? d1 : d2), ha, z[i]);
+                    });
+                    const double dv = -((d0 + d1) + d2);
+                    s = fma(v, dv, s);                                // (v is zero in lanes past the end)
+                    double xn[D], zn[D];
+#pragma unroll
+                    for (int j = 0; j < J; j++)
+#pragma unroll
+                        for (int r = 0; r < DB; r++) {
+                            double sx = ablk[j * DB * DB + r * DB] * xr[j * DB], sz = ablk[j * DB * DB + r * DB] * z[j * DB];
+#pragma unroll
+                            for (int q = 1; q < DB; q++) {
+                                sx = fma(ablk[j * DB * DB + r * DB + q], xr[j * DB + q], sx);
+                                sz = fma(ablk[j * DB * DB + r * DB + q], z[j * DB + q], sz);
+                            }
+                            xn[j * DB + r] = sx;
+                            zn[j * DB + r] = sz;
+                        }
+                    static_for<NAB>([&](auto ee) {                    // + dA_p x (block diagonal)
+                        constexpr int e = decltype(ee)::value, jb = e / (DB * DB), r = (e % (DB * DB)) / DB, q = e % DB;
+                        fmac_bc<e % 16>(zn[jb * DB + r], dab[e / 16], xr[jb * DB + q]);
+                    });
+                    static_for<D>([&](auto ii) {
+                        constexpr int i = decltype(ii)::value;
+                        fmac_bc<i>(xn[i], kk, v);                     // x' = A x + K v
+                        fmac_bc<i>(zn[i], dkp, v);                    // + dK_p v
+                        fmac_bc<i>(zn[i], kk, dv);                    // + K dv
+                    });
+#pragma unroll
+                    for (int i = 0; i < D; i++) { xr[i] = xn[i]; z[i] = zn[i]; }
+                }
+            }
+            // ---- carry-in on lane 0, then the 64-lane Kogge-Stone scan with the uniform powers of M (as the filter's) ----
+            double t[D], cin[D];
+            if (it == 0) {
+#pragma unroll
+                for (int i = 0; i < D; i++) cin[i] = xc[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < D; i++) cin[i] = sm.dcarry[p * D + i];
+            }
+            {
+                double m0[NSL];
+                load_slabs<double, NSL>(cu + Lc::SP, lane, m0);
+#pragma unroll
+                for (int i = 0; i < D; i++) { t[i] = 0.0; z[i] = mine ? z[i] : 0.0; }
+                matvec_bc<double, D, NSL>(m0, cin, t);
+#pragma unroll
+                for (int i = 0; i < D; i++) z[i] += (lane == 0) ? t[i] : 0.0;
+#pragma unroll 1
+                for (int lv = 0; lv < nlev; lv++) {
+                    double m[NSL];
+                    load_slabs<double, NSL>(cu + Lc::SP + lv * Lc::LS, lane, m);
+                    const int sh = 1 << lv, addr = ((lane - sh) & 63) * 4;
+#pragma unroll
+                    for (int i = 0; i < D; i++) { const double mv = bperm<double>(addr, z[i]); t[i] = lane >= sh ? mv : 0.0; }
+                    matvec_bc<double, D, NSL>(m, t, z);
+                }
+            }
+            // start of every lane's chunk = end of the chunk before it; the carry-out is the end of the last chunk in use
+            double st[D], cout[D];
+            {
+                const int addr = ((lane - 1) & 63) * 4;
+#pragma unroll
+                for (int i = 0; i < D; i++) {
+                    const double mv = bperm<double>(addr, z[i]);
+                    st[i] = lane >= 1 ? mv : cin[i];
+                    cout[i] = read_lane(z[i], nc - 1);
+                }
+            }
+            if (it == 0) {
+#pragma unroll
+                for (int i = 0; i < D; i++) { xs[i] = st[i]; xc[i] = cout[i]; }
+                // ---- step 2: replay x; v replaces y in the tile (zero in lanes past the end) ----
+                double xr[D];
+#pragma unroll
+                for (int i = 0; i < D; i++) xr[i] = xs[i];
+                double part = 0.0;
+#pragma unroll 1
+                for (int k = 0; k < CK; k++) {
+                    const double y = tile_lane[k];
+                    double h0 = 0.0, h1 = 0.0, h2 = 0.0;
+                    static_for<D>([&](auto ii) {
+                        constexpr int i = decltype(ii)::value;
+                        fmac_bc<i>(i % 3 == 0 ? h0 : (i % 3 == 1 ? h1 : h2), ha, xr[i]);
+                    });
+                    const double v = mine ? y - ((h0 + h1) + h2) : 0.0;
+                    part = fma(v, v, part);                           // ihgp.h:206-207, pre-step state
+                    double xn[D];
+#pragma unroll
+                    for (int j = 0; j < J; j++)
+#pragma unroll
+                        for (int r = 0; r < DB; r++) {
+                            double sx = ablk[j * DB * DB + r * DB] * xr[j * DB];
+#pragma unroll
+                            for (int q = 1; q < DB; q++) sx = fma(ablk[j * DB * DB + r * DB + q], xr[j * DB + q], sx);
+                            xn[j * DB + r] = sx;
+                        }
+                    static_for<D>([&](auto ii) { fmac_bc<decltype(ii)::value>(xn[decltype(ii)::value], kk, v); });
+#pragma unroll
+                    for (int i = 0; i < D; i++) xr[i] = xn[i];
+                    tile_lane[k] = v;
+                }
+                acc += part;
+                // ---- step 3: r = sum_k v_k hp_k ----
+#pragma unroll
+                for (int i = 0; i < D; i++) rr[i] = 0.0;
+                bool dummy = false;
+                chunk_response<D>(sm.hp, tile_lane, lane, rr, dummy);
+            } else {
+                // sum_k v_k dv_k over the chunk = s - r . dx_start; all chunks of the segment into the stream's total
+                double tot = s;
+#pragma unroll
+                for (int i = 0; i < D; i++) tot = fma(-rr[i], st[i], tot);
+                tot = mine ? tot : 0.0;
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) tot += __shfl_xor(tot, o, 64);
+                if (lane == 0) sm.gacc[p] += tot;
+                if (lane < D) {
+                    double cv = 0.0;
+#pragma unroll
+                    for (int i = 0; i < D; i++) cv = lane == i ? cout[i] : cv;
+                    sm.dcarry[p * D + lane] = cv;
+                }
+                wave_lds_fence();
+            }
+        }
+        // ---- step 5: the stream of means ----
+        if (WRITE) {
+            double xr[D];
+#pragma unroll
+            for (int i = 0; i < D; i++) xr[i] = xs[i];
+#pragma unroll 1
+            for (int k = 0; k < CK; k++) {
+                const double v = tile_lane[k];
+                double xn[D], h0 = 0.0, h1 = 0.0, h2 = 0.0;
+                if (WRITE == 2) {
+                    static_for<D>([&](auto ii) {
+                        constexpr int i = decltype(ii)::value;
+                        fmac_bc<i>(i % 3 == 0 ? h0 : (i % 3 == 1 ? h1 : h2), ha, xr[i]);
+                    });
+                }
+#pragma unroll
+                for (int j = 0; j < J; j++)
+#pragma unroll
+                    for (int r = 0; r < DB; r++) {
+                        double sx = ablk[j * DB * DB + r * DB] * xr[j * DB];
+#pragma unroll
+                        for (int q = 1; q < DB; q++) sx = fma(ablk[j * DB * DB + r * DB + q], xr[j * DB + q], sx);
+                        xn[j * DB + r] = sx;
+                    }
+                static_for<D>([&](auto ii) { fmac_bc<decltype(ii)::value>(xn[decltype(ii)::value], kk, v); });
+#pragma unroll
+                for (int i = 0; i < D; i++) xr[i] = xn[i];
+                tile_lane[k] = WRITE == 2 ? (h0 + h1) + h2 : xn[0];   // HA x_t, or ihgp.h:51 `yhat = xnew(0, 0)`
+            }
+            wave_lds_fence();
+#pragma unroll
+            for (int r = 0; r < CK / EPV; r++) {
+                const int e = (r * 64 + lane) * EPV;
+                if (e < n) {
+                    const double* src = sm.tile + (e / CK) * STRIDE + (e % CK);
+                    TS vals[EPV];
+#pragma unroll
+                    for (int q = 0; q < EPV; q++) vals[q] = (TS)src[q];
+                    nt_store(pack<TS>(vals), reinterpret_cast<VS*>(orow + t0 + e));
+                }
+            }
+        }
+        wave_lds_fence();
+    }
+
+    // ---- results: carried (x, dx), NLL and gradient of the ticks swept (grad_x_kernel adds the stream's last T mod 32 ticks) ----
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) {
+        flags[l] = 0;
+#pragma unroll
+        for (int i = 0; i < D; i++) x[l * D + i] = (TS)xc[i];
+    }
+    for (int e = lane; e < P * D; e += 64) dx[l * P * D + e] = (TS)sm.dcarry[e];
+    const double S = c[Lc::S], nobs = (double)Tpar;
+    if (lane == 0 && nll) nll[l] = 0.5 * (acc / S + nobs * c[Lc::LOGS]);
+    if (lane < P) grad[l * P + lane] = sm.gacc[lane] / S - 0.5 * (acc / S - nobs) * cd[Ld::DS + lane] / S;   // ihgp.h:219 summed over the ticks
+}
+
+template <typename TS, int DB, int J>
+int launch_gsx(const void* Ty, size_t Tpar, size_t ld, size_t L, const double* cb64, const double* cbd64, void* x, void* dx, void* yhat,
+               double* nll, double* grad, int* flags, hipStream_t stream, int out_mode) {
+    dim3 block(64 * kGxWaves), grid((unsigned)((L + kGxWaves - 1) / kGxWaves));
+#define MOIHGP_GSX_LAUNCH(W_) hipLaunchKernelGGL((grad_scan_x_kernel<TS, DB, J, W_>), grid, block, 0, stream, (const TS*)Ty, Tpar, ld, L, cb64, cbd64, \
+                                                 (TS*)x, (TS*)dx, (TS*)yhat, nll, grad, flags)
+    if (yhat && out_mode == 2) MOIHGP_GSX_LAUNCH(2);
+    else if (yhat) MOIHGP_GSX_LAUNCH(1);
+    else MOIHGP_GSX_LAUNCH(0);
+#undef MOIHGP_GSX_LAUNCH
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_last_error("grad_scan_x_kernel launch: %s", hipGetErrorString(e)); return 2; }
+    return 0;
+}
+
+}  // namespace
+
+// The whole chunks [0, Tpar) of every latent's stream; flags[l] = 1 where the latent was left untouched (missing ticks, unusable scan
+// tables), 0 where (x, dx, nll, grad) now hold the state after / the sums over those Tpar ticks.
+int launch_grad_scan_x(int kernel, int dtype, const void* Ty, size_t Tpar, size_t ld, size_t L, const double* cb64, const double* cbd64,
+                       void* x, void* dx, void* yhat, double* nll, double* grad, int* flags, hipStream_t stream, int out_mode) {
+    if (L == 0) return 0;
+    const int base = kernel_base(kernel), J = kernel_stack(kernel);
+#define MOIHGP_GSX_CASE(DBB, JJ)                                                                                                        \
+    if (base == (DBB == 2 ? 0 : 1) && J == JJ)                                                                                          \
+        return dtype == 0 ? launch_gsx<double, DBB, JJ>(Ty, Tpar, ld, L, cb64, cbd64, x, dx, yhat, nll, grad, flags, stream, out_mode)  \
+                          : launch_gsx<float, DBB, JJ>(Ty, Tpar, ld, L, cb64, cbd64, x, dx, yhat, nll, grad, flags, stream, out_mode)
+    MOIHGP_GSX_CASE(2, 2); MOIHGP_GSX_CASE(2, 3); MOIHGP_GSX_CASE(2, 4);
+    MOIHGP_GSX_CASE(3, 2); MOIHGP_GSX_CASE(3, 3); MOIHGP_GSX_CASE(3, 4);
+#undef MOIHGP_GSX_CASE
+    set_last_error("stacked kernel id %d is not built", kernel);
+    return 1;
+}
+
+}  // namespace moihgp

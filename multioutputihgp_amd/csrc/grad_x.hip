@@ -11,6 +11,7 @@
 // :216-219); lanes 0 .. P-1 carry one gradient entry each.  All arithmetic is fp64 whatever the stream's type.
 // Latency-bound by construction (about 0.25 us per tick at D = 12): fine for the learners' windows, slow for long streams.
 #include "kernels_common.h"
+#include <cstdlib>
 
 namespace moihgp {
 namespace {
@@ -18,7 +19,8 @@ namespace {
 template <typename T, int DB, int J>
 __global__ void __launch_bounds__(64)
 grad_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, const double* __restrict__ cb64, const double* __restrict__ cbd64,
-              T* __restrict__ x, T* __restrict__ dx, T* __restrict__ yhat, double* __restrict__ nll, double* __restrict__ grad, int out_mode) {
+              T* __restrict__ x, T* __restrict__ dx, T* __restrict__ yhat, double* __restrict__ nll, double* __restrict__ grad, int out_mode,
+              const int* __restrict__ only /* NULL: every latent whole */, size_t t_cont) {
     constexpr int D = DB * J, NN = D * D, P = 2 * J + 1, NE = (P + 1) * D;
     using Lc = XC<D>;
     using Ld = XD<D, P>;
@@ -38,6 +40,11 @@ grad_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, const 
     const int lane = threadIdx.x;
     const size_t l = blockIdx.x;
     if (l >= L) return;
+    // after grad_scan_x_kernel: a flagged latent is swept whole; the others continue at tick t_cont from the carried (x, dx) and
+    // ADD to the sums that kernel left in nll / grad
+    const bool cont = only && !only[l];
+    if (cont && t_cont >= Tlen) return;
+    const size_t t_first = cont ? t_cont : 0;
     const double* c = cb64 + l * Lc::SIZE;
     const double* cd = cbd64 + l * Ld::SIZE;
     for (int e = lane; e < NN; e += 64) { sAKHA[e] = c[Lc::AKHA + e]; sA[e] = c[Lc::A + e]; }
@@ -53,7 +60,7 @@ grad_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, const 
     int cur = 0;
     const T* row = Ty + l * ld;
     T* orow = yhat ? yhat + l * ld : nullptr;
-    for (size_t t0 = 0; t0 < Tlen; t0 += 64) {
+    for (size_t t0 = t_first; t0 < Tlen; t0 += 64) {
         const int nt = (int)(Tlen - t0 < 64 ? Tlen - t0 : 64);
         if (lane < nt) sy[lane] = (double)row[t0 + lane];
         wave_lds_fence();
@@ -110,17 +117,17 @@ grad_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, const 
         if (e < D) x[l * D + e] = (T)st[e];
         else dx[l * P * D + (e - D)] = (T)st[e];
     }
-    if (lane == 0) nll[l] = acc;
-    if (lane < P) grad[l * P + lane] = g;
+    if (lane == 0) nll[l] = cont ? nll[l] + acc : acc;
+    if (lane < P) grad[l * P + lane] = cont ? grad[l * P + lane] + g : g;
 }
 
 template <typename T, int DB, int J>
 int launch_gx(const void* Ty, size_t Tlen, size_t ld, size_t L, const double* cb64, const double* cbd64, void* x, void* dx, void* yhat,
-              double* nll, double* grad, hipStream_t stream, int out_mode) {
+              double* nll, double* grad, hipStream_t stream, int out_mode, const int* only, size_t t_cont) {
     constexpr int D = DB * J, NN = D * D, P = 2 * J + 1, NE = (P + 1) * D;
     const size_t smem = (size_t)(2 * NN + 2 * P * NN + 2 * D + 2 * P * D + P + 2 * NE + 128) * sizeof(double);
     hipLaunchKernelGGL((grad_x_kernel<T, DB, J>), dim3((unsigned)L), dim3(64), smem, stream, (const T*)Ty, Tlen, ld, L, cb64, cbd64,
-                       (T*)x, (T*)dx, (T*)yhat, nll, grad, out_mode);
+                       (T*)x, (T*)dx, (T*)yhat, nll, grad, out_mode, only, t_cont);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_last_error("grad_x_kernel launch: %s", hipGetErrorString(e)); return 2; }
     return 0;
@@ -129,13 +136,23 @@ int launch_gx(const void* Ty, size_t Tlen, size_t ld, size_t L, const double* cb
 }  // namespace
 
 int launch_grad_stream_x(int kernel, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* cb64, const double* cbd64,
-                         void* x, void* dx, void* yhat, double* nll, double* grad, hipStream_t stream, int out_mode) {
+                         void* x, void* dx, void* yhat, double* nll, double* grad, hipStream_t stream, int out_mode, int* flags) {
     if (L == 0) return 0;
+    // long streams: the time-parallel sweep (grad_scan_x.hip) takes the whole 32-tick chunks of every latent it can; what it leaves
+    // (flags[l] = 1: missing ticks, unusable scan tables; the last T mod 32 ticks of the others) is walked tick by tick here
+    static const size_t scan_from = [] { const char* e = std::getenv("MOIHGP_GRADX_SCAN_FROM"); return e ? (size_t)std::atoll(e) : (size_t)512; }();
+    const int* only = nullptr;
+    size_t t_cont = 0;
+    if (flags && nll && T >= scan_from) {
+        t_cont = T / kChunkX * kChunkX;
+        if (int rc = launch_grad_scan_x(kernel, dtype, Ty, t_cont, ld, L, cb64, cbd64, x, dx, yhat, nll, grad, flags, stream, out_mode)) return rc;
+        only = flags;
+    }
     const int base = kernel_base(kernel), J = kernel_stack(kernel);
 #define MOIHGP_GX_CASE(DBB, JJ)                                                                                          \
     if (base == (DBB == 2 ? 0 : 1) && J == JJ)                                                                           \
-        return dtype == 0 ? launch_gx<double, DBB, JJ>(Ty, T, ld, L, cb64, cbd64, x, dx, yhat, nll, grad, stream, out_mode) \
-                          : launch_gx<float, DBB, JJ>(Ty, T, ld, L, cb64, cbd64, x, dx, yhat, nll, grad, stream, out_mode)
+        return dtype == 0 ? launch_gx<double, DBB, JJ>(Ty, T, ld, L, cb64, cbd64, x, dx, yhat, nll, grad, stream, out_mode, only, t_cont) \
+                          : launch_gx<float, DBB, JJ>(Ty, T, ld, L, cb64, cbd64, x, dx, yhat, nll, grad, stream, out_mode, only, t_cont)
     MOIHGP_GX_CASE(2, 2); MOIHGP_GX_CASE(2, 3); MOIHGP_GX_CASE(2, 4);
     MOIHGP_GX_CASE(3, 2); MOIHGP_GX_CASE(3, 3); MOIHGP_GX_CASE(3, 4);
 #undef MOIHGP_GX_CASE

@@ -1136,6 +1136,41 @@ def test_stacked_gradstream_vs_oracle(env, kern, dtype, L, T, nanf):
     assert err(r["grad"].cpu().numpy(), o["grad"], 1e-6) < tol * 10
 
 
+@pytest.mark.parametrize("kern", STACKED)
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("L,T,gap", [(3, 512, None), (2, 543, None), (5, 2048, None), (3, 2081, None), (2, 4133, None), (3, 6500, None),
+                                     (4, 2500, 1700), (3, 1024, 0)])
+def test_stacked_gradstream_long_streams_vs_oracle(env, kern, dtype, L, T, gap):
+    """Streams of >= 512 ticks take the time-parallel sweep of the stacked models (grad_scan_x.hip: innovation-form sensitivity
+    recursion, chunk-local sensitivities scanned with the filter's own powers): whole 32-tick chunks there, the last T mod 32 ticks
+    and every latent with a missing tick (gap: one NaN in latents 1..) in the tick-by-tick kernel, which must continue / redo
+    seamlessly.  Exactly one segment, one chunk past a segment, several segments, ragged ends."""
+    J = int(kern[-1])
+    rng = np.random.default_rng(11 * L + T + J)
+    prm = synth_params_stacked(L, J, rng)
+    bank = env["streams"].LatentBank(0.1, prm, kernel=kern)
+    d, P = bank.d, bank.P
+    Ty = synth(L, T, rng)
+    if gap is not None:
+        Ty[1:, gap] = np.nan
+    x0 = 0.2 * rng.standard_normal((L, d)); dx0 = 0.05 * rng.standard_normal((L, P, d))
+    o = env["cref"].grad_stream(env["cref"].ihgp_array(kern, 0.1, prm), Ty, x0=x0, dx0=dx0)
+    tol = 1e-9 if dtype == torch.float64 else FP32_TOL
+    tame = np.nan_to_num(np.abs(o["yhat"]), nan=0.0).max(axis=1) < 1e6
+    if not tame.any():
+        return
+    def err(a, b, floor=0.0):
+        return float(np.abs(a[tame] - b[tame]).max() / max(np.abs(b[tame]).max(), floor, 1e-300))
+    for want in (True, False):
+        r = bank.grad(to_dev(Ty, dtype), T=T, x=torch.from_numpy(x0).to(dtype).cuda(), dx=torch.from_numpy(dx0).to(dtype).cuda(), want_yhat=want)
+        torch.cuda.synchronize()
+        if want:
+            assert err(np.nan_to_num(r["yhat"][:, :T].cpu().numpy()), np.nan_to_num(o["yhat"])) < tol
+        assert err(r["x"].cpu().numpy(), o["x"]) < tol and err(r["dx"].cpu().numpy(), o["dx"], 1e-6) < tol * 10
+        assert err(r["nll"].cpu().numpy(), o["nll_per_latent"]) < tol * 10
+        assert err(r["grad"].cpu().numpy(), o["grad"], 1e-6) < tol * 10
+
+
 @pytest.mark.parametrize("kern", ["Matern52", "Matern52x2"])
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 def test_filter_separate_start_state(env, kern, dtype):
