@@ -12,7 +12,7 @@ latents of a 4096*N-output model (weak scaling, configs[3] at N=8); the only col
 all-reduce of the scalar NLL.  Other configs: --config c1 | c2 | c3f64 | c2d6 | c5 | c4 | c3learn (configs[2] with its outer loop: one
 objective evaluation of the online learner, MOIHGP::update + the windowed NLL/gradient sweep, at M = L = 4096).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c1|c2|c3f64|c2d6|c5|c4|c3learn] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c1|c2|c3f64|c2d6|c5|c4|c3learn|c3grad|c5grad] [--no-cpu]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 """
@@ -256,6 +256,72 @@ def run_c3learn(args, rank, world):
     print(json.dumps(out), flush=True)
 
 
+def run_grad(args, rank, world):
+    """Mode G of SURVEY 8(d) over whole streams: the sensitivity / gradient sweep (ihgp.h:37-57 + :212-222 per tick: step with
+    sensitivities, NLL and its gradient w.r.t. the latent's hyper-parameters), resident streams, one GPU.  c3grad: C3's shape
+    (4096 x 10^4, Matern-5/2, d = 3, P = 3, fp32); c5grad: C5's (d = 12 stacked, P = 9, fp64).  A step = one sweep."""
+    from multioutputihgp_amd.streams import LatentBank
+    L, T, dtype, kernel, _ = CONFIGS["c3" if args.config == "c3grad" else "c5"]
+    dev = torch.device("cuda", torch.cuda.current_device())
+    prm = synth_params(L, 0, np.random.default_rng(SEED), kernel)
+    bank = LatentBank(0.1, prm, kernel=kernel)
+    Ty = synth_stream(L, 0, T, dtype, dev, SEED + 1)
+    d, P = bank.d, bank.P
+    for _ in range(max(1, args.warmup)):
+        r = bank.grad(Ty, T=T, want_yhat=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        r = bank.grad(Ty, T=T, want_yhat=False)
+    torch.cuda.synchronize()
+    sec = (time.perf_counter() - t0) / args.steps
+    steps_per_s = L * T / sec
+    peak = 157.3 if dtype == torch.float32 else 78.6
+    ref_flops = 2 * d * d + 4 * d + 5 + P * (4 * d * d + 6 * d + 8)              # SURVEY 8(d), mode G, the reference's dense form
+    if bank.stacked:
+        # what grad_scan_x.hip's innovation form needs at least (A block diagonal, dA_p one block or none): x' = A x + K v and
+        # v = y - HA x: d DB + 2 d;  per parameter dz' = A dz + dK v + K dv, dv = -HA dz: d DB + 3 d, + DB^2 + DB for a lengthscale
+        J = (P - 1) // 2; DB = d // J
+        min_fma = d * DB + 2 * d + P * (d * DB + 3 * d) + J * (DB * DB + DB)
+        flops, form = 2 * min_fma, "innovation form with block-diagonal A (the multiply-adds grad_scan_x.hip cannot avoid; replays, scans and response sums on top are overhead)"
+    else:
+        flops, form = ref_flops, "SURVEY 8(d) mode G count of the reference's form"
+    out = {
+        "metric": "Kalman steps/sec (M outputs x T ticks) + NLL rel-err vs CPU oracle",
+        "value": steps_per_s, "unit": "Kalman steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if dtype == torch.float32 else "f64", "data": "synthetic",
+        "config": {"workload": f"{args.config}: gradient sweep (step with sensitivities + NLL + dNLL/dtheta per tick) over L={L} latents x T={T} ticks, {kernel}, "
+                               f"d={d}, P={P}; streams resident in HBM", "latents_total": L, "ticks": T, "state_dim": d, "hyper_parameters_per_latent": P},
+        "roofline": {"bound": "valu", "achieved": steps_per_s * flops / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": steps_per_s * flops / 1e12 / peak,
+                     "traffic": None, "kernel": "grad_scan_x_kernel" if bank.stacked else "grad_scan_kernel", "kernel_ms": sec * 1e3,
+                     "kernel_ms_from": f"wall clock over {args.steps} sweeps (one launch of the sweep kernel + the small continuation kernel each)",
+                     "flops_per_step": flops, "flop_count": form, "reference_form_flops_per_step": ref_flops,
+                     "reference_form_equivalent_TFLOPs": steps_per_s * ref_flops / 1e12,
+                     "note": "vector-ALU bound (no MFMA: per-latent matrices, d <= 12); HBM side: " + f"{steps_per_s * (4 if dtype == torch.float32 else 8) / 1e9:.0f} GB/s of 8000"},
+        "nll_total": float(r["nll"].sum()),
+    }
+    if not args.no_cpu:
+        from oracle import cref
+        okern = ORACLE_KERNEL.get(kernel, kernel)
+        wide = cref.is_wide(okern)
+        cref.build(native=True, wide=wide)
+        Lb = cref.lib(True, wide)
+        nthreads = min(os.cpu_count() or 1, int(Lb.orc_max_threads()))
+        Ls = min(L, 256 if bank.stacked else 1024)
+        igps = cref.ihgp_array(okern, 0.1, prm[:Ls], native=True)
+        Th = np.ascontiguousarray(Ty[:Ls, :T].double().cpu().numpy())
+        t0 = time.perf_counter()
+        o = cref.grad_stream(igps, Th, want_yhat=False, nthreads=nthreads)
+        tc = time.perf_counter() - t0
+        out["cpu_baseline"] = dict(value=Ls * T / tc, unit="Kalman steps/s", cores=nthreads, kind="port",
+                                   sample=f"first {Ls} latents x T={T}, fp64, oracle/moihgp_oracle.c orc_grad_stream (-O3 -march=native, OpenMP over latents), one pass")
+        g = r["grad"][:Ls].cpu().numpy(); n = r["nll"][:Ls].cpu().numpy()
+        out["nll_rel_err"] = float(np.abs(n - o["nll_per_latent"]).max() / np.abs(o["nll_per_latent"]).max())
+        out["grad_rel_err"] = float(np.abs(g - o["grad"]).max() / np.abs(o["grad"]).max())
+        out["speedup_vs_cpu_all_cores"] = steps_per_s / out["cpu_baseline"]["value"]
+    print(json.dumps(out), flush=True)
+
+
 def valu_side(d, dtype, steps_per_s):
     """Vector-ALU side of the roofline: SURVEY 8(d)'s flop count for the filter (2 d^2 + 2 d per Kalman step) over the
     dense vector peak of the dtype (MI355X_MICROARCH.md: 157.3 TFLOP/s fp32, 78.6 fp64)."""
@@ -270,7 +336,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS) + ["c1", "c3learn"])
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS) + ["c1", "c3learn", "c3grad", "c5grad"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / parity leg")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold-stream leg (roofline.frac_cold): profiled runs, so that a kernel trace holds the timed launches only")
     ap.add_argument("--sync-allreduce", action="store_true", help="N > 1: make every pass wait for its own NLL all-reduce (no overlap with the next sweep)")
@@ -304,6 +370,8 @@ def main():
         return run_c1(args, rank, world)
     if args.config == "c3learn":
         return run_c3learn(args, rank, world)
+    if args.config in ("c3grad", "c5grad"):
+        return run_grad(args, rank, world)
 
     Lg_per, T, dtype, kernel, desc = CONFIGS[args.config]
     slab = SLAB.get(args.config, T)

@@ -73,6 +73,7 @@ struct moihgp_gp {
     double* dwork = nullptr;   // L*L + L, lazily (missing-output projection)
     double* dpolar = nullptr;  // M*L + 2*L*L + 8, lazily (device polar factor)
     int* dfallback = nullptr;  // [L] flags of latents redone by the sequential gradient kernel
+    double* dhp = nullptr;     // [L][gradx_hp_len(d)] HA AKHA^k rows of the stacked models' time-parallel gradient sweep (on first use)
     double* dxscratch = nullptr; // stacked kernels, few latents: per-slice NLL partials
     double* cbd64 = nullptr;     // stacked kernels: sensitivity blocks (XD), fp64; filled once somebody asks for gradients
     bool sens_wanted = false, sens_valid = false;
@@ -102,7 +103,7 @@ struct moihgp_gp {
 
 static void gp_free(moihgp_gp* g) {
     if (!g) return;
-    void* ptrs[] = {g->dU, g->dS, g->dsqrtS, g->dinvsqrtS, g->dsigma, g->dparams, g->cb64, g->cb32, g->dx, g->dpart, g->dTy, g->dUty, g->dTyhat, g->dloss, g->dgrad, g->dscratch, g->dwork, g->dpolar, g->dfallback, g->dwin, g->dunstable, g->dxscratch, g->cbd64, g->dU32};
+    void* ptrs[] = {g->dU, g->dS, g->dsqrtS, g->dinvsqrtS, g->dsigma, g->dparams, g->cb64, g->cb32, g->dx, g->dpart, g->dTy, g->dUty, g->dTyhat, g->dloss, g->dgrad, g->dscratch, g->dwork, g->dpolar, g->dfallback, g->dwin, g->dunstable, g->dxscratch, g->cbd64, g->dU32, g->dhp};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (void* p : g->pinned) (void)hipHostUnregister(p);
@@ -735,7 +736,10 @@ static int grad_stream_impl(moihgp_gp* gp, int dtype, const void* Ty, size_t T, 
     ensure_sensitivities(gp);
     note_user_stream(gp, (hipStream_t)stream);
     if (kernel_stack(gp->kernel))
-        return launch_grad_stream_x(gp->kernel, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cbd64, x, dx, yhat, nll, grad, (hipStream_t)stream, 1, gp->dfallback);
+        {
+        if (!gp->dhp) gp->dhp = dev_alloc<double>(gp->L * gradx_hp_len(gp->d));    // table of the time-parallel sweep (grad_scan_x.hip)
+        return launch_grad_stream_x(gp->kernel, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cbd64, x, dx, yhat, nll, grad, (hipStream_t)stream, 1, gp->dfallback, gp->dhp);
+    }
     return launch_grad_stream(gp->d, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cb32, x, dx, yhat, nll, grad, gp->dfallback, (hipStream_t)stream);
 }
 

@@ -32,16 +32,41 @@
 namespace moihgp {
 namespace {
 
-constexpr int kGxWaves = 2;                                           // wavefronts per workgroup (LDS: 20.5 KB each)
+constexpr int kGxWaves = 2;                                           // wavefronts per workgroup (LDS: 18.3 KB each)
 
 template <int D> struct GxLds {
     static constexpr int CK = kChunkX, STRIDE = CK + 2;
     static constexpr int HPN = (CK * D + 15) / 16 * 16;
     double tile[64 * STRIDE];        // the segment, chunk per lane row, padded
-    double hp[HPN];                  // HA AKHA^k, [k][i]: slab table of step 3
-    double dcarry[9 * D];            // carried sensitivities dx_p between segments
+    double carry[10 * D];            // carried x and sensitivities dx_p between segments ([0]: x, [p + 1]: dx_p)
     double gacc[9];                  // sum over the stream of v dv_p
 };
+
+// hp_k = HA AKHA^k, k < CK, as a slab table [k][i] per latent (step 3 of the sweep): lane j < D holds column j of AKHA and entry j
+// of the running row.  Its own small kernel: the table is wave-uniform data of the sweep, fetched there like the response table.
+template <int D>
+__global__ void __launch_bounds__(64) hp_table_kernel(const double* __restrict__ cb64, double* __restrict__ hp, size_t L) {
+    using Lc = XC<D>;
+    const int lane = threadIdx.x;
+    const size_t l = blockIdx.x;
+    if (l >= L) return;
+    const double* c = cb64 + l * Lc::SIZE;
+    double* out = hp + l * GxLds<D>::HPN;
+    double col[D];
+    const int jc = lane < D ? lane : 0;
+#pragma unroll
+    for (int i = 0; i < D; i++) col[i] = c[Lc::AKHA + i * D + jc];
+    double h = c[Lc::HA + jc];
+    for (int e = kChunkX * D + lane; e < GxLds<D>::HPN; e += 64) out[e] = 0.0;
+#pragma unroll 1
+    for (int k = 0; k < kChunkX; k++) {
+        if (lane < D) out[k * D + lane] = h;
+        double hn = 0.0;
+#pragma unroll
+        for (int i = 0; i < D; i++) hn = fma(read_lane(h, i), col[i], hn);
+        h = hn;
+    }
+}
 
 // z += sum_k tab[k][.] tile_lane[k]: the chunk response to a slab table [CK][D] (16-aligned, global or LDS)
 template <int D, typename Ptr>
@@ -72,7 +97,7 @@ template <typename TS, int DB, int J, int WRITE>
 __global__ void __launch_bounds__(64 * kGxWaves)
 grad_scan_x_kernel(const TS* __restrict__ Ty, size_t Tpar /* whole chunks */, size_t ld, size_t L, const double* __restrict__ cb64,
                    const double* __restrict__ cbd64, TS* __restrict__ x, TS* __restrict__ dx, TS* __restrict__ yhat, double* __restrict__ nll,
-                   double* __restrict__ grad, int* __restrict__ flags) {
+                   double* __restrict__ grad, int* __restrict__ flags, const double* __restrict__ hpg /* [L][HPN]: hp_table_kernel */) {
     constexpr int D = DB * J, P = 2 * J + 1, CK = kChunkX, SEG = 64 * CK, STRIDE = GxLds<D>::STRIDE;
     constexpr int EPV = 16 / (int)sizeof(TS);
     using VS = typename VecOf<TS>::type;
@@ -98,31 +123,11 @@ grad_scan_x_kernel(const TS* __restrict__ Ty, size_t Tpar /* whole chunks */, si
     }
     const int nlev = __builtin_amdgcn_readfirstlane((int)c[Lc::NLEV]);
 
-    // ---- once per latent: hp_k = HA AKHA^k, k < CK (lane j < D holds column j of AKHA and entry j of the running row) ----
-    {
-        double col[D], h = 0.0;
-        const int jc = lane < D ? lane : 0;
-#pragma unroll
-        for (int i = 0; i < D; i++) col[i] = c[Lc::AKHA + i * D + jc];
-        h = c[Lc::HA + jc];
-        for (int e = lane; e < GxLds<D>::HPN; e += 64) sm.hp[e] = 0.0;
-        wave_lds_fence();
-#pragma unroll 1
-        for (int k = 0; k < CK; k++) {
-            if (lane < D) sm.hp[k * D + lane] = h;
-            double hn = 0.0;
-#pragma unroll
-            for (int i = 0; i < D; i++) hn = fma(read_lane(h, i), col[i], hn);
-            h = hn;
-        }
-        for (int e = lane; e < P * D; e += 64) sm.dcarry[e] = (double)dx[l * P * D + e];
-        if (lane < P) sm.gacc[lane] = 0.0;
-        wave_lds_fence();
-    }
+    for (int e = lane; e < (P + 1) * D; e += 64) sm.carry[e] = e < D ? (double)x[l * D + e] : (double)dx[l * P * D + (e - D)];
+    if (lane < P) sm.gacc[lane] = 0.0;
+    wave_lds_fence();
+    const double* __restrict__ hpl = hpg + l * GxLds<D>::HPN;
 
-    double xc[D];                                                    // carried state between segments
-#pragma unroll
-    for (int i = 0; i < D; i++) xc[i] = (double)x[l * D + i];
     double acc = 0.0;                                                // per lane: sum of v^2
     const double ha = c[Lc::HA16 + (lane & 15)], kk = c[Lc::K16 + (lane & 15)];
 
@@ -179,60 +184,77 @@ grad_scan_x_kernel(const TS* __restrict__ Ty, size_t Tpar /* whole chunks */, si
                     dkp = cd[Ld::DK + p * D + i16];
                     hdap = cd[Ld::HDA + p * D + i16];
                 }
+                // Which blocks of dA_p are there at all: none (p a magnitude or the noise variance: dA_p = 0, H dA_p = 0), one (p the
+                // lengthscale of component j), or -- not produced by the update kernel, kept for safety -- several.  Read off the
+                // data, so nothing here depends on the order of the parameters.
+                unsigned nzmask = 0;
+#pragma unroll
+                for (int sidx = 0; sidx < NSA; sidx++) {
+                    const int e = sidx * 16 + (lane & 15);
+                    if (e < NAB && dab[sidx] != 0.0) nzmask |= 1u << (e / (DB * DB));
+                }
+                if ((lane & 15) < D && hdap != 0.0) nzmask |= 1u << J;
+                unsigned blocks = 0;
+#pragma unroll
+                for (int j = 0; j <= J; j++) blocks |= (__builtin_amdgcn_ballot_w64((nzmask >> j) & 1u) != 0 ? 1u : 0u) << j;
+                const int nblk = __builtin_popcount(blocks & ((1u << J) - 1u));
+                // MODE: -1 no dA_p, j = only block j, J = every block
+                const int mode = nblk == 0 ? ((blocks >> J) ? J : -1) : (nblk == 1 ? __builtin_ctz(blocks) : J);
                 double xr[D];
 #pragma unroll
                 for (int i = 0; i < D; i++) xr[i] = xs[i];
+                auto replay_p = [&](auto mode_c) {
+                    constexpr int MODE = decltype(mode_c)::value - 1;   // (integral_constant of MODE + 1)
 #pragma unroll 1
-                for (int k = 0; k < CK; k++) {
-                    const double v = tile_lane[k];
-                    double d0 = 0.0, d1 = 0.0, d2 = 0.0;               // dv = -(H dA_p) x - HA dz, three partial sums
-                    static_for<D>([&](auto ii) {
-                        constexpr int i = decltype(ii)::value;
-                        fmac_bc<i>(i % 3 == 0 ? d0 : (i % 3 == 1 ? d1 : d2), hdap, xr[i]);
-                    });
-                    static_for<D>([&](auto ii) {
-                        constexpr int i = decltype(ii)::value;
-                        fmac_bc<i>(i % 3 == 0 ? d0 : (i % 3 == 1 ? d1 : d2), ha, z[i]);
-                    });
-                    const double dv = -((d0 + d1) + d2);
-                    s = fma(v, dv, s);                                // (v is zero in lanes past the end)
-                    double xn[D], zn[D];
+                    for (int k = 0; k < CK; k++) {
+                        const double v = tile_lane[k];
+                        double d0 = 0.0, d1 = 0.0, d2 = 0.0;           // dv = -(H dA_p) x - HA dz, three partial sums
+                        static_for<D>([&](auto ii) {
+                            constexpr int i = decltype(ii)::value;
+                            if constexpr (MODE == J || (MODE >= 0 && i / DB == MODE)) fmac_bc<i>(i % 3 == 0 ? d0 : (i % 3 == 1 ? d1 : d2), hdap, xr[i]);
+                        });
+                        static_for<D>([&](auto ii) {
+                            constexpr int i = decltype(ii)::value;
+                            fmac_bc<i>(i % 3 == 0 ? d0 : (i % 3 == 1 ? d1 : d2), ha, z[i]);
+                        });
+                        const double dv = -((d0 + d1) + d2);
+                        s = fma(v, dv, s);                            // (v is zero in lanes past the end)
+                        double xn[D], zn[D];
 #pragma unroll
-                    for (int j = 0; j < J; j++)
+                        for (int j = 0; j < J; j++)
 #pragma unroll
-                        for (int r = 0; r < DB; r++) {
-                            double sx = ablk[j * DB * DB + r * DB] * xr[j * DB], sz = ablk[j * DB * DB + r * DB] * z[j * DB];
+                            for (int r = 0; r < DB; r++) {
+                                double sx = ablk[j * DB * DB + r * DB] * xr[j * DB], sz = ablk[j * DB * DB + r * DB] * z[j * DB];
 #pragma unroll
-                            for (int q = 1; q < DB; q++) {
-                                sx = fma(ablk[j * DB * DB + r * DB + q], xr[j * DB + q], sx);
-                                sz = fma(ablk[j * DB * DB + r * DB + q], z[j * DB + q], sz);
+                                for (int q = 1; q < DB; q++) {
+                                    sx = fma(ablk[j * DB * DB + r * DB + q], xr[j * DB + q], sx);
+                                    sz = fma(ablk[j * DB * DB + r * DB + q], z[j * DB + q], sz);
+                                }
+                                xn[j * DB + r] = sx;
+                                zn[j * DB + r] = sz;
                             }
-                            xn[j * DB + r] = sx;
-                            zn[j * DB + r] = sz;
-                        }
-                    static_for<NAB>([&](auto ee) {                    // + dA_p x (block diagonal)
-                        constexpr int e = decltype(ee)::value, jb = e / (DB * DB), r = (e % (DB * DB)) / DB, q = e % DB;
-                        fmac_bc<e % 16>(zn[jb * DB + r], dab[e / 16], xr[jb * DB + q]);
-                    });
-                    static_for<D>([&](auto ii) {
-                        constexpr int i = decltype(ii)::value;
-                        fmac_bc<i>(xn[i], kk, v);                     // x' = A x + K v
-                        fmac_bc<i>(zn[i], dkp, v);                    // + dK_p v
-                        fmac_bc<i>(zn[i], kk, dv);                    // + K dv
-                    });
+                        static_for<NAB>([&](auto ee) {                // + dA_p x (block diagonal)
+                            constexpr int e = decltype(ee)::value, jb = e / (DB * DB), r = (e % (DB * DB)) / DB, q = e % DB;
+                            if constexpr (MODE == J || jb == MODE) fmac_bc<e % 16>(zn[jb * DB + r], dab[e / 16], xr[jb * DB + q]);
+                        });
+                        static_for<D>([&](auto ii) {
+                            constexpr int i = decltype(ii)::value;
+                            fmac_bc<i>(xn[i], kk, v);                 // x' = A x + K v
+                            fmac_bc<i>(zn[i], dkp, v);                // + dK_p v
+                            fmac_bc<i>(zn[i], kk, dv);                // + K dv
+                        });
 #pragma unroll
-                    for (int i = 0; i < D; i++) { xr[i] = xn[i]; z[i] = zn[i]; }
-                }
+                        for (int i = 0; i < D; i++) { xr[i] = xn[i]; z[i] = zn[i]; }
+                    }
+                };
+                if (mode < 0) replay_p(std::integral_constant<int, 0>{});
+                else if (mode >= J) replay_p(std::integral_constant<int, J + 1>{});
+                else static_for<J>([&](auto jj) { if (mode == decltype(jj)::value) replay_p(std::integral_constant<int, decltype(jj)::value + 1>{}); });
             }
             // ---- carry-in on lane 0, then the 64-lane Kogge-Stone scan with the uniform powers of M (as the filter's) ----
             double t[D], cin[D];
-            if (it == 0) {
 #pragma unroll
-                for (int i = 0; i < D; i++) cin[i] = xc[i];
-            } else {
-#pragma unroll
-                for (int i = 0; i < D; i++) cin[i] = sm.dcarry[p * D + i];
-            }
+            for (int i = 0; i < D; i++) cin[i] = sm.carry[it * D + i];
             {
                 double m0[NSL];
                 load_slabs<double, NSL>(cu + Lc::SP, lane, m0);
@@ -264,7 +286,7 @@ grad_scan_x_kernel(const TS* __restrict__ Ty, size_t Tpar /* whole chunks */, si
             }
             if (it == 0) {
 #pragma unroll
-                for (int i = 0; i < D; i++) { xs[i] = st[i]; xc[i] = cout[i]; }
+                for (int i = 0; i < D; i++) xs[i] = st[i];
                 // ---- step 2: replay x; v replaces y in the tile (zero in lanes past the end) ----
                 double xr[D];
 #pragma unroll
@@ -300,7 +322,7 @@ grad_scan_x_kernel(const TS* __restrict__ Ty, size_t Tpar /* whole chunks */, si
 #pragma unroll
                 for (int i = 0; i < D; i++) rr[i] = 0.0;
                 bool dummy = false;
-                chunk_response<D>(sm.hp, tile_lane, lane, rr, dummy);
+                chunk_response<D>(launder(hpl), tile_lane, lane, rr, dummy);
             } else {
                 // sum_k v_k dv_k over the chunk = s - r . dx_start; all chunks of the segment into the stream's total
                 double tot = s;
@@ -310,14 +332,14 @@ grad_scan_x_kernel(const TS* __restrict__ Ty, size_t Tpar /* whole chunks */, si
 #pragma unroll
                 for (int o = 32; o >= 1; o >>= 1) tot += __shfl_xor(tot, o, 64);
                 if (lane == 0) sm.gacc[p] += tot;
-                if (lane < D) {
-                    double cv = 0.0;
-#pragma unroll
-                    for (int i = 0; i < D; i++) cv = lane == i ? cout[i] : cv;
-                    sm.dcarry[p * D + lane] = cv;
-                }
-                wave_lds_fence();
             }
+            if (lane < D) {
+                double cv = 0.0;
+#pragma unroll
+                for (int i = 0; i < D; i++) cv = lane == i ? cout[i] : cv;
+                sm.carry[it * D + lane] = cv;
+            }
+            wave_lds_fence();
         }
         // ---- step 5: the stream of means ----
         if (WRITE) {
@@ -369,10 +391,11 @@ grad_scan_x_kernel(const TS* __restrict__ Ty, size_t Tpar /* whole chunks */, si
     for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
     if (lane == 0) {
         flags[l] = 0;
-#pragma unroll
-        for (int i = 0; i < D; i++) x[l * D + i] = (TS)xc[i];
     }
-    for (int e = lane; e < P * D; e += 64) dx[l * P * D + e] = (TS)sm.dcarry[e];
+    for (int e = lane; e < (P + 1) * D; e += 64) {
+        if (e < D) x[l * D + e] = (TS)sm.carry[e];
+        else dx[l * P * D + (e - D)] = (TS)sm.carry[e];
+    }
     const double S = c[Lc::S], nobs = (double)Tpar;
     if (lane == 0 && nll) nll[l] = 0.5 * (acc / S + nobs * c[Lc::LOGS]);
     if (lane < P) grad[l * P + lane] = sm.gacc[lane] / S - 0.5 * (acc / S - nobs) * cd[Ld::DS + lane] / S;   // ihgp.h:219 summed over the ticks
@@ -380,10 +403,11 @@ grad_scan_x_kernel(const TS* __restrict__ Ty, size_t Tpar /* whole chunks */, si
 
 template <typename TS, int DB, int J>
 int launch_gsx(const void* Ty, size_t Tpar, size_t ld, size_t L, const double* cb64, const double* cbd64, void* x, void* dx, void* yhat,
-               double* nll, double* grad, int* flags, hipStream_t stream, int out_mode) {
+               double* nll, double* grad, int* flags, double* hp, hipStream_t stream, int out_mode) {
     dim3 block(64 * kGxWaves), grid((unsigned)((L + kGxWaves - 1) / kGxWaves));
+    hipLaunchKernelGGL((hp_table_kernel<DB * J>), dim3((unsigned)L), dim3(64), 0, stream, cb64, hp, L);
 #define MOIHGP_GSX_LAUNCH(W_) hipLaunchKernelGGL((grad_scan_x_kernel<TS, DB, J, W_>), grid, block, 0, stream, (const TS*)Ty, Tpar, ld, L, cb64, cbd64, \
-                                                 (TS*)x, (TS*)dx, (TS*)yhat, nll, grad, flags)
+                                                 (TS*)x, (TS*)dx, (TS*)yhat, nll, grad, flags, (const double*)hp)
     if (yhat && out_mode == 2) MOIHGP_GSX_LAUNCH(2);
     else if (yhat) MOIHGP_GSX_LAUNCH(1);
     else MOIHGP_GSX_LAUNCH(0);
@@ -398,13 +422,13 @@ int launch_gsx(const void* Ty, size_t Tpar, size_t ld, size_t L, const double* c
 // The whole chunks [0, Tpar) of every latent's stream; flags[l] = 1 where the latent was left untouched (missing ticks, unusable scan
 // tables), 0 where (x, dx, nll, grad) now hold the state after / the sums over those Tpar ticks.
 int launch_grad_scan_x(int kernel, int dtype, const void* Ty, size_t Tpar, size_t ld, size_t L, const double* cb64, const double* cbd64,
-                       void* x, void* dx, void* yhat, double* nll, double* grad, int* flags, hipStream_t stream, int out_mode) {
+                       void* x, void* dx, void* yhat, double* nll, double* grad, int* flags, double* hp, hipStream_t stream, int out_mode) {
     if (L == 0) return 0;
     const int base = kernel_base(kernel), J = kernel_stack(kernel);
 #define MOIHGP_GSX_CASE(DBB, JJ)                                                                                                        \
     if (base == (DBB == 2 ? 0 : 1) && J == JJ)                                                                                          \
-        return dtype == 0 ? launch_gsx<double, DBB, JJ>(Ty, Tpar, ld, L, cb64, cbd64, x, dx, yhat, nll, grad, flags, stream, out_mode)  \
-                          : launch_gsx<float, DBB, JJ>(Ty, Tpar, ld, L, cb64, cbd64, x, dx, yhat, nll, grad, flags, stream, out_mode)
+        return dtype == 0 ? launch_gsx<double, DBB, JJ>(Ty, Tpar, ld, L, cb64, cbd64, x, dx, yhat, nll, grad, flags, hp, stream, out_mode)  \
+                          : launch_gsx<float, DBB, JJ>(Ty, Tpar, ld, L, cb64, cbd64, x, dx, yhat, nll, grad, flags, hp, stream, out_mode)
     MOIHGP_GSX_CASE(2, 2); MOIHGP_GSX_CASE(2, 3); MOIHGP_GSX_CASE(2, 4);
     MOIHGP_GSX_CASE(3, 2); MOIHGP_GSX_CASE(3, 3); MOIHGP_GSX_CASE(3, 4);
 #undef MOIHGP_GSX_CASE
