@@ -132,7 +132,7 @@ int launch_grad_stream_x(int kernel, int dtype, const void* Ty, size_t T, size_t
                          void* x, void* dx, void* yhat, double* nll, double* grad, hipStream_t stream,
                          int out_mode = 1 /* 1: yhat holds filtered means, 2: predicted means HA x_t (pre-step state) */,
                          int* flags = nullptr /* device [L] */, double* hp = nullptr /* device [L][gradx_hp_len(d)] */
-                         /* with both scratch areas (and nll), streams of >= 512 ticks take the time-parallel sweep */);
+                         /* with both scratch areas, streams of >= 512 ticks take the time-parallel sweep */);
 constexpr size_t gradx_hp_len(int d) { return (size_t)(kChunkX * d + 15) / 16 * 16; }
 // grad_scan_x.hip: the same sweep parallel in time over the stream's whole 32-tick chunks [0, Tpar); flags[l] = 1 marks latents left
 // untouched (missing ticks, unusable scan tables), for the others (x, dx, nll, grad) hold the state after / sums over those ticks.

@@ -117,7 +117,7 @@ grad_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, const 
         if (e < D) x[l * D + e] = (T)st[e];
         else dx[l * P * D + (e - D)] = (T)st[e];
     }
-    if (lane == 0) nll[l] = cont ? nll[l] + acc : acc;
+    if (lane == 0 && nll) nll[l] = cont ? nll[l] + acc : acc;
     if (lane < P) grad[l * P + lane] = cont ? grad[l * P + lane] + g : g;
 }
 
@@ -143,7 +143,7 @@ int launch_grad_stream_x(int kernel, int dtype, const void* Ty, size_t T, size_t
     static const size_t scan_from = [] { const char* e = std::getenv("MOIHGP_GRADX_SCAN_FROM"); return e ? (size_t)std::atoll(e) : (size_t)512; }();
     const int* only = nullptr;
     size_t t_cont = 0;
-    if (flags && hp && nll && T >= scan_from) {
+    if (flags && hp && T >= scan_from) {
         t_cont = T / kChunkX * kChunkX;
         if (int rc = launch_grad_scan_x(kernel, dtype, Ty, t_cont, ld, L, cb64, cbd64, x, dx, yhat, nll, grad, flags, hp, stream, out_mode)) return rc;
         only = flags;
