@@ -173,3 +173,38 @@ def test_c4_two_shards_add_up_to_the_unsharded_total(env):
     _, _, nll = bank.filter(Ty, T=20000, want_yhat=False)
     torch.cuda.synchronize()
     assert abs(nll.sum().item() - tot0) < 1e-6 * abs(tot0)             # (one 2 x 10^4 launch vs two 10^4 slabs: fp32 rounding at the slab seam)
+
+
+# ------------------------------------------------------------------------------------------ gradient sweeps at BASELINE's sizes
+@pytest.mark.parametrize("kern,dtype", [("Matern52x4", torch.float64), ("Matern52x2", torch.float64), ("Matern52", torch.float32)])
+def test_gradient_sweep_at_full_size(env, kern, dtype):
+    """Mode G at the sizes of configs[4] / [1] / [2]: 4096 latents x 10^4 ticks, d = 12 / 6 / 3.  Checks that do not need
+    a full-size oracle run: (1) a 16-latent subset against the oracle (NLL, gradient, final x and dx), (2) a sweep cut in two
+    that carries (x, dx) -- at a tick that is neither a segment nor a chunk boundary -- gives the same final state and, added up,
+    the same NLL and gradient as one sweep (ihgp.h:37-57 is a recursion in (x, dx); :215-219 a sum over ticks)."""
+    import bench
+    L, T = 4096, 10000
+    rng = np.random.default_rng(23)
+    stacked = "x" in kern
+    prm = bench.synth_params(L, 0, rng, kern if stacked else "Matern52ss")
+    bank = env["streams"].LatentBank(0.1, prm, kernel=kern if stacked else "Matern52ss")
+    Ty = rng.standard_normal((L, T))
+    Tyd = torch.from_numpy(Ty).to(dtype).cuda()
+    tol = 1e-9 if dtype == torch.float64 else 2e-4
+    r = bank.grad(Tyd, T=T, want_yhat=False)
+    torch.cuda.synchronize()
+    sub = np.sort(rng.choice(L, size=16, replace=False))
+    o = env["cref"].grad_stream(env["cref"].ihgp_array(kern, 0.1, prm[sub]), np.ascontiguousarray(Ty[sub]), want_yhat=False, nthreads=4)
+    def err(a, b):
+        return float(np.abs(a - b).max() / np.abs(b).max())
+    e = (err(r["nll"][sub].cpu().numpy(), o["nll_per_latent"]), err(r["grad"][sub].cpu().numpy(), o["grad"]),
+         err(r["x"][sub].cpu().numpy(), o["x"]), err(r["dx"][sub].double().cpu().numpy(), o["dx"]))
+    print(f"gradient sweep {kern} {dtype}: subset vs oracle nll {e[0]:.2e} grad {e[1]:.2e} x {e[2]:.2e} dx {e[3]:.2e}")
+    assert max(e) < tol * 10, e
+    cut = 2 * 2048 + 32 * 7 + 4                                        # (rows of both parts stay 16-byte multiples)
+    a = bank.grad(Tyd[:, :cut].contiguous(), T=cut, want_yhat=False)
+    b = bank.grad(Tyd[:, cut:].contiguous(), T=T - cut, x=a["x"].clone(), dx=a["dx"].clone(), want_yhat=False)
+    torch.cuda.synchronize()
+    d = (err((a["nll"] + b["nll"]).cpu().numpy(), r["nll"].cpu().numpy()), err((a["grad"] + b["grad"]).cpu().numpy(), r["grad"].cpu().numpy()),
+         err(b["x"].cpu().numpy(), r["x"].cpu().numpy()), err(b["dx"].double().cpu().numpy(), r["dx"].double().cpu().numpy()))
+    assert max(d) < tol, d
