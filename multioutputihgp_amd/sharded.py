@@ -205,6 +205,43 @@ class ShardedMOIHGP:
         dist.reduce_scatter_tensor(out, pad, op=dist.ReduceOp.SUM, group=self.group)
         return out[:, :hi - lo]
 
+    def _project_with_missing_outputs(self, Y, missing):
+        """The least-squares projection of partially observed ticks (moihgp.h:167-178, `(U0^T U0).ldlt().solve(U0^T y_obs)`) with the
+        latents split over the ranks.  (U0^T U0)^-1 couples ALL latents, so a rank's column slice alone gives a different vector; but U
+        is a polar factor (U^T U = I), hence U0^T U0 = I - Um^T Um with Um the k rows of U at the missing outputs, and by Woodbury
+            a = r + Um^T (I_k - Um Um^T)^-1 Um r,      r = U^T (y with NaN -> 0).
+        r and the correction are column-local; the k x k Gram matrix G = Um Um^T and the k-vector b = Um r are sums over the column
+        shards: ONE all-reduce of sum_t (k_t + k_t^2) doubles for all affected ticks of the stream, then every rank solves the same
+        small systems and corrects its own rows.  (The unsharded device path does the same per tick: csrc/tick.hip ls_project_kernel.)"""
+        from .streams import project_stream
+        Ty = project_stream(self._shard, torch.where(missing, torch.zeros((), dtype=Y.dtype, device=Y.device), Y))
+        aff = missing.any(dim=1).nonzero().flatten()
+        k_t = missing[aff].sum(dim=1)
+        kmax = int(k_t.max())
+        if kmax > 64 or self.M - kmax < self.L:
+            raise NotImplementedError(f"ShardedMOIHGP.filter: a tick with {kmax} of {self.M} outputs missing (limit: 64, and at least "
+                                      f"{self.L} observed) needs the per-tick path")
+        dev = Y.device
+        U = torch.from_numpy(self._full.params[:self.M * self.L].reshape(self.M, self.L)[:, self.lo:self.hi].copy()).to(dev)   # [M, L_r] fp64
+        sqrtS = torch.from_numpy(self.S[self.lo:self.hi] ** 0.5).to(dev)
+        Lr = self.hi - self.lo
+        step = max(1, int(2 ** 28 // max(1, kmax * Lr)))                          # <= 2 GiB of gathered rows at a time
+        for a in range(0, aff.numel(), step):
+            ticks = aff[a:a + step]
+            flag, order = torch.sort(missing[ticks].to(torch.int8), dim=1, descending=True, stable=True)
+            idx, valid = order[:, :kmax], flag[:, :kmax].bool()                   # the missing outputs of every tick, padded to kmax
+            Um = U[idx] * valid[..., None]                                        # [n, kmax, L_r]; padding rows are zero
+            r = Ty[:, ticks].double().T * sqrtS[None, :]                          # [n, L_r] = U_r^T y0 (project_stream scales by S^-1/2)
+            b = torch.bmm(Um, r[..., None])[..., 0]                               # [n, kmax]
+            G = torch.bmm(Um, Um.transpose(1, 2))                                 # [n, kmax, kmax]
+            n = ticks.numel()
+            packed = self._allreduce(torch.cat([b, G.reshape(n, -1)], dim=1))     # the path's extra exchange: n (kmax + kmax^2) doubles
+            b, G = packed[:, :kmax], packed[:, kmax:].reshape(n, kmax, kmax)
+            w = torch.linalg.solve(torch.eye(kmax, dtype=torch.float64, device=dev)[None] - G, b[..., None])   # padding: identity rows
+            corr = torch.bmm(Um.transpose(1, 2), w)[..., 0] / sqrtS[None, :]      # [n, L_r]
+            Ty[:, ticks] += corr.T.to(Ty.dtype)
+        return Ty
+
     def filter(self, Y: torch.Tensor, scatter: bool = False):
         """Y [T, M] (CUDA, fp32/fp64, replicated on every rank).  Returns (Yhat, nll_total) where nll_total is the sum over ticks of
         MOIHGP::negLogLikelihood(x, y) (moihgp.h:614-688) along the filtered trajectory.
@@ -215,12 +252,11 @@ class ShardedMOIHGP:
         from .streams import LatentBank, project_stream, unproject_stream
         import math
         T = Y.shape[0]
-        if self.world > 1 and bool(torch.isnan(Y).any()):
-            # the least-squares projection of a partially observed tick (moihgp.h:167-178) couples ALL latents through (U0^T U0)^-1: a
-            # rank's column slice alone gives a different vector.  (The k x k system of the missing rows would need its Gram matrix and
-            # right-hand side summed over the ranks: one more small all-reduce per affected tick -- not built yet.)
-            raise NotImplementedError("ShardedMOIHGP.filter: observation vectors with missing outputs (NaN) need the unsharded path")
-        Ty = project_stream(self._shard, Y)
+        missing = torch.isnan(Y)
+        if self.world > 1 and bool(missing.any()):
+            Ty = self._project_with_missing_outputs(Y, missing)
+        else:
+            Ty = project_stream(self._shard, Y)
         bank = LatentBank.from_handle(self._shard)
         yhat_lat, _, nll = bank.filter(Ty, T=T)
         part = unproject_stream(self._shard, yhat_lat, T)                 # this rank's partial prediction

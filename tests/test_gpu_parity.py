@@ -589,6 +589,54 @@ def test_sharded_pipeline_two_ranks_vs_oracle(env, M, L, T):
     assert rel_err(Yhat0, yh) < 1e-9 and abs(nll0 - nll) < 1e-9 * abs(nll)
 
 
+def _sharded_missing_worker(rank, world, port, M, L, T, q):
+    import os
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from multioutputihgp_amd.sharded import ShardedMOIHGP
+    rng = np.random.default_rng(5)
+    params = np.concatenate([(np.eye(M, L) + 0.2 * rng.standard_normal((M, L))).ravel(), rng.uniform(0.5, 2, L), [0.04], synth_params(L, rng).ravel()])
+    Y = rng.standard_normal((T, M))
+    Y[rng.random((T, M)) < 0.03] = np.nan                               # a few outputs missing here and there
+    Y[3, :min(5, M - L)] = np.nan                                        # a tick with several missing at once
+    Y[T // 2] = rng.standard_normal(M)                                   # (and fully observed ticks in between)
+    sh = ShardedMOIHGP(0.1, M, L, kernel="Matern32")
+    sh.update(params)
+    Yd = torch.from_numpy(Y).cuda()
+    Yhat, nll = sh.filter(Yd)
+    Ys, _ = sh.filter(Yd, scatter=True)
+    torch.cuda.synchronize()
+    q.put((rank, Yhat.cpu().numpy(), nll, params, Y, Ys.cpu().numpy()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("M,L,T", [(12, 7, 40), (96, 64, 120)])
+def test_sharded_pipeline_with_missing_outputs(env, M, L, T):
+    """Partially observed ticks with the latents split over 2 ranks: the least-squares projection (moihgp.h:167-178) couples all
+    latents; the shards exchange the k x k Gram matrix and right-hand side of the missing rows (one small all-reduce for the whole
+    stream) and must reproduce the oracle's tick-by-tick MOIHGP::step on the full model.  The NLL of such a stream is NaN in the
+    reference (moihgp.h:651 takes the norm of a vector with NaN entries), and here."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_missing_worker, args=(r, 2, port, M, L, T, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
+    for p in procs: p.join(timeout=60)
+    (_, Yhat0, nll0, params, Y, Ys0), (_, Yhat1, nll1, _, _, Ys1) = res
+    assert np.array_equal(Yhat0, Yhat1) and np.isnan(nll0) and np.isnan(nll1)
+    assert rel_err(np.concatenate([Ys0, Ys1]), Yhat0) < 1e-13
+    ref = env["cref"].GP(0.1, M, L, "Matern32"); ref.update(params)
+    x = np.zeros((L, 2)); yh = np.zeros((T, M))
+    for t in range(T):
+        x, yh[t] = ref.step(x, Y[t])
+    assert np.isfinite(Yhat0).all() and rel_err(Yhat0, yh) < 1e-9
+
+
 # ------------------------------------------------------------------------------------------ unstable latents (literal DARE quirk)
 @pytest.mark.parametrize("dtype,T", [(torch.float64, 1500), (torch.float32, 150)])
 @pytest.mark.parametrize("split", ["1", "0"])
