@@ -115,6 +115,41 @@ def gather_latent_grads(grad_local: torch.Tensor, L: int, group=None) -> torch.T
     return torch.cat([o[:n] for o, n in zip(out, sizes)], dim=0)
 
 
+def missing_output_correction(U_r, sqrtS_r, Ty_r, missing, allreduce):
+    """Least-squares projection of partially observed ticks (moihgp.h:167-178, `(U0^T U0).ldlt().solve(U0^T y_obs)`) when the latents
+    are split over ranks.  (U0^T U0)^-1 couples ALL latents, so a rank's column slice alone gives a different vector; but U is a polar
+    factor (U^T U = I), hence U0^T U0 = I - Um^T Um with Um the k rows of U at the missing outputs, and by Woodbury
+        a = r + Um^T (I_k - Um Um^T)^-1 Um r,      r = U^T (y with NaN -> 0).
+    r and the correction are column-local; the k x k Gram matrix G = Um Um^T and the k-vector b = Um r are sums over the column shards:
+    ONE all-reduce of sum_t (k_t + k_t^2) doubles for all affected ticks of the stream, then every rank solves the same small systems
+    and corrects its own rows.  (The unsharded device path does the same per tick: csrc/tick.hip ls_project_kernel.)
+
+    U_r [M, L_r] fp64: this rank's columns;  sqrtS_r [L_r];  Ty_r [L_r, >= T]: S_r^-1/2 U_r^T y0_t in column t, corrected IN PLACE;
+    missing [T, M] bool;  allreduce: tensor -> its sum over the ranks."""
+    aff = missing.any(dim=1).nonzero().flatten()
+    if aff.numel() == 0:
+        return Ty_r
+    kmax = int(missing[aff].sum(dim=1).max())
+    Lr = U_r.shape[1]
+    step = max(1, int(2 ** 28 // max(1, kmax * Lr)))                          # <= 2 GiB of gathered rows at a time
+    eye = torch.eye(kmax, dtype=torch.float64, device=U_r.device)[None]
+    for a in range(0, aff.numel(), step):
+        ticks = aff[a:a + step]
+        flag, order = torch.sort(missing[ticks].to(torch.int8), dim=1, descending=True, stable=True)
+        idx, valid = order[:, :kmax], flag[:, :kmax].bool()                   # the missing outputs of every tick, padded to kmax
+        Um = U_r[idx] * valid[..., None]                                      # [n, kmax, L_r]; padding rows are zero
+        r = Ty_r[:, ticks].double().T * sqrtS_r[None, :]                      # [n, L_r] = U_r^T y0
+        b = torch.bmm(Um, r[..., None])[..., 0]                               # [n, kmax]
+        G = torch.bmm(Um, Um.transpose(1, 2))                                 # [n, kmax, kmax]
+        n = ticks.numel()
+        packed = allreduce(torch.cat([b, G.reshape(n, -1)], dim=1))           # the path's extra exchange: n (kmax + kmax^2) doubles
+        b, G = packed[:, :kmax], packed[:, kmax:].reshape(n, kmax, kmax)
+        w = torch.linalg.solve(eye - G, b[..., None])                         # padding rows / columns: identity
+        corr = torch.bmm(Um.transpose(1, 2), w)[..., 0] / sqrtS_r[None, :]    # [n, L_r]
+        Ty_r[:, ticks] += corr.T.to(Ty_r.dtype)
+    return Ty_r
+
+
 class ShardedMOIHGP:
     """The whole-stream pipeline of one model sharded over the ranks of a process group, one process per GPU
     (SURVEY 8e / 8f N1).
@@ -206,40 +241,18 @@ class ShardedMOIHGP:
         return out[:, :hi - lo]
 
     def _project_with_missing_outputs(self, Y, missing):
-        """The least-squares projection of partially observed ticks (moihgp.h:167-178, `(U0^T U0).ldlt().solve(U0^T y_obs)`) with the
-        latents split over the ranks.  (U0^T U0)^-1 couples ALL latents, so a rank's column slice alone gives a different vector; but U
-        is a polar factor (U^T U = I), hence U0^T U0 = I - Um^T Um with Um the k rows of U at the missing outputs, and by Woodbury
-            a = r + Um^T (I_k - Um Um^T)^-1 Um r,      r = U^T (y with NaN -> 0).
-        r and the correction are column-local; the k x k Gram matrix G = Um Um^T and the k-vector b = Um r are sums over the column
-        shards: ONE all-reduce of sum_t (k_t + k_t^2) doubles for all affected ticks of the stream, then every rank solves the same
-        small systems and corrects its own rows.  (The unsharded device path does the same per tick: csrc/tick.hip ls_project_kernel.)"""
+        """Projection of a stream whose observation vectors hold missing outputs, latents split over the ranks: the column-local
+        projection of (y with NaN -> 0), then `missing_output_correction` (one small all-reduce) on the affected ticks."""
         from .streams import project_stream
         Ty = project_stream(self._shard, torch.where(missing, torch.zeros((), dtype=Y.dtype, device=Y.device), Y))
-        aff = missing.any(dim=1).nonzero().flatten()
-        k_t = missing[aff].sum(dim=1)
-        kmax = int(k_t.max())
+        kmax = int(missing.sum(dim=1).max())
         if kmax > 64 or self.M - kmax < self.L:
             raise NotImplementedError(f"ShardedMOIHGP.filter: a tick with {kmax} of {self.M} outputs missing (limit: 64, and at least "
                                       f"{self.L} observed) needs the per-tick path")
         dev = Y.device
         U = torch.from_numpy(self._full.params[:self.M * self.L].reshape(self.M, self.L)[:, self.lo:self.hi].copy()).to(dev)   # [M, L_r] fp64
         sqrtS = torch.from_numpy(self.S[self.lo:self.hi] ** 0.5).to(dev)
-        Lr = self.hi - self.lo
-        step = max(1, int(2 ** 28 // max(1, kmax * Lr)))                          # <= 2 GiB of gathered rows at a time
-        for a in range(0, aff.numel(), step):
-            ticks = aff[a:a + step]
-            flag, order = torch.sort(missing[ticks].to(torch.int8), dim=1, descending=True, stable=True)
-            idx, valid = order[:, :kmax], flag[:, :kmax].bool()                   # the missing outputs of every tick, padded to kmax
-            Um = U[idx] * valid[..., None]                                        # [n, kmax, L_r]; padding rows are zero
-            r = Ty[:, ticks].double().T * sqrtS[None, :]                          # [n, L_r] = U_r^T y0 (project_stream scales by S^-1/2)
-            b = torch.bmm(Um, r[..., None])[..., 0]                               # [n, kmax]
-            G = torch.bmm(Um, Um.transpose(1, 2))                                 # [n, kmax, kmax]
-            n = ticks.numel()
-            packed = self._allreduce(torch.cat([b, G.reshape(n, -1)], dim=1))     # the path's extra exchange: n (kmax + kmax^2) doubles
-            b, G = packed[:, :kmax], packed[:, kmax:].reshape(n, kmax, kmax)
-            w = torch.linalg.solve(torch.eye(kmax, dtype=torch.float64, device=dev)[None] - G, b[..., None])   # padding: identity rows
-            corr = torch.bmm(Um.transpose(1, 2), w)[..., 0] / sqrtS[None, :]      # [n, L_r]
-            Ty[:, ticks] += corr.T.to(Ty.dtype)
+        missing_output_correction(U, sqrtS, Ty, missing, self._allreduce)
         return Ty
 
     def filter(self, Y: torch.Tensor, scatter: bool = False):

@@ -104,6 +104,26 @@ def _worker8(rank, ws, port, q):
     mine = sh._reduce_scatter_rows(torch.from_numpy(parts[rank].copy()))
     t_lo, t_hi = time_slice_bounds(T, ws, rank)
     ok &= mine.shape == (2, t_hi - t_lo, M) and np.allclose(mine.numpy(), parts.sum(axis=0)[:, t_lo:t_hi], rtol=0, atol=1e-12)
+    # (6) least-squares projection of partially observed ticks with the latents split over the ranks (moihgp.h:167-178): column-local
+    #     terms + one all-reduce of the k x k systems must give the rows of the full model's (U0^T U0)^-1 U0^T y_obs
+    from multioutputihgp_amd.sharded import missing_output_correction
+    M, L, T = 19, 11, 9
+    rng = np.random.default_rng(11)                                     # identical on every rank
+    Uf, _ = np.linalg.qr(rng.standard_normal((M, L)))
+    S = rng.uniform(0.5, 2.0, L)
+    Y = rng.standard_normal((T, M))
+    Y[1, [0, 7]] = np.nan; Y[4, 3] = np.nan; Y[6, [2, 5, 9, 18]] = np.nan; Y[8, 1] = np.nan
+    lo, hi = shard_bounds(L, ws, rank)
+    miss = torch.from_numpy(np.isnan(Y))
+    Ty = torch.from_numpy((Uf[:, lo:hi].T @ np.nan_to_num(Y).T) / np.sqrt(S[lo:hi])[:, None])      # what project_stream hands over
+    sh.group = None
+    missing_output_correction(torch.from_numpy(Uf[:, lo:hi].copy()), torch.from_numpy(np.sqrt(S[lo:hi])), Ty, miss, sh._allreduce)
+    want = np.empty((L, T))
+    for t in range(T):
+        obs = ~np.isnan(Y[t])
+        U0 = Uf[obs]
+        want[:, t] = np.linalg.solve(U0.T @ U0, U0.T @ Y[t, obs]) / np.sqrt(S)
+    ok &= (hi == lo) or bool(np.abs(Ty.numpy() - want[lo:hi]).max() < 1e-11)
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 
