@@ -72,7 +72,7 @@ struct moihgp_gp {
     double *dTy = nullptr, *dUty = nullptr, *dTyhat = nullptr, *dloss = nullptr, *dgrad = nullptr, *dscratch = nullptr;
     double* dwork = nullptr;   // L*L + L, lazily (missing-output projection)
     double* dpolar = nullptr;  // M*L + 2*L*L + 8, lazily (device polar factor)
-    int* dfallback = nullptr;  // [L] flags of latents redone by the sequential gradient kernel
+    int* dfallback = nullptr;  // [2 L + 1] flags of the latents the gradient sweep leaves to its later passes, their compact list, its length
     double* dhp = nullptr;     // [L][gradx_hp_len(d)] HA AKHA^k rows of the stacked models' time-parallel gradient sweep (on first use)
     double* dxscratch = nullptr; // stacked kernels, few latents: per-slice NLL partials
     double* cbd64 = nullptr;     // stacked kernels: sensitivity blocks (XD), fp64; filled once somebody asks for gradients
@@ -213,7 +213,7 @@ static moihgp_gp* gp_create(int kernel, double dt, size_t M, size_t L, bool late
     g->cb64 = dev_alloc<double>(L * cbs);
     g->cb32 = dev_alloc<float>(L * cbs);
     if (kstack) g->cbd64 = dev_alloc<double>(L * (size_t)xd_size(g->d, g->P));
-    g->dfallback = dev_alloc<int>(L);
+    g->dfallback = dev_alloc<int>(2 * L + 1);
     g->dunstable = dev_alloc<int>(2);
     g->igp.resize(L * g->P);
     for (size_t l = 0; l < L; l++) {

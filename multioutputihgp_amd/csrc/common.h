@@ -127,6 +127,9 @@ int launch_filter_stream_x(int kernel, int dtype, const void* Ty, size_t T, size
                            double* scratch = nullptr /* [scratch_len] per-slice NLL partials of the time split */, size_t scratch_len = 0,
                            int force_slices = 0 /* tuning / test hook: 1 = no split, n > 1 = n slices */, size_t ld_out = 0 /* row stride of yhat; 0 = ld */);
 
+// grad_gen.hip: gradient sweep of the latents flagged 1 in fallback[] (missing ticks), scan over the chunks' affine maps; clears the flag
+int launch_grad_gen(int d, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* cb64, const float* cb32, void* x, void* dx,
+                    void* yhat, double* nll, double* grad, int* fallback, hipStream_t stream, int out_mode);
 // grad_x.hip: sensitivity / gradient sweep of the stacked models (needs the XD blocks).
 int launch_grad_stream_x(int kernel, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* cb64, const double* cbd64,
                          void* x, void* dx, void* yhat, double* nll, double* grad, hipStream_t stream,
@@ -152,7 +155,7 @@ void launch_nll_total(const double* nll, size_t L, double* total, hipStream_t st
 void filter_split_plan(int dtype, size_t T, size_t L, int* nsplit, size_t* Tslice, int* nbig /* leading slices of Tslice ticks; the rest hold one segment less */);
 int launch_grad_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, size_t L,
                        const double* cb64, const float* cb32, void* x, void* dx, void* yhat,
-                       double* nll, double* grad, int* fallback /* int[L] scratch */, hipStream_t stream,
+                       double* nll, double* grad, int* fallback /* int[2 L + 1] scratch */, hipStream_t stream,
                        int out_mode = 1 /* 1: yhat holds filtered means, 2: predicted means HA x_t */);
 
 // tick.hip: one-tick kernels behind the reference ABI (all fp64, device pointers).

@@ -22,7 +22,6 @@
 // the scan kernel flags such a latent and grad_seq_kernel (one lane per latent, sequential, loads prefetched in
 // 16-byte vectors) recomputes it.  The reference never feeds a NaN to IHGP through MOIHGP (SURVEY 8a notes).
 #include "kernels_common.h"
-#include <cstdlib>
 #include <type_traits>
 
 #ifndef MOIHGP_GRAD_SPREG
@@ -138,105 +137,9 @@ __device__ inline T tick_mean(const GradConst<T, D>& c, T* xs, T y, T& hx_out) {
     return v;
 }
 
-// One segment that holds missing ticks, walked tick by tick from the chunk-per-lane LDS tile (ihgp.h:37-57 with :212-222 literally,
-// the missing-data branch included).  The (P + 1) D state entries live in registers, one per lane, a quad of lanes per vector:
-// quad 0 holds x, quad p + 1 holds dx_p (lane 4 g + i = entry i; lanes past 4 (P + 1) idle along).  Every lane evaluates its row of
-//     x' = AKHA x + K y  (:50;  A x, :41)        dx_p' = dAKHA_p x + AKHA dx_p + dK_p y  (:54;  dA_p x + A dx_p, :45)
-// from x (v_readlane of quad 0: wave-uniform) and its own quad's vector (DPP quad_perm broadcasts) -- no LDS round trip on the
-// serial chain; the first lane of quad p + 1 carries the `v dv_p` sum, lane 0 the v^2 sum; the outputs replace the observations in
-// the tile.  st (LDS, wave-private): x [D], dx [P][D] in / out, then sum v^2, sum v dv_p [P], n_obs out.
-// A latent with one missing tick in 10^4 used to be handed over whole to grad_seq_kernel (one lane, all 10^4 ticks: 4.7 ms at 4096
-// latents against 0.3 ms clean); now only the segments that hold a gap pay the walk (second pass, MIXED instantiation: the walk's
-// registers must not shape the first pass's allocation -- inlined or called, they took it from 2 waves per SIMD to 1).
-constexpr int kSeqArea = 24;
-template <typename T, int D, int ck>
-__device__ __forceinline__ void grad_segment_seq(const T* __restrict__ cb, typename VecOf<T>::type* lds, int n, int write_mode, double* st) {
-    using Lay = CB<D>;
-    using V = typename VecOf<T>::type;
-    constexpr int EPV = 16 / sizeof(T);
-    static_assert(D + P * D + P + 2 <= kSeqArea && D <= 3, "hand-over area / quad layout");
-    const int lane = threadIdx.x & 63;
-    constexpr int vrow = ck / EPV + 1;                               // vectors per lane row of the padded tile
-    const int g = (lane >> 2) <= P ? (lane >> 2) : 0, i = (lane & 3) < D ? (lane & 3) : 0;
-    const bool live = (lane >> 2) <= P && (lane & 3) < D, isx = g == 0;
-    const int p = isx ? 0 : g - 1;
-    T mo[D], mm[D], dmo[D], dmm[D], ha[D], hda[D];
-#pragma unroll
-    for (int j = 0; j < D; j++) {
-        mo[j] = cb[Lay::AKHA + i * D + j];
-        mm[j] = cb[Lay::A + i * D + j];
-        dmo[j] = isx ? T(0) : cb[Lay::DAKHA + p * D * D + i * D + j];
-        dmm[j] = isx ? T(0) : cb[Lay::DA + p * D * D + i * D + j];
-        ha[j] = cb[Lay::HA + j];
-        hda[j] = cb[Lay::HDA + p * D + j];
-    }
-    const T kc = isx ? cb[Lay::K + i] : cb[Lay::DK + p * D + i];
-    T val = live ? (T)st[isx ? i : D + p * D + i] : T(0);
-    double sv2 = 0.0, svdv = 0.0;
-    unsigned cnt = 0;
-    // one lane row of the tile (a chunk of ck ticks) at a time: its observations come into registers with one LDS wait, the walk
-    // over them is unrolled, the sums of the chunk are formed in the stream's precision as in the scanned segments
-    for (int c0 = 0; c0 < n; c0 += ck) {
-        V* rowp = lds + (size_t)(c0 / ck) * vrow;
-        T yv[ck], out[ck];
-#pragma unroll
-        for (int q = 0; q < ck / EPV; q++) unpack<T>(rowp[q], yv + q * EPV);
-        T cv2 = 0, cvdv = 0;
-#pragma unroll
-        for (int k = 0; k < ck; k++) {
-            out[k] = yv[k];
-            if (c0 + k < n) {                                            // (the ragged last segment is zero padded past the stream's end)
-                const T y = yv[k];
-                T xs[D], bs[D];
-#pragma unroll
-                for (int j = 0; j < D; j++) xs[j] = read_lane(val, j);
-                bs[0] = dpp0<0x00, 0xF>(val);
-                bs[1] = dpp0<0x55, 0xF>(val);
-                if (D > 2) bs[D - 1] = dpp0<0xAA, 0xF>(val);
-                T hx = 0, acc;
-                if (y == y) {
-#pragma unroll
-                    for (int j = 0; j < D; j++) hx = fma(ha[j], xs[j], hx);
-                    const T v = y - hx;
-                    T a = 0, b = 0;
-#pragma unroll
-                    for (int j = 0; j < D; j++) { a = fma(hda[j], xs[j], a); b = fma(ha[j], bs[j], b); }
-                    cv2 = fma(v, v, cv2); cnt++;
-                    cvdv = fma(v, -a - b, cvdv);                         // v dv_p, ihgp.h:218-219 (meaningful in quads 1 .. P)
-                    acc = kc * y;
-#pragma unroll
-                    for (int j = 0; j < D; j++) acc = fma(dmo[j], xs[j], acc);
-#pragma unroll
-                    for (int j = 0; j < D; j++) acc = fma(mo[j], bs[j], acc);
-                } else {
-                    if (write_mode == 2) {
-#pragma unroll
-                        for (int j = 0; j < D; j++) hx = fma(ha[j], xs[j], hx);
-                    }
-                    acc = 0;
-#pragma unroll
-                    for (int j = 0; j < D; j++) acc = fma(dmm[j], xs[j], acc);
-#pragma unroll
-                    for (int j = 0; j < D; j++) acc = fma(mm[j], bs[j], acc);
-                }
-                val = acc;
-                out[k] = (write_mode == 2) ? hx : acc;                   // ihgp.h:51 `yhat = xnew(0, 0)`, or HA x_t
-            }
-        }
-        sv2 += (double)cv2; svdv += (double)cvdv;
-        if (write_mode && lane == 0) {
-#pragma unroll
-            for (int q = 0; q < ck / EPV; q++) rowp[q] = pack<T>(out + q * EPV);
-        }
-    }
-    if (live) st[isx ? i : D + p * D + i] = (double)val;
-    if (lane == 0) { st[D + P * D] = sv2; st[D + P * D + 1 + P] = (double)cnt; }
-    if (live && !isx && i == 0) st[D + P * D + 1 + p] = svdv;
-}
-
 // WRITE: 0 no stream output, 1 filtered means yhat_t = x_{t+1}[0] (ihgp.h:51), 2 predicted means hx_t = HA x_t (pre-step; what
 // MOIHGP::negLogLikelihood needs for `pv`, moihgp.h:505-512)
-template <typename T, int D, int CK, int WRITE, bool MIXED>
+template <typename T, int D, int CK, int WRITE>
 __global__ void __launch_bounds__(64 * kWavesPerBlock, MOIHGP_GRAD_MINW)
 grad_scan_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, const T* __restrict__ cbT,
                  const double* __restrict__ cb64, T* __restrict__ x, T* __restrict__ dx, T* __restrict__ yhat,
@@ -249,13 +152,11 @@ grad_scan_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, con
     static_assert(CK % EPV == 0, "CK must be a multiple of 16 bytes");
     __shared__ V lds_all[kWavesPerBlock][NVP];
     __shared__ T tab_all[kWavesPerBlock][NTAB];
-    __shared__ double seq_all[MIXED ? kWavesPerBlock : 1][kSeqArea];   // hand-over area of a segment walked tick by tick (grad_segment_seq)
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t l = (size_t)blockIdx.x * kWavesPerBlock + wave;
     if (l >= L) return;
-    if (MIXED && fallback[l] != 1) return;                         // second pass: only the latents the first one left for missing ticks
     V* lds = lds_all[wave];
     T* tab = tab_all[wave];
     const T* cb = cbT + l * Lay::SIZE;
@@ -411,45 +312,7 @@ grad_scan_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, con
         bool bad = false;
 #pragma unroll
         for (int i = 0; i < D; i++) bad |= (z[i] != z[i]);
-        if (!MIXED && __any(bad)) { has_nan = true; return; }      // first pass: leave the latent to the second one (or to grad_seq_kernel)
-        if (MIXED && __any(bad)) {
-            // missing ticks in this segment: walk it tick by tick (the observations are still in the tile), then carry on with the scan
-            double* st = seq_all[wave];
-            if (lane == 0) {
-#pragma unroll
-                for (int i = 0; i < D; i++) st[i] = (double)xin[i];
-#pragma unroll
-                for (int p = 0; p < P; p++)
-#pragma unroll
-                    for (int i = 0; i < D; i++) st[D + p * D + i] = (double)dxin[p][i];
-            }
-            wave_lds_fence();
-            const int nt = tail ? (int)(Tlen - tbase) : SEG;
-            grad_segment_seq<T, D, CK>(cb, lds, nt, WRITE, st);
-            wave_lds_fence();
-#pragma unroll
-            for (int i = 0; i < D; i++) xin[i] = (T)st[i];
-#pragma unroll
-            for (int p = 0; p < P; p++)
-#pragma unroll
-                for (int i = 0; i < D; i++) dxin[p][i] = (T)st[D + p * D + i];
-            if (lane == 0) {                                        // (the sums are added up over the lanes at the end)
-                sv2 += st[D + P * D];
-#pragma unroll
-                for (int p = 0; p < P; p++) svdv[p] += st[D + P * D + 1 + p];
-                nobs += (unsigned)st[D + P * D + 1 + P];
-            }
-            if (WRITE) {
-#pragma unroll
-                for (int i = 0; i < VPL; i++) {
-                    const int q = i * 64 + lane;
-                    const size_t tq = tbase + (size_t)q * EPV;
-                    if (!tail || tq < Tlen) nt_store(lds[q + q / VPL], reinterpret_cast<V*>(orow + tq));
-                }
-            }
-            wave_lds_fence();
-            return;
-        }
+        if (__any(bad)) { has_nan = true; return; }                // missing ticks: leave the latent to grad_gen_kernel (second pass)
         {
             T x0[D];
 #pragma unroll
@@ -715,7 +578,11 @@ grad_scan_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, con
     if (nseg > nfull && !has_nan) segment(nfull, std::true_type{});
 
     if (has_nan) {                                                  // nothing has been written for this latent's state yet
-        if (lane == 0) fallback[l] = 1;
+        if (lane == 0) {                                            // flag + a place in the compact list grad_gen_kernel works from
+            fallback[l] = 1;
+            int* list = fallback + L;
+            list[atomicAdd(list + L, 1)] = (int)l;
+        }
         return;
     }
 #pragma unroll
@@ -823,24 +690,17 @@ template <typename T, int D, int CK>
 int launch_grad_t(const T* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, const double* cb64, T* x, T* dx, T* yhat,
                   double* nll, double* grad, int* fallback, int out_mode, hipStream_t stream) {
     dim3 block(64 * kWavesPerBlock), grid((unsigned)((L + kWavesPerBlock - 1) / kWavesPerBlock));
-    constexpr int SEG = 64 * CK;
-    // second pass for latents with missing ticks: the same segment solve with a tick-by-tick walk of the segments that hold a gap.
-    // Built for the long-stream chunk lengths only; a stream of one segment gains nothing from it.
-    constexpr bool kHasMixed = CK == (sizeof(T) == 4 ? 16 : 8);
-    const bool mixed = kHasMixed && Tlen > (size_t)SEG;
-#define MOIHGP_GRAD_LAUNCH(W)                                                                                                              \
-    do {                                                                                                                                   \
-        hipLaunchKernelGGL((grad_scan_kernel<T, D, CK, W, false>), grid, block, 0, stream, Ty, Tlen, ld, L, cbT, cb64, x, dx, yhat, nll, grad, fallback); \
-        if constexpr (kHasMixed) {                                                                                                         \
-            if (mixed)                                                                                                                     \
-                hipLaunchKernelGGL((grad_scan_kernel<T, D, CK, W, true>), grid, block, 0, stream, Ty, Tlen, ld, L, cbT, cb64, x, dx, yhat, nll, grad, fallback); \
-        }                                                                                                                                  \
-    } while (0)
-    if (yhat && out_mode == 2) MOIHGP_GRAD_LAUNCH(2);
-    else if (yhat) MOIHGP_GRAD_LAUNCH(1);
-    else MOIHGP_GRAD_LAUNCH(0);
-#undef MOIHGP_GRAD_LAUNCH
-    // what is still flagged (unstable latents; short streams with missing ticks) is redone sequentially (x / dx were left untouched)
+    (void)hipMemsetAsync(fallback + 2 * L, 0, sizeof(int), stream);     // number of latents left for the second pass
+    if (yhat && out_mode == 2)
+        hipLaunchKernelGGL((grad_scan_kernel<T, D, CK, 2>), grid, block, 0, stream, Ty, Tlen, ld, L, cbT, cb64, x, dx, yhat, nll, grad, fallback);
+    else if (yhat)
+        hipLaunchKernelGGL((grad_scan_kernel<T, D, CK, 1>), grid, block, 0, stream, Ty, Tlen, ld, L, cbT, cb64, x, dx, yhat, nll, grad, fallback);
+    else
+        hipLaunchKernelGGL((grad_scan_kernel<T, D, CK, 0>), grid, block, 0, stream, Ty, Tlen, ld, L, cbT, cb64, x, dx, yhat, nll, grad, fallback);
+    // latents with missing ticks (flag 1): scan over the chunks' affine maps (grad_gen.hip); it clears the flags it has dealt with
+    if (int rc = launch_grad_gen(D, sizeof(T) == 8 ? 0 : 1, Ty, Tlen, ld, L, cb64, sizeof(T) == 8 ? nullptr : reinterpret_cast<const float*>(cbT),
+                                 x, dx, yhat, nll, grad, fallback, stream, out_mode)) return rc;
+    // what is still flagged (unstable latents) is redone sequentially (x / dx were left untouched)
     hipLaunchKernelGGL((grad_seq_kernel<T, D>), dim3((unsigned)((L + 63) / 64)), dim3(64), 0, stream, Ty, Tlen, ld, L, cbT, cb64, x, dx, yhat, nll,
                        grad, (const int*)fallback, out_mode);
     hipError_t e = hipGetLastError();
@@ -850,7 +710,8 @@ int launch_grad_t(const T* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, c
 
 }  // namespace
 
-// fallback: device int[L] scratch (flags of latents with missing ticks)
+// fallback: device int[2 L + 1] scratch: flags of the latents left to the later passes [L], the compact list of those with missing ticks
+// [L] and its length
 int launch_grad_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* cb64,
                        const float* cb32, void* x, void* dx, void* yhat, double* nll, double* grad, int* fallback,
                        hipStream_t stream, int out_mode) {
