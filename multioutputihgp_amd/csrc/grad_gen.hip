@@ -282,7 +282,9 @@ grad_gen_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
             for (int i = 0; i < D; i++) dxs[p][i] = wave_shr1(g.dz[p][i], dxin[p][i]);
 
         // ---- pass 2: replay from the true start state ----
-        T part2 = 0, partdv[P] = {0, 0, 0};
+        // (sums in fp64 also for fp32 streams: a latent whose trajectory leaves fp32's range for v^2 -- the mildly unstable ones of the
+        //  literal DARE that the first pass mistook for streams with gaps -- keeps the finite sums the tick-by-tick kernel gave it)
+        double part2 = 0.0, partdv[P] = {0.0, 0.0, 0.0};
 #pragma unroll 2
         for (int k = 0; k < CK; k++) {
             const T yk = yl[k];
@@ -297,9 +299,10 @@ grad_gen_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
                 for (int i = 0; i < D; i++) dxo[p][i] = dxs[p][i];
             T v, dv[P], hx;
             gen_tick<T, D>(c, xs, dxs, yk, w, v, dv, hx);
-            part2 = fma(v, v, part2);
+            const double vd = (double)v;
+            part2 = fma(vd, vd, part2);
 #pragma unroll
-            for (int p = 0; p < P; p++) partdv[p] = fma(v, dv[p], partdv[p]);
+            for (int p = 0; p < P; p++) partdv[p] = fma(vd, (double)dv[p], partdv[p]);
             nobs += w ? 1u : 0u;
             if (!valid) {                                           // past the end of the stream: the state stays
 #pragma unroll
@@ -311,9 +314,9 @@ grad_gen_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
             }
             if (WRITE) yl[k] = (WRITE == 2) ? hx : xs[0];
         }
-        sv2 += (double)part2;
+        sv2 += part2;
 #pragma unroll
-        for (int p = 0; p < P; p++) svdv[p] += (double)partdv[p];
+        for (int p = 0; p < P; p++) svdv[p] += partdv[p];
         // carried state = state of the lane that owns the last valid tick of the segment
         int jl = 63;
         if (tbase + SEG > Tlen) jl = (int)((Tlen - 1 - tbase) / CK);
