@@ -82,36 +82,49 @@ __device__ inline void replay(const T (&a)[J * DB * DB], const T& ha, const T& k
     wave_lds_fence();
 }
 
-// n ticks of the tile, one after the other, in innovation form: lane i < D owns row i of A, lane D owns HA; per tick every lane
-// forms its row's product with the state, lane D's result is HA x, and an observed tick adds K (y - HA x) (ihgp.h:90 as
-// A x + K (y - HA x); a missing tick is ihgp.h:83-87, x <- A x).  One row per lane: this path must not set the kernel's registers.
-template <typename T, int D, bool WRITE, bool NLL>
-__device__ inline void sequential(const T* __restrict__ c, T* tile, int stride, int n, int head, int lane, T (&xc)[D], double& acc, unsigned& nobs) {
+// n ticks of the tile, one after the other, in innovation form (an observed tick is ihgp.h:90 as A x + K (y - HA x); a missing one
+// ihgp.h:83-87, x <- A x).  One state entry per lane, a QUAD of lanes per component: lane 4 j + r holds entry r of component j and
+// row r of its diagonal block of A.  Per tick a lane forms (A x)_i from its quad (DPP quad_perm broadcasts: DB multiply-adds);
+// H = [H_1 .. H_J] reads the first state of every component, so HA x is the sum over the quads of their lane-0 value of A x -- two
+// row_ror additions inside the wave's first 16-lane row -- and an observed tick adds K (y - HA x).  About a dozen dependent
+// instructions per tick (the first version gathered the whole state with v_readlane against full rows of A: 2 D + ... per tick,
+// 175 ns; this one 40-60 ns).  One entry per lane: this path must not set the kernel's registers.
+template <typename T, int DB, int J, bool WRITE, bool NLL>
+__device__ inline void sequential(const T* __restrict__ c, T* tile, int stride, int n, int head, int lane, T (&xc)[DB * J], double& acc, unsigned& nobs) {
+    constexpr int D = DB * J;
     using Lay = XC<D>;
-    T row[D], kk = 0, xv = 0;
-    const int r = lane < D ? lane : 0;
+    static_assert(J <= 4 && DB <= 3, "one 16-lane row holds the quads");
+    const int jb = (lane >> 2) < J ? (lane >> 2) : 0, r = (lane & 3) < DB ? (lane & 3) : 0;
+    const bool live = (lane >> 2) < J && (lane & 3) < DB;
+    T arow[DB], kk = live ? c[Lay::K + jb * DB + r] : T(0), xv = 0;
 #pragma unroll
-    for (int j = 0; j < D; j++) row[j] = lane < D ? c[Lay::A + r * D + j] : (lane == D ? c[Lay::HA + j] : T(0));
-    if (lane < D) kk = c[Lay::K + r];
+    for (int q = 0; q < DB; q++) arow[q] = live ? c[Lay::AB + jb * DB * DB + r * DB + q] : T(0);
 #pragma unroll
-    for (int i = 0; i < D; i++) if (lane == i) xv = xc[i];
+    for (int i = 0; i < D; i++) if (live && jb * DB + r == i) xv = xc[i];
+    const bool head_lane = live && r == 0;
+    T ynext = tile[0];
 #pragma unroll 1
     for (int t = 0; t < n; t++) {
         T* slot = tile + (t / kChunkX) * stride + (t % kChunkX);
-        const T y = *slot;                                           // same address in every lane: one broadcast read
-        T s = 0;
-#pragma unroll
-        for (int j = 0; j < D; j++) s = fma(row[j], read_lane(xv, j), s);
+        const T y = ynext;                                           // same address in every lane: one broadcast read, one tick ahead
+        const int tn = t + 1 < n ? t + 1 : t;
+        ynext = tile[(tn / kChunkX) * stride + (tn % kChunkX)];
+        T s = arow[0] * dpp0<0x00, 0xF>(xv);
+        s = fma(arow[1], dpp0<0x55, 0xF>(xv), s);
+        if (DB > 2) s = fma(arow[DB - 1], dpp0<0xAA, 0xF>(xv), s);
         if (!(y != y)) {
-            const T v = y - read_lane(s, D);                         // lane D computed HA x
+            T hs = head_lane ? s : T(0);
+            hs += dpp0<0x124, 0xF>(hs);                              // row_ror:4, row_ror:8: the four quads' lane-0 values summed
+            hs += dpp0<0x128, 0xF>(hs);
+            const T v = y - dpp0<0x00, 0xF>(hs);                     // (every lane of a quad reads its lane 0)
             s = fma(kk, v, s);
             if (NLL && lane == 0 && t >= head) { const double vd = (double)v; acc = fma(vd, vd, acc); nobs++; }
         }
         xv = s;
-        if (WRITE) { const T yh = read_lane(s, 0); if (lane == 0) *slot = yh; }
+        if (WRITE && lane == 0) *slot = s;                           // ihgp.h:91 `yhat = xnew(0, 0)`
     }
 #pragma unroll
-    for (int i = 0; i < D; i++) xc[i] = read_lane(xv, i);
+    for (int i = 0; i < D; i++) xc[i] = read_lane(xv, 4 * (i / DB) + i % DB);
 }
 
 // SPLIT (few latents, WPB == 1): workgroup (l, s) of the 2-D grid handles time slice s of latent l.  A slice after the first
@@ -269,7 +282,7 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
                 for (int i = 0; i < D; i++) xc[i] = qnan;
                 if (NLL) acc = __builtin_nan("");
             } else {
-                sequential<T, D, WRITE, NLL>(c, tile, STRIDE, n, head, lane, xc, acc, nobs);
+                sequential<T, DB, J, WRITE, NLL>(c, tile, STRIDE, n, head, lane, xc, acc, nobs);
             }
         } else {
             // ---- carry-in on lane 0, then the 64-lane Kogge-Stone scan with uniform powers ----

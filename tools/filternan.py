@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Filter + NLL sweep with and without missing ticks: kernel time (HIP events).  usage: python tools/filternan.py [kernel ...]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from bench import synth_params, synth_stream, SEED
+from multioutputihgp_amd.streams import LatentBank
+L, T = 4096, 10000
+dev = torch.device("cuda", 0)
+for kern in (sys.argv[1:] or ["Matern52ss", "Matern52x2", "Matern52x4"]):
+    bank = LatentBank(0.1, synth_params(L, 0, np.random.default_rng(SEED), kern), kernel=kern)
+    for dtype in (torch.float64, torch.float32):
+        for nan in (0.0, 0.0001, 0.01, 0.05):
+            Ty = synth_stream(L, 0, T, dtype, dev, SEED + 1)
+            if nan > 0:
+                Ty[torch.rand(Ty.shape, device=dev) < nan] = float("nan")
+            yh = torch.empty_like(Ty); n = torch.empty((L,), dtype=torch.float64, device=dev)
+            x = torch.zeros((L, bank.d), dtype=dtype, device=dev); xz = torch.zeros_like(x)
+            for _ in range(2):
+                bank.filter(Ty, T=T, x=x, x_start=xz, yhat=yh, nll=n)
+            bank.profile_enable(10)
+            for _ in range(10):
+                bank.filter(Ty, T=T, x=x, x_start=xz, yhat=yh, nll=n)
+            torch.cuda.synchronize()
+            ms = float(np.mean(bank.profile_read()))
+            print(f"{kern} d={bank.d} {str(dtype)[6:]} nan={nan}: kernel {ms * 1e3:9.1f} us", flush=True)
