@@ -73,6 +73,7 @@ struct moihgp_gp {
     double* dwork = nullptr;   // L*L + L, lazily (missing-output projection)
     double* dpolar = nullptr;  // M*L + 2*L*L + 8, lazily (device polar factor)
     int* dfallback = nullptr;  // [2 L + 1] flags of the latents the gradient sweep leaves to its later passes, their compact list, its length
+    double* dlink = nullptr;   // [L][144] stacked filter: where the second (broken-link) pass resumes a latent (on first use)
     double* dhp = nullptr;     // [L][gradx_hp_len(d)] HA AKHA^k rows of the stacked models' time-parallel gradient sweep (on first use)
     double* dxscratch = nullptr; // stacked kernels, few latents: per-slice NLL partials
     double* cbd64 = nullptr;     // stacked kernels: sensitivity blocks (XD), fp64; filled once somebody asks for gradients
@@ -103,7 +104,7 @@ struct moihgp_gp {
 
 static void gp_free(moihgp_gp* g) {
     if (!g) return;
-    void* ptrs[] = {g->dU, g->dS, g->dsqrtS, g->dinvsqrtS, g->dsigma, g->dparams, g->cb64, g->cb32, g->dx, g->dpart, g->dTy, g->dUty, g->dTyhat, g->dloss, g->dgrad, g->dscratch, g->dwork, g->dpolar, g->dfallback, g->dwin, g->dunstable, g->dxscratch, g->cbd64, g->dU32, g->dhp};
+    void* ptrs[] = {g->dU, g->dS, g->dsqrtS, g->dinvsqrtS, g->dsigma, g->dparams, g->cb64, g->cb32, g->dx, g->dpart, g->dTy, g->dUty, g->dTyhat, g->dloss, g->dgrad, g->dscratch, g->dwork, g->dpolar, g->dfallback, g->dwin, g->dunstable, g->dxscratch, g->cbd64, g->dU32, g->dhp, g->dlink};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (void* p : g->pinned) (void)hipHostUnregister(p);
@@ -653,8 +654,9 @@ static int filter_stream_io_impl(moihgp_gp* gp, int dtype, const void* Ty, size_
         const size_t slen = gp->L < 1024 ? gp->L * 16 : 0;              // per-slice NLL partials of the time split (few latents only)
         if (slen && !gp->dxscratch) gp->dxscratch = dev_alloc<double>(slen);
         const char* fs = std::getenv("MOIHGP_FILTER_SPLIT");            // tuning / test hook, as for the reference models: 1 = off, n = slices
+        if (gp->L >= 1024 && !gp->dlink) gp->dlink = dev_alloc<double>(gp->L * 144);     // hand-over records of the second (broken-link) pass
         int rc = launch_filter_stream_x(gp->kernel, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cb32, x_in, x, yhat, nll, (hipStream_t)stream, e0, e1,
-                                        gp->dxscratch, slen, fs ? std::atoi(fs) : 0, ld_out);
+                                        gp->dxscratch, slen, fs ? std::atoi(fs) : 0, ld_out, gp->L >= 1024 ? gp->dfallback : nullptr, gp->dlink);
         if (rc == 0 && nll_total) launch_nll_total(nll, gp->L, nll_total, (hipStream_t)stream);
         return rc;
     }

@@ -20,6 +20,7 @@
 // against 16 B of traffic), near the HBM / VALU balance point for D = 6.  DESIGN.md 3.7.
 #include "x_common.h"
 #include <hip/hip_ext.h>
+#include <cstdlib>
 
 namespace moihgp {
 namespace {
@@ -132,11 +133,26 @@ __device__ inline void sequential(const T* __restrict__ c, T* tile, int stride, 
 // through AKHA^(CK 2^nlev) = M^(2^nlev), which the update kernel has flagged as below 1e-20 (1e-10 in fp32) -- the criterion
 // by which the scan already drops its upper levels.  Warm-up ticks are neither counted nor written.  Latents that do not
 // decay that fast (nlev = 6, or unstable) are run whole by slice 0.  Per-slice NLL partials go to nll_part [L][nslice].
-template <typename T, int DB, int J, bool WRITE, bool NLL, int WPB, bool SPLIT>
+
+// LINKS (second pass, many latents only): the first pass (LINKS = false, given link_flags) stops a latent at the first segment whose
+// gaps can be handled as broken links (below: at most max_links chunks with a gap), parks the carried state, the segment's start
+// and the per-lane NLL sums in link_state and flags it; the LINKS = true instantiation resumes exactly those latents there and
+// finishes them (broken links where a segment allows it, the walk where not).  Two instantiations because the broken-link stages
+// keep a second response vector alive next to the scan's: built into the one kernel they took d = 12 fp64 from 256 VGPRs to
+// 256 + 72 AGPRs (one wave per SIMD), for every stream, gaps or not.
+// The first pass hands a latent over at a segment with at most max_links chunks with a gap (launch argument, carried by segs_per_slice:
+// 32, or 3 for fp64 with d > 9, whose second pass runs one wave per SIMD and loses to the walk from ~15 such chunks on); once there, the second pass takes every segment with up to
+// kLinksSecondPass such chunks as broken links: a stage is one scan + one replay (~10 us), the walk ~400 us per segment and, in the
+// second pass, without a second wave to overlap with.  Measured with tools/filternan.py (profiles/r02/filternan_links.log).
+constexpr int kLinksSecondPass = 32;
+constexpr int kLinkState = 144;      // doubles per latent in link_state: x [D], segment start; from 16 on the per-lane sums of v^2 [64], n_obs [64]
+
+template <typename T, int DB, int J, bool WRITE, bool NLL, int WPB, bool SPLIT, bool LINKS>
 __global__ void __launch_bounds__(64 * WPB)
 filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, const T* __restrict__ cbT, const double* __restrict__ cb64,
                 const T* xin0 /* start state */, T* x /* end state; may be the same buffer */, T* __restrict__ yhat, double* __restrict__ nll,
-                int nslice, int segs_per_slice, double* __restrict__ nll_part, size_t ldo /* row stride of yhat */) {
+                int nslice, int segs_per_slice, double* __restrict__ nll_part, size_t ldo /* row stride of yhat */,
+                int* __restrict__ link_flags /* [L] or NULL */, double* __restrict__ link_state /* [L][kLinkState] */) {
     constexpr int D = DB * J;
     using V = typename VecOf<T>::type;
     using Lay = XC<D>;
@@ -158,6 +174,15 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
     for (int i = 0; i < D; i++) xc[i] = xin0[l * D + i];
     double acc = 0.0;
     unsigned nobs = 0;
+    size_t t_resume = 0;
+    if (LINKS) {                                                     // second pass: resume where the first one stopped this latent
+        if (!link_flags[l]) return;
+        const double* st = link_state + l * kLinkState;
+#pragma unroll
+        for (int i = 0; i < D; i++) xc[i] = (T)st[i];
+        t_resume = (size_t)st[D];
+        if (NLL) { acc = st[16 + lane]; nobs = (unsigned)st[80 + lane]; }          // (per-lane partial sums, added up at the end)
+    }
     const bool scan_ok = __builtin_amdgcn_readfirstlane((int)(c[Lay::SCANOK] != T(0))) != 0;
     // The scan powers and the response table are streamed in at the start of every segment (L2-resident, coalesced, issued ahead
     // of the phases that use them) rather than held for the whole sweep: that leaves registers to fetch the NEXT segment of the
@@ -170,7 +195,7 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
     T ha = c[Lay::HA16 + (lane & 15)], kk = c[Lay::K16 + (lane & 15)];
     const int nlev = __builtin_amdgcn_readfirstlane((int)c[Lay::NLEV]);
     // the ticks this wave sweeps: [t_start, t_end), of which [t_begin, t_end) count (everything, unless SPLIT)
-    size_t t_begin = 0, t_end = Tlen, t_start = 0;
+    size_t t_begin = 0, t_end = Tlen, t_start = LINKS ? t_resume : 0;
     bool last = true;
     if (SPLIT) {
         const bool split_ok = scan_ok && nlev <= 5;                  // M^(2^nlev) is in the table and negligible
@@ -263,7 +288,17 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
         });
         const size_t left = t0 + SEG < t_end ? t_end - (t0 + SEG) : 0;
         const int nnext = (int)(left < (size_t)SEG ? left : (size_t)SEG);
-        if (!scan_ok || __builtin_amdgcn_ballot_w64(bad) != 0) {
+        // Chunks (lanes) that hold a missing tick.  Few of them, and a latent the scan can be trusted with: the second pass (LINKS) treats
+        // them as broken links of the chain (below); otherwise (time slices, too: their warm-up bookkeeping assumes whole passes) the
+        // segment is walked tick by tick.  (The two forms of the test below are deliberate: the d = 12 fp64 instantiations sit at
+        // 256 VGPRs exactly, and each of them stays there with one form and tips into AGPRs -- one wave per SIMD -- with the other.)
+        unsigned long long dirty = 0;
+        bool links = false;
+        if constexpr (!SPLIT) {
+            dirty = __builtin_amdgcn_ballot_w64(bad);
+            links = LINKS && scan_ok && dirty != 0 && __builtin_popcountll(dirty) <= kLinksSecondPass;
+        }
+        if (SPLIT ? (!scan_ok || __builtin_amdgcn_ballot_w64(bad) != 0) : (!scan_ok || (dirty != 0 && !links))) {
             fetch(t0 + SEG, nnext);
             __builtin_amdgcn_sched_barrier(0);
             // An unstable latent whose state has left the format (inf / NaN) has nothing finite ahead of it: the rest of its
@@ -282,8 +317,115 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
                 for (int i = 0; i < D; i++) xc[i] = qnan;
                 if (NLL) acc = __builtin_nan("");
             } else {
+                if (!LINKS && !SPLIT && link_flags && scan_ok && __builtin_popcountll(dirty) <= segs_per_slice) {
+                    // first pass: hand the latent over to the second one, from this segment on
+                    double* st = link_state + l * kLinkState;
+                    if (NLL) { st[16 + lane] = acc; st[80 + lane] = (double)nobs; }
+                    if (lane == 0) {
+#pragma unroll
+                        for (int i = 0; i < D; i++) st[i] = (double)xc[i];
+                        st[D] = (double)t0;
+                        link_flags[l] = 1;
+                    }
+                    return;
+                }
                 sequential<T, DB, J, WRITE, NLL>(c, tile, STRIDE, n, head, lane, xc, acc, nobs);
             }
+        } else if (LINKS && links) {
+            // ---- Broken links.  The chunks WITHOUT a gap still move the state by the uniform M = AKHA^32 and their responses z are
+            // the table sums above; a chunk with a gap moves it by a matrix of its own, which nobody forms: the chain is cut there.
+            // Stage by stage: scan the gap-free run [lo, hi) that starts from the carried state, which gives the start state of every
+            // chunk up to and including the one with the gap (hi); replay exactly those chunks, gap-aware (a missing tick is
+            // x <- A x: v = 0, ihgp.h:83-87); the end state of chunk hi is the carried state of the next run.  One scan + one replay
+            // per chunk with a gap, against ~200 ns per tick for the walk: sparse gaps cost little more than none.
+            fetch(t0 + SEG, nnext);
+            __builtin_amdgcn_sched_barrier(0);
+            const int jl = (n - 1) / CK, klast = (n - 1) % CK;       // lane and tick of the segment's last tick
+            T cin[D];
+#pragma unroll
+            for (int i = 0; i < D; i++) cin[i] = xc[i];
+            double part = 0.0;
+            unsigned cnt = 0;
+            int lo = 0;
+#pragma unroll 1
+            for (;;) {
+                const unsigned long long rem = (dirty >> lo) << lo;
+                int hi = rem ? (int)__builtin_ctzll(rem) : jl;
+                if (hi > jl) hi = jl;
+                const bool in_run = lane >= lo && lane < hi;
+                T zz[D], t[D];
+#pragma unroll
+                for (int i = 0; i < D; i++) { zz[i] = in_run ? z[i] : T(0); t[i] = T(0); }   // (z of a chunk with a gap is NaN: never read)
+                if (lo < hi) {
+                    matvec_bc<T, D, NSL>(sp[0], cin, t);
+#pragma unroll
+                    for (int i = 0; i < D; i++) zz[i] += (lane == lo) ? t[i] : T(0);
+#pragma unroll
+                    for (int lv = 0; lv < 6; lv++) {
+                        if (lv >= nlev) break;
+                        const int sh = 1 << lv, addr = ((lane - sh) & 63) * 4;
+#pragma unroll
+                        for (int i = 0; i < D; i++) { const T m = bperm<T>(addr, zz[i]); t[i] = lane >= sh ? m : T(0); }
+                        if (lv < NRES) matvec_bc<T, D, NSL>(sp[lv < NRES ? lv : 0], t, zz);
+                        else {
+                            T hp[NSL];
+                            load_slabs<T, NSL>(cu + Lay::SP + lv * Lay::LS, lane, hp);
+                            matvec_bc<T, D, NSL>(hp, t, zz);
+                        }
+                    }
+                }
+                T xs[D];
+                {
+                    const int addr = ((lane - 1) & 63) * 4;
+#pragma unroll
+                    for (int i = 0; i < D; i++) { const T m = bperm<T>(addr, zz[i]); xs[i] = lane == lo ? cin[i] : m; }
+                }
+                const bool act = lane >= lo && lane <= hi;
+#pragma unroll 1
+                for (int k = 0; k < CK; k++) {
+                    const T y = tile_lane[k];
+                    const bool miss = (y != y);
+                    T h0 = 0, h1 = 0, h2 = 0;
+                    static_for<D>([&](auto ii) {
+                        constexpr int i = decltype(ii)::value;
+                        fmac_bc<i>(i % 3 == 0 ? h0 : (i % 3 == 1 ? h1 : h2), ha, xs[i]);
+                    });
+                    const T v = miss ? T(0) : y - ((h0 + h1) + h2);
+                    if (NLL) {
+                        const bool counted = act && !miss && (lane < jl || k <= klast);
+                        const double vd = counted ? (double)v : 0.0;
+                        part = fma(vd, vd, part);
+                        cnt += counted ? 1u : 0u;
+                    }
+                    T xn[D];
+#pragma unroll
+                    for (int j = 0; j < J; j++)
+#pragma unroll
+                        for (int r = 0; r < DB; r++) {
+                            T sum = ablk[j * DB * DB + r * DB] * xs[j * DB];
+#pragma unroll
+                            for (int q = 1; q < DB; q++) sum = fma(ablk[j * DB * DB + r * DB + q], xs[j * DB + q], sum);
+                            xn[j * DB + r] = sum;
+                        }
+                    static_for<D>([&](auto ii) { fmac_bc<decltype(ii)::value>(xn[decltype(ii)::value], kk, v); });
+#pragma unroll
+                    for (int i = 0; i < D; i++) xs[i] = xn[i];
+                    if (WRITE && act) tile_lane[k] = xn[0];
+                    if (k == klast && lane == jl && act) {             // the state after the segment's last tick
+#pragma unroll
+                        for (int i = 0; i < D; i++) carries[wave][i] = xn[i];
+                    }
+                }
+                if (hi >= jl) break;
+#pragma unroll
+                for (int i = 0; i < D; i++) cin[i] = read_lane(xs[i], hi);
+                lo = hi + 1;
+            }
+            wave_lds_fence();
+#pragma unroll
+            for (int i = 0; i < D; i++) xc[i] = carries[wave][i];
+            wave_lds_fence();
+            if (NLL) { acc += part; nobs += cnt; }
         } else {
             // ---- carry-in on lane 0, then the 64-lane Kogge-Stone scan with uniform powers ----
             T t[D];
@@ -359,14 +501,25 @@ __global__ void __launch_bounds__(256) sum_slices_kernel(const double* __restric
 
 template <typename T, int DB, int J, int WPB, bool SPLIT>
 int launch_x(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, const double* cb64, const void* xin, void* x, void* yhat, double* nll,
-             hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, int nslice, int segs_per_slice, double* nll_part, size_t ldo) {
+             hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, int nslice, int segs_per_slice, double* nll_part, size_t ldo,
+             int* link_flags = nullptr, double* link_state = nullptr) {
     dim3 block(64 * WPB), grid(SPLIT ? (unsigned)L : (unsigned)((L + WPB - 1) / WPB), SPLIT ? (unsigned)nslice : 1u);
     const T* ty = static_cast<const T*>(Ty);
     const T* xi = static_cast<const T*>(xin);
     T* xs = static_cast<T*>(x);
     T* yh = static_cast<T*>(yhat);
-#define MOIHGP_X_LAUNCH(W_, N_) hipExtLaunchKernelGGL((filter_x_kernel<T, DB, J, W_, N_, WPB, SPLIT>), grid, block, 0, stream, ev0, ev1, 0, \
-                                                      ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nslice, segs_per_slice, nll_part, ldo)
+    if (SPLIT) link_flags = nullptr;
+    if (link_flags) (void)hipMemsetAsync(link_flags, 0, L * sizeof(int), stream);
+#define MOIHGP_X_LAUNCH(W_, N_)                                                                                                              \
+    do {                                                                                                                                     \
+        hipExtLaunchKernelGGL((filter_x_kernel<T, DB, J, W_, N_, WPB, SPLIT, false>), grid, block, 0, stream, ev0, ev1, 0,                    \
+                              ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nslice, segs_per_slice, nll_part, ldo, link_flags, link_state);   \
+        if constexpr (!SPLIT) {                                                                                                              \
+            if (link_flags)      /* second pass: the latents stopped at a segment with gaps (none: the grid exits at once) */                 \
+                hipLaunchKernelGGL((filter_x_kernel<T, DB, J, W_, N_, WPB, SPLIT, true>), grid, block, 0, stream,                             \
+                                   ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nslice, segs_per_slice, nll_part, ldo, link_flags, link_state); \
+        }                                                                                                                                    \
+    } while (0)
     if (yhat && nll) MOIHGP_X_LAUNCH(true, true);
     else if (yhat) MOIHGP_X_LAUNCH(true, false);
     else if (nll) MOIHGP_X_LAUNCH(false, true);
@@ -380,9 +533,17 @@ int launch_x(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, con
 
 template <typename T, int DB, int J>
 int launch_xd(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, const double* cb64, const void* xin, void* x, void* yhat, double* nll,
-              hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, double* scratch, size_t scratch_len, int force_slices, size_t ldo) {
+              hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, double* scratch, size_t scratch_len, int force_slices, size_t ldo,
+              int* link_flags, double* link_state) {
     constexpr size_t SEG = 64 * (size_t)kChunkX;
-    if (L >= 1024) return launch_x<T, DB, J, 4, false>(Ty, Tlen, ld, L, cbT, cb64, xin, x, yhat, nll, stream, ev0, ev1, 1, 0, nullptr, ldo);
+    if (L >= 1024) {
+        // chunks with a gap per segment up to which the broken-link stages of the second pass beat the tick-by-tick walk (measured,
+        // tools/filternan.py: a stage costs one scan + one replay, the second pass of the fp64 d = 12 kernel runs one wave per SIMD)
+        static const int env_links = [] { const char* e = std::getenv("MOIHGP_FILTER_MAXLINKS"); return e ? std::atoi(e) : -1; }();
+        const int max_links = env_links >= 0 ? env_links : ((sizeof(T) == 8 && DB * J > 9) ? 3 : 32);
+        return launch_x<T, DB, J, 4, false>(Ty, Tlen, ld, L, cbT, cb64, xin, x, yhat, nll, stream, ev0, ev1, 1, max_links, nullptr, ldo,
+                                            (max_links > 0 && link_state) ? link_flags : nullptr, link_state);
+    }
     // few latents: one wavefront per workgroup, and the stream cut into time slices (one wavefront each) while that adds
     // wavefronts the chip can still use
     const size_t nseg = (Tlen + SEG - 1) / SEG;
@@ -406,16 +567,19 @@ int launch_xd(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, co
 
 int launch_filter_stream_x(int kernel, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* cb64, const float* cb32,
                            const void* xin, void* x, void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1,
-                           double* scratch, size_t scratch_len, int force_slices, size_t ldo) {
+                           double* scratch, size_t scratch_len, int force_slices, size_t ldo, int* link_flags, double* link_state) {
     if (L == 0) return 0;
     if (ldo == 0) ldo = ld;
     const int base = kernel_base(kernel), J = kernel_stack(kernel);
 #define MOIHGP_X_CASE(DBB, JJ)                                                                                        \
     if (base == (DBB == 2 ? 0 : 1) && J == JJ)                                                                        \
-        return dtype == 0 ? launch_xd<double, DBB, JJ>(Ty, T, ld, L, cb64, cb64, xin, x, yhat, nll, stream, ev0, ev1, scratch, scratch_len, force_slices, ldo) \
-                          : launch_xd<float, DBB, JJ>(Ty, T, ld, L, cb32, cb64, xin, x, yhat, nll, stream, ev0, ev1, scratch, scratch_len, force_slices, ldo)
+        return dtype == 0 ? launch_xd<double, DBB, JJ>(Ty, T, ld, L, cb64, cb64, xin, x, yhat, nll, stream, ev0, ev1, scratch, scratch_len, force_slices, ldo, link_flags, link_state) \
+                          : launch_xd<float, DBB, JJ>(Ty, T, ld, L, cb32, cb64, xin, x, yhat, nll, stream, ev0, ev1, scratch, scratch_len, force_slices, ldo, link_flags, link_state)
+#ifndef MOIHGP_X_ONLY_D12        // (development: -DMOIHGP_X_ONLY_D12 builds the d = 12 kernels alone, for quick resource checks)
     MOIHGP_X_CASE(2, 2); MOIHGP_X_CASE(2, 3); MOIHGP_X_CASE(2, 4);
-    MOIHGP_X_CASE(3, 2); MOIHGP_X_CASE(3, 3); MOIHGP_X_CASE(3, 4);
+    MOIHGP_X_CASE(3, 2); MOIHGP_X_CASE(3, 3);
+#endif
+    MOIHGP_X_CASE(3, 4);
 #undef MOIHGP_X_CASE
     set_last_error("stacked kernel id %d is not built", kernel);
     return 1;

@@ -838,6 +838,49 @@ def test_stacked_missing_data_and_slabs(env, kern):
     assert rel_err((na + nb).cpu().numpy(), o["nll_per_latent"]) < FP64_TIGHT and rel_err(xb.cpu().numpy(), o["x"]) < FP64_TIGHT
 
 
+@pytest.mark.parametrize("kern", ["Matern32x2", "Matern52x2", "Matern52x3", "Matern52x4"])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_stacked_filter_gaps_as_broken_links(env, kern, dtype):
+    """With >= 1024 latents the stacked filter handles a segment with few gaps in a second pass that treats the chunks holding them as
+    broken links of the scan (csrc/recursion_x.hip: scan of the gap-free run, gap-aware replay up to and including the chunk with
+    the gap, its end state carried into the next run) instead of walking the segment tick by tick.  Gaps are placed where the
+    stages meet: first and last tick of the stream, first / last tick of a chunk, neighbouring chunks, a whole chunk missing, the
+    ragged last segment, more chunks with a gap than the second pass takes (walked), a series without any observation."""
+    J = int(kern[-1])
+    L, T = 1030, 4500
+    rng = np.random.default_rng(17 + J)
+    prm = synth_params_stacked(L, J, rng)
+    bank = env["streams"].LatentBank(0.1, prm, kernel=kern)
+    Ty = synth(L, T, rng)
+    Ty[1, 0] = np.nan; Ty[2, T - 1] = np.nan
+    Ty[3, [31, 32, 63, 64]] = np.nan                      # chunk ends and starts: neighbouring chunks with a gap
+    Ty[4, 96:128] = np.nan                                # a whole chunk
+    Ty[5, [700, 2100, 2200, 4300, 4490]] = np.nan         # one or two per segment, the ragged one too
+    Ty[6, ::50] = np.nan                                  # 41 chunks with a gap per segment: walked
+    Ty[7, :] = np.nan
+    Ty[8, 2048 - 1] = np.nan; Ty[8, 2048] = np.nan        # both sides of a segment boundary
+    Ty[9, 5::512] = np.nan
+    Ty[100:, :][rng.random((L - 100, T)) < 0.0004] = np.nan          # here and there in most of the others
+    sub = np.concatenate([np.arange(12), np.sort(rng.choice(np.arange(100, L), size=20, replace=False))])
+    o = env["cref"].filter_stream(env["cref"].ihgp_array(kern, 0.1, prm[sub]), np.ascontiguousarray(Ty[sub]), nthreads=4)
+    yhat, xT, nll = bank.filter(to_dev(Ty, dtype), T=T)
+    torch.cuda.synchronize()
+    tol = FP64_TIGHT if dtype == torch.float64 else FP32_TOL
+    tame = np.nan_to_num(np.abs(o["yhat"]), nan=0.0).max(axis=1) < 1e6                 # literal-DARE unstable latents aside
+    yg = yhat[sub][:, :T].cpu().numpy().astype(np.float64)
+    assert rel_err_rows(yg[tame], o["yhat"][tame]) < tol * 10
+    assert rel_err(xT[sub].cpu().numpy()[tame], o["x"][tame]) < tol * 10
+    assert rel_err(nll[sub].cpu().numpy()[tame], o["nll_per_latent"][tame]) < tol * 10 and nll[7].item() == 0.0
+    # the same stream in two slabs that carry the state (cut inside a chunk)
+    cut = 2048 + 32 * 5 + 8
+    Tyd = to_dev(Ty, dtype)
+    ya, xa, na = bank.filter(Tyd[:, :cut].contiguous(), T=cut)
+    yb, xb, nb = bank.filter(Tyd[:, cut:].contiguous(), T=T - cut, x=xa.clone())
+    torch.cuda.synchronize()
+    assert rel_err_rows(torch.cat([ya[:, :cut], yb[:, :T - cut]], 1)[sub].cpu().numpy().astype(np.float64)[tame], o["yhat"][tame]) < tol * 10
+    assert rel_err((na + nb)[sub].cpu().numpy()[tame], o["nll_per_latent"][tame]) < tol * 10
+
+
 @pytest.mark.parametrize("kern,M,L", [("Matern32x2", 6, 3), ("Matern52x2", 8, 8), ("Matern52x4", 9, 4), ("Matern52x3", 150, 70)])
 def test_stacked_full_objects_vs_oracle(env, kern, M, L):
     """BASELINE.json's d = 6 / d = 12 configurations behind the whole MOIHGP surface: a stacked StateSpace in the template slot of
