@@ -92,6 +92,94 @@ __device__ inline void chunk_response(Ptr tab, const double* tile_lane, int lane
     });
 }
 
+// A segment that holds missing ticks, walked tick by tick (ihgp.h:37-57 incl. the missing-data branch, and :215-219) with all
+// P + 1 vectors of the state in registers.  Layout: a 16-lane row holds ONE vector, a quad of lanes per component (lane 4 j + e of
+// the row = entry e of component j); x is replicated in all four rows, the P sensitivities sit in rows and "sets" (registers):
+// dx_p lives in row (p + 1) % 4 of set (p + 1) / 4.  One tick, innovation form with w = 1 observed / 0 missing:
+//     t = A x (the lane's block row against its quad: quad_perm broadcasts);  HA x = sum over the quads of their lane-0 entry of t
+//     (H reads the first state of every component; two row_ror additions);  v = w (y - HA x);  x' = t + K v
+//     u_p = A dx_p + dA_p x;  H u_p = HA dx_p + (H dA_p) x the same way;  dv_p = -w H u_p;  dx_p' = u_p + dK_p v + K dv_p
+// -- no matrix operand leaves the registers.  About 100 instructions per tick for all ten vectors at d = 12 (the tick-by-tick
+// kernel of grad_x.hip fetches ~1200 operands from LDS for the same tick).  Results go where the segment solve puts them: carried
+// vectors in sm.carry, sum v dv_p in sm.gacc, sum v^2 into acc (lane 0), outputs into the tile; nmiss counts the missing ticks.
+template <int DB, int J, int WRITE>
+__device__ inline void walk_segment_x(const double* __restrict__ c, const double* __restrict__ cd, GxLds<DB * J>& sm, int n, int lane,
+                                      double& acc, unsigned& nmiss) {
+    constexpr int D = DB * J, P = 2 * J + 1, CK = kChunkX, STRIDE = GxLds<D>::STRIDE, NSET = (P + 1 + 3) / 4;
+    using Lc = XC<D>;
+    using Ld = XD<D, P>;
+    static_assert(J <= 4 && DB <= 3, "one 16-lane row holds a vector");
+    const int rowi = lane >> 4, jb = ((lane >> 2) & 3) < J ? ((lane >> 2) & 3) : 0, e = (lane & 3) < DB ? (lane & 3) : 0;
+    const bool live = ((lane >> 2) & 3) < J && (lane & 3) < DB;
+    const bool head = live && e == 0;
+    double arow[DB], kx = live ? c[Lc::K + jb * DB + e] : 0.0;
+#pragma unroll
+    for (int q = 0; q < DB; q++) arow[q] = live ? c[Lc::AB + jb * DB * DB + e * DB + q] : 0.0;
+    const double x0 = live ? sm.carry[jb * DB + e] : 0.0;
+    wave_lds_fence();
+    // One set of sensitivities per pass over the segment (x is walked again in every pass: cheap, and three sets at once -- their rows
+    // of dA_p, dK_p, the vectors and the sums -- took the whole kernel from 253 VGPRs into AGPRs, the gap-free path included).
+    // Outputs, sum v^2 and the carried x come from the first pass.
+#pragma unroll 1
+    for (int sidx = 0; sidx < NSET; sidx++) {
+        const int q = 4 * sidx + rowi, p = q - 1;                    // vector q of the state: 0 = x (kept apart), q >= 1: dx_{q-1}
+        const bool has = live && q >= 1 && q <= P;
+        const int ps = has ? p : 0;
+        double darow[DB];
+#pragma unroll
+        for (int qq = 0; qq < DB; qq++) darow[qq] = has ? cd[Ld::DA + ps * D * D + (jb * DB + e) * D + jb * DB + qq] : 0.0;
+        const double dk = has ? cd[Ld::DK + ps * D + jb * DB + e] : 0.0;
+        double dxv = has ? sm.carry[(ps + 1) * D + jb * DB + e] : 0.0, g = 0.0, xv = x0, sv2 = 0.0;
+        unsigned miss_cnt = 0;
+        const bool first = sidx == 0;
+        double ynext = sm.tile[0];
+#pragma unroll 1
+        for (int t = 0; t < n; t++) {
+            double* slot = sm.tile + (t / CK) * STRIDE + (t % CK);
+            const double y = ynext;
+            const int tn = t + 1 < n ? t + 1 : t;
+            ynext = sm.tile[(tn / CK) * STRIDE + (tn % CK)];
+            const bool w = !(y != y);
+            double xb[DB];
+            xb[0] = dpp0<0x00, 0xF>(xv);
+            xb[1] = dpp0<0x55, 0xF>(xv);
+            if (DB > 2) xb[DB - 1] = dpp0<0xAA, 0xF>(xv);
+            double tx = 0.0;
+#pragma unroll
+            for (int qq = 0; qq < DB; qq++) tx = fma(arow[qq], xb[qq], tx);
+            double hs = head ? tx : 0.0;
+            hs += dpp0<0x124, 0xF>(hs);                              // row_ror:4, row_ror:8: the row's quads summed
+            hs += dpp0<0x128, 0xF>(hs);
+            const double hx = dpp0<0x00, 0xF>(hs);                   // (every lane of a quad reads its lane 0: HA x)
+            const double v = w ? y - hx : 0.0;
+            const double xn = fma(kx, v, tx);
+            double u = 0.0;
+            u = fma(arow[0], dpp0<0x00, 0xF>(dxv), u);
+            u = fma(arow[1], dpp0<0x55, 0xF>(dxv), u);
+            if (DB > 2) u = fma(arow[DB - 1], dpp0<0xAA, 0xF>(dxv), u);
+#pragma unroll
+            for (int qq = 0; qq < DB; qq++) u = fma(darow[qq], xb[qq], u);
+            double ds = (head && has) ? u : 0.0;
+            ds += dpp0<0x124, 0xF>(ds);
+            ds += dpp0<0x128, 0xF>(ds);
+            const double dv = w ? -dpp0<0x00, 0xF>(ds) : 0.0;       // -(HA dx_p + (H dA_p) x), ihgp.h:218
+            dxv = has ? fma(kx, dv, fma(dk, v, u)) : 0.0;
+            g = fma(v, dv, g);
+            sv2 = fma(v, v, sv2);
+            miss_cnt += w ? 0u : 1u;
+            xv = live ? xn : 0.0;
+            // (the observation must stay in the tile for the next pass: the outputs go out in the LAST one)
+            if (WRITE && sidx == NSET - 1 && lane == 0) *slot = (WRITE == 2) ? hx : xn;   // HA x_t, or ihgp.h:51 `yhat = xnew(0, 0)`
+        }
+        // ---- back to where the segment solve keeps things (the carried x only once every pass has started from the old one) ----
+        if (has) sm.carry[q * D + jb * DB + e] = dxv;
+        if (has && jb == 0 && e == 0) sm.gacc[q - 1] += g;
+        if (first && lane == 0) { acc += sv2; nmiss += miss_cnt; }
+        if (sidx == NSET - 1 && live && rowi == 0) sm.carry[jb * DB + e] = xv;
+        wave_lds_fence();
+    }
+}
+
 // TS: the stream's type.  WRITE: 0 none, 1 filtered means (ihgp.h:51), 2 predicted means HA x_t.
 template <typename TS, int DB, int J, int WRITE>
 __global__ void __launch_bounds__(64 * kGxWaves)
@@ -129,6 +217,7 @@ grad_scan_x_kernel(const TS* __restrict__ Ty, size_t Tpar /* whole chunks */, si
     const double* __restrict__ hpl = hpg + l * GxLds<D>::HPN;
 
     double acc = 0.0;                                                // per lane: sum of v^2
+    unsigned nmiss = 0;                                              // lane 0: missing ticks met (segments walked tick by tick)
     const double ha = c[Lc::HA16 + (lane & 15)], kk = c[Lc::K16 + (lane & 15)];
 
     for (size_t t0 = 0; t0 < Tpar; t0 += SEG) {
@@ -154,6 +243,7 @@ grad_scan_x_kernel(const TS* __restrict__ Ty, size_t Tpar /* whole chunks */, si
         wave_lds_fence();
 
         double xs[D], rr[D];                                          // start state of the lane's chunk; r of step 3
+        bool walked = false;
         // it = 0: the state itself (steps 1-3); it = p + 1: parameter p (step 4).  One loop so that the scan is instantiated once.
 #pragma unroll 1
         for (int it = 0; it <= P; it++) {
@@ -164,9 +254,10 @@ grad_scan_x_kernel(const TS* __restrict__ Ty, size_t Tpar /* whole chunks */, si
             if (it == 0) {
                 bool bad = false;
                 chunk_response<D>(cu + Lc::G, tile_lane, lane, z, bad);
-                if (__builtin_amdgcn_ballot_w64(bad) != 0) {          // missing ticks: the whole latent goes to the tick-by-tick kernel
-                    if (lane == 0) flags[l] = 1;
-                    return;
+                if (__builtin_amdgcn_ballot_w64(bad) != 0) {          // missing ticks in this segment: walk it, then carry on with the next
+                    walk_segment_x<DB, J, WRITE>(c, cd, sm, n, lane, acc, nmiss);
+                    walked = true;
+                    break;
                 }
             } else {
                 // ---- step 4: replay (x, dz_p) over the chunk from dz = 0 ----
@@ -341,8 +432,9 @@ grad_scan_x_kernel(const TS* __restrict__ Ty, size_t Tpar /* whole chunks */, si
             }
             wave_lds_fence();
         }
-        // ---- step 5: the stream of means ----
+        // ---- step 5: the stream of means (a walked segment has written them already) ----
         if (WRITE) {
+          if (!walked) {
             double xr[D];
 #pragma unroll
             for (int i = 0; i < D; i++) xr[i] = xs[i];
@@ -370,6 +462,7 @@ grad_scan_x_kernel(const TS* __restrict__ Ty, size_t Tpar /* whole chunks */, si
                 for (int i = 0; i < D; i++) xr[i] = xn[i];
                 tile_lane[k] = WRITE == 2 ? (h0 + h1) + h2 : xn[0];   // HA x_t, or ihgp.h:51 `yhat = xnew(0, 0)`
             }
+          }
             wave_lds_fence();
 #pragma unroll
             for (int r = 0; r < CK / EPV; r++) {
@@ -396,7 +489,7 @@ grad_scan_x_kernel(const TS* __restrict__ Ty, size_t Tpar /* whole chunks */, si
         if (e < D) x[l * D + e] = (TS)sm.carry[e];
         else dx[l * P * D + (e - D)] = (TS)sm.carry[e];
     }
-    const double S = c[Lc::S], nobs = (double)Tpar;
+    const double S = c[Lc::S], nobs = (double)Tpar - (double)__shfl(nmiss, 0, 64);
     if (lane == 0 && nll) nll[l] = 0.5 * (acc / S + nobs * c[Lc::LOGS]);
     if (lane < P) grad[l * P + lane] = sm.gacc[lane] / S - 0.5 * (acc / S - nobs) * cd[Ld::DS + lane] / S;   // ihgp.h:219 summed over the ticks
 }

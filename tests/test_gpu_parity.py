@@ -1230,19 +1230,22 @@ def test_stacked_gradstream_vs_oracle(env, kern, dtype, L, T, nanf):
 @pytest.mark.parametrize("kern", STACKED)
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 @pytest.mark.parametrize("L,T,gap", [(3, 512, None), (2, 543, None), (5, 2048, None), (3, 2081, None), (2, 4133, None), (3, 6500, None),
-                                     (4, 2500, 1700), (3, 1024, 0)])
+                                     (4, 2500, 1700), (3, 1024, 0), (3, 4500, [0, 31, 32, 2047, 2048, 4499]), (3, 5000, "dense")])
 def test_stacked_gradstream_long_streams_vs_oracle(env, kern, dtype, L, T, gap):
     """Streams of >= 512 ticks take the time-parallel sweep of the stacked models (grad_scan_x.hip: innovation-form sensitivity
     recursion, chunk-local sensitivities scanned with the filter's own powers): whole 32-tick chunks there, the last T mod 32 ticks
-    and every latent with a missing tick (gap: one NaN in latents 1..) in the tick-by-tick kernel, which must continue / redo
-    seamlessly.  Exactly one segment, one chunk past a segment, several segments, ragged ends."""
+    in the tick-by-tick kernel, which must continue seamlessly; a segment with a missing tick (gap: NaNs in latents 1..) is walked
+    tick by tick inside the sweep (all P + 1 vectors in registers) between segments solved in parallel.  Exactly one segment, one chunk past a segment, several segments, ragged ends."""
     J = int(kern[-1])
     rng = np.random.default_rng(11 * L + T + J)
     prm = synth_params_stacked(L, J, rng)
     bank = env["streams"].LatentBank(0.1, prm, kernel=kern)
     d, P = bank.d, bank.P
     Ty = synth(L, T, rng)
-    if gap is not None:
+    if isinstance(gap, str):
+        Ty[1:, ::37] = np.nan                               # a gap in every segment (and most chunks)
+        Ty[2, :] = np.nan                                   # nothing observed at all
+    elif gap is not None:
         Ty[1:, gap] = np.nan
     x0 = 0.2 * rng.standard_normal((L, d)); dx0 = 0.05 * rng.standard_normal((L, P, d))
     o = env["cref"].grad_stream(env["cref"].ihgp_array(kern, 0.1, prm), Ty, x0=x0, dx0=dx0)
