@@ -218,7 +218,8 @@ def run_c3learn(args, rank, world):
     W = 128
     # roofline of the dominant part: the fp64 MFMA GEMMs of the polar factor (Newton-Schulz: per step one symmetric Gram 2 M L^2 / 2
     # upper tiles + one product 2 M L^2) and of the window (projection, U U^T y, U-gradient: 3 x 2 W M L)
-    ns_steps = 5
+    from multioutputihgp_amd import load_library
+    ns_steps = max(1, int(load_library().moihgp_polar_iterations(gp.handle)))   # what the last update() actually took
     flops = ns_steps * (1.0 * M * L * L + 2.0 * M * L * L) + 3 * 2.0 * W * M * L
     t = rows[W]["evaluation_ms"] * 1e-3
     out = {

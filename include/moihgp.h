@@ -122,6 +122,9 @@ size_t      moihgp_num_latent(moihgp_gp* gp);
  * (see gp32_new above). */
 void        moihgp_set_threading(moihgp_gp* gp, int threading);
 int         moihgp_get_threading(moihgp_gp* gp);
+/* Newton-Schulz steps the last update() / construction took for the polar factor of the mixing (moihgp.h:433-447 computes it by SVD;
+ * DESIGN.md 3.6): one symmetric Gram product and one M x L x L product each.  0 for small models (single-workgroup kernel). */
+int         moihgp_polar_iterations(moihgp_gp* gp);
 
 /* Deterministic counterpart of the ctor's random U (moihgp.h:103-125 uses std::random_device):
  * reseeds and redraws U = polar(I + N(0,1e-3)) from a fixed 64-bit seed. */

@@ -18,7 +18,7 @@ REFERENCE_SYMBOLS = [
 ]
 ADDITIVE_SYMBOLS = [
     "moihgp_last_error", "moihgp_device_count", "moihgp_version", "moihgp_new", "moihgp_del",
-    "moihgp_num_output", "moihgp_num_latent", "moihgp_set_threading", "moihgp_get_threading", "moihgp_reseed_U", "moihgp_new_latents",
+    "moihgp_num_output", "moihgp_num_latent", "moihgp_set_threading", "moihgp_get_threading", "moihgp_polar_iterations", "moihgp_reseed_U", "moihgp_new_latents",
     "moihgp_update_latents", "moihgp_set_mixing", "moihgp_get_latent", "moihgp_filter_stream", "moihgp_filter_stream_io", "moihgp_filter_stream_v2", "moihgp_grad_stream",
     "moihgp_project_stream", "moihgp_unproject_stream", "moihgp_stream_sync",
     "moihgp_profile_enable", "moihgp_profile_stride", "moihgp_profile_read", "moihgp_window_set", "moihgp_window_eval", "moihgp_pin_host_buffer",
@@ -74,6 +74,7 @@ def load_library():
     lib.moihgp_num_latent.restype = C.c_size_t; lib.moihgp_num_latent.argtypes = [C.c_void_p]
     lib.moihgp_set_threading.restype = None; lib.moihgp_set_threading.argtypes = [C.c_void_p, C.c_int]
     lib.moihgp_get_threading.restype = C.c_int; lib.moihgp_get_threading.argtypes = [C.c_void_p]
+    lib.moihgp_polar_iterations.restype = C.c_int; lib.moihgp_polar_iterations.argtypes = [C.c_void_p]
     lib.moihgp_reseed_U.restype = None; lib.moihgp_reseed_U.argtypes = [C.c_void_p, C.c_ulonglong]
     lib.moihgp_new_latents.restype = C.c_void_p
     lib.moihgp_new_latents.argtypes = [C.c_int, C.c_double, C.c_size_t, c_double_p]

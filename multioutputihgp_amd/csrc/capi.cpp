@@ -74,6 +74,7 @@ struct moihgp_gp {
     double* dpolar = nullptr;  // M*L + 2*L*L + 8, lazily (device polar factor)
     int* dfallback = nullptr;  // [2 L + 1] flags of the latents the gradient sweep leaves to its later passes, their compact list, its length
     double* dlink = nullptr;   // [L][144] stacked filter: where the second (broken-link) pass resumes a latent (on first use)
+    int polar_its = 0;         // Newton-Schulz steps of the last device polar factor (0: single-workgroup kernel / none yet)
     double* dhp = nullptr;     // [L][gradx_hp_len(d)] HA AKHA^k rows of the stacked models' time-parallel gradient sweep (on first use)
     double* dxscratch = nullptr; // stacked kernels, few latents: per-slice NLL partials
     double* cbd64 = nullptr;     // stacked kernels: sensitivity blocks (XD), fp64; filled once somebody asks for gradients
@@ -383,6 +384,7 @@ static bool compute_polar(moihgp_gp* g, const double* Uparam) {
         if (!g->dpolar) g->dpolar = dev_alloc<double>(M * L + 2 * L * L + 8 + 3 * L);
         its = polar_factor_device(g->dU, M, L, g->dpolar, g->stream);
     }
+    g->polar_its = its > 0 ? its : 0;
     if (its < 0) return false;
     g->U_host_stale = true;                      // 8*M*L bytes over PCIe only when somebody asks (getParams)
     g->mix_ortho = true;                         // a polar factor
@@ -513,6 +515,7 @@ size_t moihgp_num_output(moihgp_gp* gp) { return gp->M; }
 size_t moihgp_num_latent(moihgp_gp* gp) { return gp->L; }
 void moihgp_set_threading(moihgp_gp* gp, int threading) { if (gp) gp->threading = (gp->L < 2) ? false : (threading != 0); }   // moihgp.h:128-135
 int moihgp_get_threading(moihgp_gp* gp) { return gp && gp->threading ? 1 : 0; }
+int moihgp_polar_iterations(moihgp_gp* gp) { return gp ? gp->polar_its : -1; }
 
 void moihgp_reseed_U(moihgp_gp* gp, unsigned long long seed) {           // (void like the constructor it re-runs: a device failure aborts)
     if (!gp || gp->latents_only) return;
