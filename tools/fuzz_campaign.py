@@ -15,7 +15,7 @@ kerns_f = ["Matern32", "Matern52", "Matern52x2", "Matern32x2", "Matern52x3", "Ma
 for i in range(int(sys.argv[2]) if len(sys.argv) > 2 else 150):
     T = int(rng.choice(Ts + [int(rng.integers(1, 6000))]))
     L = int(rng.integers(1, 12)) if rng.random() < 0.8 else int(rng.integers(1024, 1100))
-    nanf = float(rng.choice([0.0, 0.0, 0.0, 0.01, 0.3]))
+    nanf = float(rng.choice([0.0, 0.0, 0.0, 0.001, 0.01, 0.3]))          # 0.001: sparse gaps (broken links / one walked segment)
     dt_ = "f64" if rng.random() < 0.5 else "f32"
     seed = int(rng.integers(0, 2 ** 31))
     kern = kerns_f[i % len(kerns_f)]
@@ -29,4 +29,10 @@ for i in range(int(sys.argv[2]) if len(sys.argv) > 2 else 150):
             tp.test_gradstream_fuzz_vs_oracle(env, kern, Lg, T, nanf if nanf < 0.3 else 0.02, dt_, seed); n += 1
         except Exception as e:
             nfail += 1; print("GRAD FAIL", kern, Lg, T, nanf, dt_, seed, repr(e)[:200])
+    else:
+        Lg = min(L, 6)
+        try:
+            tp.test_stacked_gradstream_vs_oracle(env, kern, torch.float64 if dt_ == "f64" else torch.float32, Lg, T, nanf if nanf < 0.3 else 0.02); n += 1
+        except Exception as e:
+            nfail += 1; print("STACKED GRAD FAIL", kern, Lg, T, nanf, dt_, repr(e)[:200])
 print("campaign done:", n, "cases,", nfail, "failures")
