@@ -260,6 +260,11 @@ __device__ inline void generic_segment(T* ch, T* xin, const T* cb /* this latent
 //   SLICEMAP = true : no replay and no outputs; xin ends as the state reached from the given start and msl as
 //                     the transition matrix of the whole sweep (x_end = msl * x_start + [x_end from zero]),
 //                     exact also across missing ticks.  Used by the time split below.
+#ifndef MOIHGP_FILTER_PREFETCH
+#define MOIHGP_FILTER_PREFETCH 1
+#endif
+constexpr int kPrefetch = MOIHGP_FILTER_PREFETCH;
+
 template <typename T, int D, int CK, bool WRITE, bool NLL, bool SLICEMAP, int DBG>
 __device__ inline void sweep(const T* __restrict__ row, T* __restrict__ orow, size_t Tlen, T* xin, const FastConst<T, D, CK>& c,
                              const T* __restrict__ cb, typename VecOf<T>::type* lds, int lane, double& acc, unsigned& nobs,
@@ -280,8 +285,12 @@ __device__ inline void sweep(const T* __restrict__ row, T* __restrict__ orow, si
         matmul<T, D>(mfull, mfull, mfull);   // M^64
     }
 
-    V r[VPL];
-    auto load_full = [&](size_t seg) {
+    // Segments in flight ahead of the one being solved: kPrefetch register sets, filled round-robin.  With one set a wave has at most
+    // 4 KB on its way while it computes; a cold stream (nothing of it in the Infinity Cache) then leaves the memory system short of
+    // requests: 16 waves x 4 KB per CU against the ~50 KB per CU that 6.4 TB/s x ~2 us of latency ask for (a plain copy kernel with
+    // one 16-byte element per thread reaches 6.4 TB/s cold on this box, tools/micro/copy_bench.hip).
+    V rs[kPrefetch][VPL];
+    auto load_full = [&](size_t seg, V (&r)[VPL]) {
         const T* p = row + seg * SEG + (size_t)lane * EPV;
 #pragma unroll
         for (int i = 0; i < VPL; i++) {
@@ -289,7 +298,7 @@ __device__ inline void sweep(const T* __restrict__ row, T* __restrict__ orow, si
             else r[i] = *reinterpret_cast<const V*>(p + (size_t)i * 64 * EPV);
         }
     };
-    auto load_tail = [&](size_t seg) {
+    auto load_tail = [&](size_t seg, V (&r)[VPL]) {
         const size_t base = seg * SEG;
 #pragma unroll
         for (int i = 0; i < VPL; i++) {
@@ -303,9 +312,14 @@ __device__ inline void sweep(const T* __restrict__ row, T* __restrict__ orow, si
             r[i] = pack<T>(e);
         }
     };
-    if (nfull > 0) load_full(0); else if (nseg > 0) load_tail(0);
+    auto load_any = [&](size_t seg, V (&r)[VPL]) {
+        if (seg < nfull) load_full(seg, r); else if (seg < nseg) load_tail(seg, r);
+    };
+#pragma unroll
+    for (int q = 0; q < kPrefetch; q++) load_any((size_t)q, rs[q]);
 
-    for (size_t seg = 0; seg < nseg; seg++) {
+    // one segment: its data is in r (on its way since kPrefetch segments ago); r is refilled with segment seg + kPrefetch
+    auto one_segment = [&](const size_t seg, V (&r)[VPL]) {
         const size_t tbase = seg * SEG;
         const size_t t0 = tbase + (size_t)lane * CK;
         // ---- coalesced registers -> LDS -> chunk-per-lane registers ---------------------------
@@ -323,8 +337,8 @@ __device__ inline void sweep(const T* __restrict__ row, T* __restrict__ orow, si
                 V v = lds[lane * (VPL + 1) + k];
                 unpack<T>(v, &y[k * EPV]);
             }
-            // prefetch the next segment: in flight during the arithmetic below
-            if (seg + 1 < nfull) load_full(seg + 1); else if (seg + 1 < nseg) load_tail(seg + 1);
+            // prefetch: in flight during the arithmetic below (and that of the kPrefetch - 1 segments after this one)
+            load_any(seg + kPrefetch, r);
             if (DBG & 1) {                       // tuning probe: staging path only, no arithmetic
                 done = true;
 #pragma unroll
@@ -375,6 +389,11 @@ __device__ inline void sweep(const T* __restrict__ row, T* __restrict__ orow, si
             }
         }
         wave_lds_fence();
+    };
+    for (size_t seg = 0; seg < nseg; seg += kPrefetch) {
+#pragma unroll
+        for (int q = 0; q < kPrefetch; q++)
+            if (seg + q < nseg) one_segment(seg + q, rs[q]);
     }
 }
 
