@@ -32,6 +32,7 @@
 namespace moihgp {
 namespace {
 
+constexpr int kFewGaps = 3;                                          // chunks with a gap per window up to which the window is cut at them (else walked whole)
 constexpr int kGxWaves = 2;                                           // wavefronts per workgroup (LDS: 18.3 KB each)
 
 template <int D> struct GxLds {
@@ -220,10 +221,13 @@ grad_scan_x_kernel(const TS* __restrict__ Ty, size_t Tpar /* whole chunks */, si
     unsigned nmiss = 0;                                              // lane 0: missing ticks met (segments walked tick by tick)
     const double ha = c[Lc::HA16 + (lane & 15)], kk = c[Lc::K16 + (lane & 15)];
 
-    for (size_t t0 = 0; t0 < Tpar; t0 += SEG) {
-        const int n = (int)(Tpar - t0 < (size_t)SEG ? Tpar - t0 : (size_t)SEG);    // a multiple of CK
-        const int nc = n / CK;                                       // chunks (= lanes) in use
-        const bool mine = lane < nc;
+    // A window of up to 64 chunks per turn; it starts wherever the last one ended (a multiple of 32 ticks), which is what lets a gap cut
+    // it short: see step 1.
+    size_t t0 = 0;
+    while (t0 < Tpar) {
+        int n = (int)(Tpar - t0 < (size_t)SEG ? Tpar - t0 : (size_t)SEG);          // a multiple of CK
+        int nc = n / CK;                                             // chunks (= lanes) in use
+        bool mine = lane < nc;
         const uptr<double> cu = launder(c);
         // ---- stage in: coalesced 16-byte loads, chunk-major into the padded tile, zeros past the end ----
 #pragma unroll
@@ -254,10 +258,20 @@ grad_scan_x_kernel(const TS* __restrict__ Ty, size_t Tpar /* whole chunks */, si
             if (it == 0) {
                 bool bad = false;
                 chunk_response<D>(cu + Lc::G, tile_lane, lane, z, bad);
-                if (__builtin_amdgcn_ballot_w64(bad) != 0) {          // missing ticks in this segment: walk it, then carry on with the next
-                    walk_segment_x<DB, J, WRITE>(c, cd, sm, n, lane, acc, nmiss);
-                    walked = true;
-                    break;
+                // Missing ticks in this window.  A few chunks with a gap: solve the gap-free chunks in front of the first of them as a
+                // (shorter) window of their own, walk that one chunk tick by tick in the next turn, and start the turn after it right
+                // behind it -- a gap then costs one more turn and 32 walked ticks instead of a walk of 2048.  Many: walk the window.
+                const unsigned long long dirty = __builtin_amdgcn_ballot_w64(bad && mine);
+                if (dirty != 0) {
+                    const int first = (int)__builtin_ctzll(dirty);
+                    if (__builtin_popcountll(dirty) <= kFewGaps && first > 0) {
+                        nc = first; n = first * CK; mine = lane < nc;      // the prefix; lanes behind it are masked like lanes past the end
+                    } else {
+                        if (__builtin_popcountll(dirty) <= kFewGaps) n = CK;   // first == 0: just the chunk with the gap
+                        walk_segment_x<DB, J, WRITE>(c, cd, sm, n, lane, acc, nmiss);
+                        walked = true;
+                        break;
+                    }
                 }
             } else {
                 // ---- step 4: replay (x, dz_p) over the chunk from dz = 0 ----
@@ -477,6 +491,7 @@ grad_scan_x_kernel(const TS* __restrict__ Ty, size_t Tpar /* whole chunks */, si
             }
         }
         wave_lds_fence();
+        t0 += (size_t)n;
     }
 
     // ---- results: carried (x, dx), NLL and gradient of the ticks swept (grad_x_kernel adds the stream's last T mod 32 ticks) ----
