@@ -157,7 +157,10 @@ int         moihgp_get_latent(moihgp_gp* gp, size_t l, double* A, double* K, dou
  * far on every stream that carried batched work of this handle, so a rewrite never overtakes a sweep that is still in flight,
  * and (b) return only when the new tables are complete, so batched work enqueued afterwards on any stream sees them.  Buffers
  * the caller owns (streams, states, nll, grad) are ordered by the caller's own stream discipline as usual.  A handle is not
- * thread-safe (as the reference object, moihgp.h:431-457 mutates shared matrices): one host thread at a time. */
+ * thread-safe (as the reference object, moihgp.h:431-457 mutates shared matrices): one host thread at a time.
+ * The sweeps also use small scratch areas that belong to the handle (flags and hand-over records of their second passes, per-slice
+ * partial sums): batched work of ONE handle must be ordered among itself -- keep it on one stream, or order the streams with events.
+ * Different handles are independent. */
 
 /* ---- batched recursion over pre-projected streams (DEVICE pointers) -------------------------
  * The stream is SERIES-MAJOR: Ty[l*ld + t], l < L (latents owned by gp), t < T, element type per
