@@ -145,6 +145,8 @@ __device__ inline void sequential(const T* __restrict__ c, T* tile, int stride, 
 // kLinksSecondPass such chunks as broken links: a stage is one scan + one replay (~10 us), the walk ~400 us per segment and, in the
 // second pass, without a second wave to overlap with.  Measured with tools/filternan.py (profiles/r02/filternan_links.log).
 constexpr int kLinksSecondPass = 32;
+constexpr int kPairMaxDim = 6;       // state dims up to which the second pass can scan the chunks' own maps (D x D per lane in registers)
+constexpr int kPairFrom = 2;         // ... and does so for windows with more than this many chunks with a gap
 constexpr int kLinkState = 144;      // doubles per latent in link_state: x [D], segment start; from 16 on the per-lane sums of v^2 [64], n_obs [64]
 
 template <typename T, int DB, int J, bool WRITE, bool NLL, int WPB, bool SPLIT, bool LINKS>
@@ -296,7 +298,7 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
         bool links = false;
         if constexpr (!SPLIT) {
             dirty = __builtin_amdgcn_ballot_w64(bad);
-            links = LINKS && scan_ok && dirty != 0 && __builtin_popcountll(dirty) <= kLinksSecondPass;
+            links = LINKS && scan_ok && dirty != 0 && (D <= kPairMaxDim || __builtin_popcountll(dirty) <= kLinksSecondPass);
         }
         if (SPLIT ? (!scan_ok || __builtin_amdgcn_ballot_w64(bad) != 0) : (!scan_ok || (dirty != 0 && !links))) {
             fetch(t0 + SEG, nnext);
@@ -338,8 +340,8 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
             // chunk up to and including the one with the gap (hi); replay exactly those chunks, gap-aware (a missing tick is
             // x <- A x: v = 0, ihgp.h:83-87); the end state of chunk hi is the carried state of the next run.  One scan + one replay
             // per chunk with a gap, against ~200 ns per tick for the walk: sparse gaps cost little more than none.
-            fetch(t0 + SEG, nnext);
-            __builtin_amdgcn_sched_barrier(0);
+            // (The next window's stream is fetched at the END of this branch: its registers are needed here, and an allocation that
+            // overflows into AGPRs puts v_accvgpr_read in front of the DPP multiply-adds -- the hazard the build checks for.)
             const int jl = (n - 1) / CK, klast = (n - 1) % CK;       // lane and tick of the segment's last tick
             T cin[D];
 #pragma unroll
@@ -347,16 +349,99 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
             double part = 0.0;
             unsigned cnt = 0;
             int lo = 0;
+            // ---- Small states (D <= 6) with more than a couple of such chunks: the chunk maps themselves fit a lane.  Every lane
+            // walks its chunk once with D + 1 vectors -- the response from a zero state and the D unit start states, gap-aware --
+            // which gives its affine map (M_j, z_j); the pairs are scanned over the lanes (Kogge-Stone, lane shifts by ds_bpermute,
+            // identity where a lane has no source), and ONE gap-aware replay from the true start states finishes the window.
+            // ~25 us for a window however many gaps it holds, against one scan + replay (~10 us) per chunk with a gap above.
+            bool use_pairs = false;
+            T xs_pairs[D];
+            if constexpr (D <= kPairMaxDim) {
+                use_pairs = __builtin_popcountll(dirty) > kPairFrom;
+                if (use_pairs) {
+                    T mcol[D][D], zr[D];                             // mcol[c] = M e_c (column c of the chunk's transition matrix)
+#pragma unroll
+                    for (int cidx = 0; cidx < D; cidx++)
+#pragma unroll
+                        for (int i = 0; i < D; i++) mcol[cidx][i] = (i == cidx) ? T(1) : T(0);
+#pragma unroll
+                    for (int i = 0; i < D; i++) zr[i] = T(0);
+                    auto tick_vec = [&](T (&xv)[D], T yin, bool miss) {
+                        T h0 = 0, h1 = 0;
+                        static_for<D>([&](auto ii) { constexpr int i = decltype(ii)::value; fmac_bc<i>(i % 2 == 0 ? h0 : h1, ha, xv[i]); });
+                        const T v = miss ? T(0) : yin - (h0 + h1);
+                        T xn[D];
+#pragma unroll
+                        for (int j = 0; j < J; j++)
+#pragma unroll
+                            for (int r = 0; r < DB; r++) {
+                                T sum = ablk[j * DB * DB + r * DB] * xv[j * DB];
+#pragma unroll
+                                for (int q = 1; q < DB; q++) sum = fma(ablk[j * DB * DB + r * DB + q], xv[j * DB + q], sum);
+                                xn[j * DB + r] = sum;
+                            }
+                        static_for<D>([&](auto ii) { fmac_bc<decltype(ii)::value>(xn[decltype(ii)::value], kk, v); });
+#pragma unroll
+                        for (int i = 0; i < D; i++) xv[i] = xn[i];
+                    };
+#pragma unroll 1
+                    for (int k = 0; k < CK; k++) {
+                        const T y = tile_lane[k];
+                        const bool miss = (y != y);
+                        tick_vec(zr, miss ? T(0) : y, miss);
+#pragma unroll
+                        for (int cidx = 0; cidx < D; cidx++) tick_vec(mcol[cidx], T(0), miss);
+                    }
+                    if (lane == 0) {                                 // the carried state enters through lane 0's map
+#pragma unroll
+                        for (int cidx = 0; cidx < D; cidx++)
+#pragma unroll
+                            for (int i = 0; i < D; i++) zr[i] = fma(mcol[cidx][i], xc[cidx], zr[i]);
+                    }
+#pragma unroll 1
+                    for (int lv = 0; lv < 6; lv++) {
+                        const int sh = 1 << lv, addr = ((lane - sh) & 63) * 4;
+                        const bool has = lane >= sh;
+                        T zp[D], ncol[D][D];
+#pragma unroll
+                        for (int i = 0; i < D; i++) { const T m = bperm<T>(addr, zr[i]); zp[i] = has ? m : T(0); }
+#pragma unroll
+                        for (int cidx = 0; cidx < D; cidx++) {      // new column c = M (partner's column c)
+                            T pc[D];
+#pragma unroll
+                            for (int i = 0; i < D; i++) { const T m = bperm<T>(addr, mcol[cidx][i]); pc[i] = has ? m : ((i == cidx) ? T(1) : T(0)); }
+#pragma unroll
+                            for (int i = 0; i < D; i++) {
+                                T sacc = 0;
+#pragma unroll
+                                for (int q = 0; q < D; q++) sacc = fma(mcol[q][i], pc[q], sacc);
+                                ncol[cidx][i] = sacc;
+                            }
+                        }
+#pragma unroll
+                        for (int q = 0; q < D; q++)
+#pragma unroll
+                            for (int i = 0; i < D; i++) zr[i] = fma(mcol[q][i], zp[q], zr[i]);     // z = M z_p + z (old M)
+#pragma unroll
+                        for (int cidx = 0; cidx < D; cidx++)
+#pragma unroll
+                            for (int i = 0; i < D; i++) mcol[cidx][i] = ncol[cidx][i];
+                    }
+                    const int addr1 = ((lane - 1) & 63) * 4;
+#pragma unroll
+                    for (int i = 0; i < D; i++) { const T m = bperm<T>(addr1, zr[i]); xs_pairs[i] = lane >= 1 ? m : xc[i]; }
+                }
+            }
 #pragma unroll 1
             for (;;) {
                 const unsigned long long rem = (dirty >> lo) << lo;
-                int hi = rem ? (int)__builtin_ctzll(rem) : jl;
+                int hi = (rem && !use_pairs) ? (int)__builtin_ctzll(rem) : jl;
                 if (hi > jl) hi = jl;
                 const bool in_run = lane >= lo && lane < hi;
                 T zz[D], t[D];
 #pragma unroll
                 for (int i = 0; i < D; i++) { zz[i] = in_run ? z[i] : T(0); t[i] = T(0); }   // (z of a chunk with a gap is NaN: never read)
-                if (lo < hi) {
+                if (lo < hi && !use_pairs) {
                     matvec_bc<T, D, NSL>(sp[0], cin, t);
 #pragma unroll
                     for (int i = 0; i < D; i++) zz[i] += (lane == lo) ? t[i] : T(0);
@@ -379,6 +464,12 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
                     const int addr = ((lane - 1) & 63) * 4;
 #pragma unroll
                     for (int i = 0; i < D; i++) { const T m = bperm<T>(addr, zz[i]); xs[i] = lane == lo ? cin[i] : m; }
+                }
+                if constexpr (D <= kPairMaxDim) {
+                    if (use_pairs) {
+#pragma unroll
+                        for (int i = 0; i < D; i++) xs[i] = xs_pairs[i];
+                    }
                 }
                 const bool act = lane >= lo && lane <= hi;
 #pragma unroll 1
@@ -426,6 +517,9 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
             for (int i = 0; i < D; i++) xc[i] = carries[wave][i];
             wave_lds_fence();
             if (NLL) { acc += part; nobs += cnt; }
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(t0 + SEG, nnext);
+            __builtin_amdgcn_sched_barrier(0);
         } else {
             // ---- carry-in on lane 0, then the 64-lane Kogge-Stone scan with uniform powers ----
             T t[D];
@@ -540,7 +634,7 @@ int launch_xd(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, co
         // chunks with a gap per segment up to which the broken-link stages of the second pass beat the tick-by-tick walk (measured,
         // tools/filternan.py: a stage costs one scan + one replay, the second pass of the fp64 d = 12 kernel runs one wave per SIMD)
         static const int env_links = [] { const char* e = std::getenv("MOIHGP_FILTER_MAXLINKS"); return e ? std::atoi(e) : -1; }();
-        const int max_links = env_links >= 0 ? env_links : ((sizeof(T) == 8 && DB * J > 9) ? 3 : 32);
+        const int max_links = env_links >= 0 ? env_links : (DB * J <= kPairMaxDim ? 64 : ((sizeof(T) == 8 && DB * J > 9) ? 3 : 32));
         return launch_x<T, DB, J, 4, false>(Ty, Tlen, ld, L, cbT, cb64, xin, x, yhat, nll, stream, ev0, ev1, 1, max_links, nullptr, ldo,
                                             (max_links > 0 && link_state) ? link_flags : nullptr, link_state);
     }
