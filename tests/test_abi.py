@@ -84,10 +84,11 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
 
 
 def test_no_dpp_hazard_in_device_code(hip_built):
-    """recursion_x.hip's broadcast FMAs are inline-asm DPP instructions: the compiler does not guard those against the GFX9
-    "VALU writes a VGPR, DPP reads it within two issue slots" hazard, so the built gfx950 code is scanned for it."""
+    """The broadcast FMAs of recursion_x.hip and grad_scan_x.hip are inline-asm DPP instructions: the compiler does not guard those
+    against the GFX9 "VALU writes a VGPR, DPP reads it within two issue slots" hazard, so the built gfx950 code is scanned for it."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("check_dpp_hazard", os.path.join(ROOT, "tools", "check_dpp_hazard.py"))
     mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
-    hazards, ndpp = mod.scan(mod.disassemble(os.path.join(ROOT, "build", "obj", "recursion_x.o")))
-    assert ndpp > 1000 and hazards == [], hazards[:5]
+    for obj in ("recursion_x.o", "grad_scan_x.o"):
+        hazards, ndpp = mod.scan(mod.disassemble(os.path.join(ROOT, "build", "obj", obj)))
+        assert ndpp > 1000 and hazards == [], (obj, hazards[:5])
