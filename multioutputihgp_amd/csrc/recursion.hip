@@ -653,9 +653,16 @@ void launch_nll_total(const double* nll, size_t L, double* total, hipStream_t st
 void filter_split_plan(int dtype, size_t T, size_t L, int* nsplit, size_t* Tslice, int* nbig) {
     const size_t seg = 64 * (size_t)(dtype == 0 ? kChunk64 : kChunk32);
     *nsplit = 1; *Tslice = T; *nbig = 1;
-    if (L == 0 || L >= 1024 || T < 2 * seg) return;        // measured: pays below ~1024 latents (1 wave/SIMD)
+    // One workgroup per latent, `want` wavefronts each, and all of them resident at once: the fp64 kernel (171 VGPRs) fits 8 wavefronts
+    // per CU, i.e. one workgroup of 8 (up to 256 latents) or two of 4 (up to 512).  Beyond that the workgroups come in two rounds, and
+    // with 2 or 3 slices the two passes of the split cost as much as the one pass without it.  Measured (tools/micro/split_threshold.py,
+    // T = 10^4, fp64 / fp32 kernel time in us; the plan before this rule in brackets):
+    //    L = 384: 24.0 / 15.7 with 4 slices  (6 slices: 32.9 / 15.9;  no split: 30.1 / 17.7)
+    //    L = 768: 32.4 / 19.1 without split  (3 slices: 42.6 / 20.8)        L = 1023: 33.8 / 19.3  (2 slices: 53.0 / 22.0)
+    if (L == 0 || L > 512 || T < 2 * seg) return;
     size_t want = (2048 + L - 1) / L;                      // aim for >= 2048 wavefronts
     if (want > (size_t)kMaxSplit) want = kMaxSplit;
+    if (L > 256 && want > 4) want = 4;
     const size_t segs = (T + seg - 1) / seg;
     if (want > segs) want = segs;
     if (want < 2) return;
