@@ -211,17 +211,21 @@ int polar_factor_device(double* X, size_t M, size_t L, double* work, hipStream_t
     // ||G||_inf and trace(G) and the iteration falls back to them should the error ever grow.
     hipLaunchKernelGGL(gram_row_stats_kernel, dim3(nbRow), dim3(256), 0, s, G, L, rows);
     hipLaunchKernelGGL(gram_stats_kernel, dim3(1), dim3(256), 0, s, rows, L, stats);
-    double* v = rows;
-    double* y = rows + L;
-    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, s, v, L, 1.0 / sqrt((double)L));
-    for (int it = 0; it < 12; it++) {
-        hipLaunchKernelGGL(symv_kernel, dim3(nbRow), dim3(256), 0, s, (const double*)G, L, (const double*)v, y);
-        hipLaunchKernelGGL(normalize_kernel, dim3(1), dim3(256), 0, s, (const double*)y, L, v, stats);
-    }
     MOIHGP_HIP_FATAL(hipMemcpyAsync(h, stats, sizeof(double) * 4, hipMemcpyDeviceToHost, s));
     MOIHGP_HIP_FATAL(hipStreamSynchronize(s));
     const double bound = fmin(h[0], h[1]);
     if (!(bound > 0.0) || h[0] != h[0]) return -1;
+    if (bound > 2.0) {                    // (an input this close to orthonormal is not scaled at all, below: no estimate needed)
+        double* v = rows;
+        double* y = rows + L;
+        hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, s, v, L, 1.0 / sqrt((double)L));
+        for (int it = 0; it < 12; it++) {
+            hipLaunchKernelGGL(symv_kernel, dim3(nbRow), dim3(256), 0, s, (const double*)G, L, (const double*)v, y);
+            hipLaunchKernelGGL(normalize_kernel, dim3(1), dim3(256), 0, s, (const double*)y, L, v, stats);
+        }
+        MOIHGP_HIP_FATAL(hipMemcpyAsync(h, stats, sizeof(double) * 4, hipMemcpyDeviceToHost, s));
+        MOIHGP_HIP_FATAL(hipStreamSynchronize(s));
+    }
     double s2 = 1.05 * h[3];
     if (!(s2 > 0.0) || s2 > bound) s2 = bound;
     bool used_bound = (s2 == bound);
