@@ -659,8 +659,7 @@ static int filter_stream_io_impl(moihgp_gp* gp, int dtype, const void* Ty, size_
         const char* fs = std::getenv("MOIHGP_FILTER_SPLIT");            // tuning / test hook, as for the reference models: 1 = off, n = slices
         if (gp->L >= 1024 && !gp->dlink) gp->dlink = dev_alloc<double>(gp->L * 144);     // hand-over records of the second (broken-link) pass
         int rc = launch_filter_stream_x(gp->kernel, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cb32, x_in, x, yhat, nll, (hipStream_t)stream, e0, e1,
-                                        gp->dxscratch, slen, fs ? std::atoi(fs) : 0, ld_out, gp->L >= 1024 ? gp->dfallback : nullptr, gp->dlink);
-        if (rc == 0 && nll_total) launch_nll_total(nll, gp->L, nll_total, (hipStream_t)stream);
+                                        gp->dxscratch, slen, fs ? std::atoi(fs) : 0, ld_out, gp->L >= 1024 ? gp->dfallback : nullptr, gp->dlink, nll ? nll_total : nullptr);
         return rc;
     }
     // time split across the wavefronts of a workgroup when there are too few latents to fill the chip

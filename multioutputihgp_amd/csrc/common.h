@@ -126,7 +126,7 @@ int launch_filter_stream_x(int kernel, int dtype, const void* Ty, size_t T, size
                            const void* xin, void* x, void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
                            double* scratch = nullptr /* [scratch_len] per-slice NLL partials of the time split */, size_t scratch_len = 0,
                            int force_slices = 0 /* tuning / test hook: 1 = no split, n > 1 = n slices */, size_t ld_out = 0 /* row stride of yhat; 0 = ld */,
-                           int* link_flags = nullptr /* [L] */, double* link_state = nullptr /* [L][144] */
+                           int* link_flags = nullptr /* [L] */, double* link_state = nullptr /* [L][144] */, double* total = nullptr /* sum of nll[] */
                            /* scratch; with both (L >= 1024): segments with few gaps are handled as broken links by a second pass instead of
                               being walked tick by tick */);
 

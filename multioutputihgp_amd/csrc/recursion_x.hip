@@ -593,10 +593,34 @@ __global__ void __launch_bounds__(256) sum_slices_kernel(const double* __restric
     nll[l] = s;
 }
 
+// The same plus the scalar the optimiser consumes (moihgp.h:684): per-latent sums in slice order, then their total in a fixed order
+// (thread-strided partial sums, a butterfly per wavefront, the wavefront sums in order) -- one workgroup, one launch instead of two.
+__global__ void __launch_bounds__(1024) sum_slices_total_kernel(const double* __restrict__ part, size_t L, int nslice, double* __restrict__ nll,
+                                                                double* __restrict__ total) {
+    __shared__ double red[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double s = 0.0;
+    for (size_t l = tid; l < L; l += 1024) {
+        double v = 0.0;
+        for (int k = 0; k < nslice; k++) v += part[l * nslice + k];
+        nll[l] = v;
+        s += v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 16; w++) t += red[w];
+        *total = t;
+    }
+}
+
 template <typename T, int DB, int J, int WPB, bool SPLIT>
 int launch_x(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, const double* cb64, const void* xin, void* x, void* yhat, double* nll,
              hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, int nslice, int segs_per_slice, double* nll_part, size_t ldo,
-             int* link_flags = nullptr, double* link_state = nullptr) {
+             int* link_flags = nullptr, double* link_state = nullptr, double* total = nullptr) {
     dim3 block(64 * WPB), grid(SPLIT ? (unsigned)L : (unsigned)((L + WPB - 1) / WPB), SPLIT ? (unsigned)nslice : 1u);
     const T* ty = static_cast<const T*>(Ty);
     const T* xi = static_cast<const T*>(xin);
@@ -619,7 +643,9 @@ int launch_x(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, con
     else if (nll) MOIHGP_X_LAUNCH(false, true);
     else MOIHGP_X_LAUNCH(false, false);
 #undef MOIHGP_X_LAUNCH
-    if (SPLIT && nll) hipLaunchKernelGGL(sum_slices_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, stream, nll_part, L, nslice, nll);
+    if (SPLIT && nll && total) hipLaunchKernelGGL(sum_slices_total_kernel, dim3(1), dim3(1024), 0, stream, nll_part, L, nslice, nll, total);
+    else if (SPLIT && nll) hipLaunchKernelGGL(sum_slices_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, stream, nll_part, L, nslice, nll);
+    else if (nll && total) launch_nll_total(nll, L, total, stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_last_error("filter_x_kernel launch: %s", hipGetErrorString(e)); return 2; }
     return 0;
@@ -628,7 +654,7 @@ int launch_x(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, con
 template <typename T, int DB, int J>
 int launch_xd(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, const double* cb64, const void* xin, void* x, void* yhat, double* nll,
               hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, double* scratch, size_t scratch_len, int force_slices, size_t ldo,
-              int* link_flags, double* link_state) {
+              int* link_flags, double* link_state, double* total) {
     constexpr size_t SEG = 64 * (size_t)kChunkX;
     if (L >= 1024) {
         // chunks with a gap per segment up to which the broken-link stages of the second pass beat the tick-by-tick walk (measured,
@@ -636,7 +662,7 @@ int launch_xd(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, co
         static const int env_links = [] { const char* e = std::getenv("MOIHGP_FILTER_MAXLINKS"); return e ? std::atoi(e) : -1; }();
         const int max_links = env_links >= 0 ? env_links : (DB * J <= kPairMaxDim ? 64 : ((sizeof(T) == 8 && DB * J > 9) ? 3 : 32));
         return launch_x<T, DB, J, 4, false>(Ty, Tlen, ld, L, cbT, cb64, xin, x, yhat, nll, stream, ev0, ev1, 1, max_links, nullptr, ldo,
-                                            (max_links > 0 && link_state) ? link_flags : nullptr, link_state);
+                                            (max_links > 0 && link_state) ? link_flags : nullptr, link_state, total);
     }
     // few latents: one wavefront per workgroup, and the stream cut into time slices (one wavefront each) while that adds
     // wavefronts the chip can still use
@@ -653,22 +679,22 @@ int launch_xd(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, co
         const size_t own_min = per * SEG - (size_t)kChunkX * 32;
         n = 1 + (Tlen - per * SEG + own_min - 1) / own_min;
     }
-    if (n * L > scratch_len) return launch_x<T, DB, J, 1, true>(Ty, Tlen, ld, L, cbT, cb64, xin, x, yhat, nll, stream, ev0, ev1, 1, (int)nseg, scratch, ldo);
-    return launch_x<T, DB, J, 1, true>(Ty, Tlen, ld, L, cbT, cb64, xin, x, yhat, nll, stream, ev0, ev1, (int)n, (int)per, scratch, ldo);
+    if (n * L > scratch_len) return launch_x<T, DB, J, 1, true>(Ty, Tlen, ld, L, cbT, cb64, xin, x, yhat, nll, stream, ev0, ev1, 1, (int)nseg, scratch, ldo, nullptr, nullptr, total);
+    return launch_x<T, DB, J, 1, true>(Ty, Tlen, ld, L, cbT, cb64, xin, x, yhat, nll, stream, ev0, ev1, (int)n, (int)per, scratch, ldo, nullptr, nullptr, total);
 }
 
 }  // namespace
 
 int launch_filter_stream_x(int kernel, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* cb64, const float* cb32,
                            const void* xin, void* x, void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1,
-                           double* scratch, size_t scratch_len, int force_slices, size_t ldo, int* link_flags, double* link_state) {
+                           double* scratch, size_t scratch_len, int force_slices, size_t ldo, int* link_flags, double* link_state, double* total) {
     if (L == 0) return 0;
     if (ldo == 0) ldo = ld;
     const int base = kernel_base(kernel), J = kernel_stack(kernel);
 #define MOIHGP_X_CASE(DBB, JJ)                                                                                        \
     if (base == (DBB == 2 ? 0 : 1) && J == JJ)                                                                        \
-        return dtype == 0 ? launch_xd<double, DBB, JJ>(Ty, T, ld, L, cb64, cb64, xin, x, yhat, nll, stream, ev0, ev1, scratch, scratch_len, force_slices, ldo, link_flags, link_state) \
-                          : launch_xd<float, DBB, JJ>(Ty, T, ld, L, cb32, cb64, xin, x, yhat, nll, stream, ev0, ev1, scratch, scratch_len, force_slices, ldo, link_flags, link_state)
+        return dtype == 0 ? launch_xd<double, DBB, JJ>(Ty, T, ld, L, cb64, cb64, xin, x, yhat, nll, stream, ev0, ev1, scratch, scratch_len, force_slices, ldo, link_flags, link_state, total) \
+                          : launch_xd<float, DBB, JJ>(Ty, T, ld, L, cb32, cb64, xin, x, yhat, nll, stream, ev0, ev1, scratch, scratch_len, force_slices, ldo, link_flags, link_state, total)
 #ifndef MOIHGP_X_ONLY_D12        // (development: -DMOIHGP_X_ONLY_D12 builds the d = 12 kernels alone, for quick resource checks)
     MOIHGP_X_CASE(2, 2); MOIHGP_X_CASE(2, 3); MOIHGP_X_CASE(2, 4);
     MOIHGP_X_CASE(3, 2); MOIHGP_X_CASE(3, 3);
