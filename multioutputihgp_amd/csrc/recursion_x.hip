@@ -38,7 +38,9 @@ __device__ inline void replay(const T (&a)[J * DB * DB], const T& ha, const T& k
     const int jl = (n - 1) / kChunkX, klast = (n - 1) % kChunkX;      // lane and tick of the last tick of the segment
     double part = 0.0;
     const bool counted = lane * kChunkX >= head;
-#pragma unroll 1
+    // (unrolled by two: the state ping-pongs between two register sets instead of being copied back every tick -- 12 of the ~85
+    //  instructions of a tick at d = 12)
+#pragma unroll 2
     for (int k = 0; k < kChunkX; k++) {
         const T y = tile_lane[k];
         T h0 = 0, h1 = 0, h2 = 0;                                    // three partial sums of HA x: shorter dependent chains
