@@ -310,8 +310,8 @@ grad_scan_x_kernel(const TS* __restrict__ Ty, size_t Tpar /* whole chunks */, si
                 for (int i = 0; i < D; i++) xr[i] = xs[i];
                 auto replay_p = [&](auto mode_c) {
                     constexpr int MODE = decltype(mode_c)::value - 1;   // (integral_constant of MODE + 1)
-                    // (two ticks per turn, written out: within a turn the state is renamed, not copied; the loop-carried copy of
-                    //  x and dz -- 24 of ~180 instructions of a tick -- is paid once per two ticks)
+                    // (four ticks per turn, written out: within a turn the state is renamed, not copied; the loop-carried copy of
+                    //  x and dz -- 24 of ~180 instructions of a tick -- is paid once per four ticks)
                     auto one_tick = [&](const int k) {
                         const double v = tile_lane[k];
                         double d0 = 0.0, d1 = 0.0, d2 = 0.0;           // dv = -(H dA_p) x - HA dz, three partial sums
@@ -353,7 +353,7 @@ grad_scan_x_kernel(const TS* __restrict__ Ty, size_t Tpar /* whole chunks */, si
                         for (int i = 0; i < D; i++) { xr[i] = xn[i]; z[i] = zn[i]; }
                     };
 #pragma unroll 1
-                    for (int k = 0; k < CK; k += 2) { one_tick(k); one_tick(k + 1); }
+                    for (int k = 0; k < CK; k += 4) { one_tick(k); one_tick(k + 1); one_tick(k + 2); one_tick(k + 3); }
                 };
                 if (mode < 0) replay_p(std::integral_constant<int, 0>{});
                 else if (mode >= J) replay_p(std::integral_constant<int, J + 1>{});
@@ -400,8 +400,7 @@ grad_scan_x_kernel(const TS* __restrict__ Ty, size_t Tpar /* whole chunks */, si
 #pragma unroll
                 for (int i = 0; i < D; i++) xr[i] = xs[i];
                 double part = 0.0;
-#pragma unroll 1
-                for (int k = 0; k < CK; k++) {
+                auto x_tick = [&](const int k) {
                     const double y = tile_lane[k];
                     double h0 = 0.0, h1 = 0.0, h2 = 0.0;
                     static_for<D>([&](auto ii) {
@@ -424,7 +423,9 @@ grad_scan_x_kernel(const TS* __restrict__ Ty, size_t Tpar /* whole chunks */, si
 #pragma unroll
                     for (int i = 0; i < D; i++) xr[i] = xn[i];
                     tile_lane[k] = v;
-                }
+                };
+#pragma unroll 1
+                for (int k = 0; k < CK; k += 2) { x_tick(k); x_tick(k + 1); }
                 acc += part;
                 // ---- step 3: r = sum_k v_k hp_k ----
 #pragma unroll
