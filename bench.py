@@ -12,9 +12,13 @@ latents of a 4096*N-output model (weak scaling, configs[3] at N=8); the only col
 all-reduce of the scalar NLL.  Other configs: --config c1 | c2 | c3f64 | c2d6 | c5 | c4 | c3learn (configs[2] with its outer loop: one
 objective evaluation of the online learner, MOIHGP::update + the windowed NLL/gradient sweep, at M = L = 4096).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c1|c2|c3f64|c2d6|c5|c4|c3learn|c3grad|c5grad] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c1|c2|c3f64|c2d6|c3d6|c3d6f64|c5|c4|c3learn|c3grad|c5grad] [--no-cpu]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+
+`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset) starts the N ranks itself: the parent, which makes
+no GPU call, runs `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process (never exec in place), relays
+rank 0's JSON line and exits with the children's return code.
 """
 from __future__ import annotations
 
@@ -46,6 +50,9 @@ CONFIGS = {
     "c2": (256, 10000, torch.float64, "Matern52ss", "C2: M=L=256, T=10000, Matern-5/2 (d=3), fp64, fixed hyper-parameters, filter+NLL"),
     # stacked state (sum of J Matern-5/2 components): BASELINE.json's d=6 / d=12 shapes; not models of the reference
     "c2d6": (256, 10000, torch.float64, "Matern52x2", "C2 as BASELINE.json words it: M=L=256, T=10000, 2 stacked Matern-5/2 (d=6), fp64, filter+NLL"),
+    # the north-star's "d~6 Matern-5/2" reading of the target shape (M = 4096, T = 10^4), in the target's fp32 and in the reference's fp64
+    "c3d6": (4096, 10000, torch.float32, "Matern52x2", "C3 shape at d=6: M=L=4096, T=10000, 2 stacked Matern-5/2 (d=6), fp32, filter+NLL"),
+    "c3d6f64": (4096, 10000, torch.float64, "Matern52x2", "C3 shape at d=6 in fp64: M=L=4096, T=10000, 2 stacked Matern-5/2 (d=6), fp64, filter+NLL"),
     "c5": (4096, 10000, torch.float64, "Matern52x4", "C5: M=L=4096, T=10000, 4 stacked Matern-5/2 (d=12), fp64, filter+NLL (VALU-bound)"),
     # one GPU's shard of BASELINE.json configs[3] (32768 latents over 8 GPUs, T = 1e5): the stream is swept in 1e4-tick slabs that
     # carry the state, the way a stream that does not fit would be fed
@@ -183,14 +190,17 @@ def run_c1(args, rank, world):
     print(json.dumps(out), flush=True)
 
 
-def run_c3learn(args, rank, world):
+def learn_row(steps, warmup, cpu=True, windows=(16, 128)):
     """BASELINE.json configs[2] as worded: "M=4096 outputs, T=10000, Matern-5/2, fp32, online-learning L-BFGS outer loop".  The
     optimiser stays on the host (north_star); what it calls per line-search point is ONE objective evaluation
     (moihgp_online.h:40-72, online_learning.py:74-98):  MOIHGP::update(params) -- polar factor of the M x L mixing + IHGP::update of
     every latent -- then the window loop of W ticks (step with sensitivities + NLL gradient per tick).  A step of this bench = one
     such evaluation at M = L = 4096 (gp52 surface of include/moihgp.h: gpXX_update + moihgp_window_eval), fp64 like the reference's
-    learner arithmetic; value = Kalman steps (L x W) per second of whole evaluations, for W in {16, 128}."""
-    from multioutputihgp_amd import MOIHGP
+    learner arithmetic; value = Kalman steps (L x W) per second of whole evaluations, for W in {16, 128}.  Two forms are
+    timed: the reference ABI's (host parameter / gradient vectors: 2 x 134 MB over PCIe per evaluation) and the device-resident one
+    (moihgp_update_dev + moihgp_window_eval_dev: parameters and gradient stay in HBM, what an optimiser that keeps theta, g and its
+    history on the GPU pays)."""
+    from multioutputihgp_amd import MOIHGP, load_library
     M = L = 4096
     rng = np.random.default_rng(SEED)
     gp = MOIHGP(0.1, M, L, kernel="Matern52ss")
@@ -200,9 +210,14 @@ def run_c3learn(args, rank, world):
     p[M * L + L + 1:] = synth_params(L, 0, rng).ravel()
     d = gp.igp_dim
     x = np.zeros((L, d)); dx = np.zeros((L, 3, d))
-    steps = max(1, min(args.steps, 10)); warm = max(1, min(args.warmup, 2))
+    steps = max(1, min(steps, 10)); warm = max(1, min(warmup, 2))
+    dev = torch.device("cuda", torch.cuda.current_device())
+    have_dev = hasattr(gp, "update_dev")
+    if have_dev:
+        p_dev = torch.from_numpy(p).to(dev); g_dev = torch.empty_like(p_dev); loss_dev = torch.zeros(1, dtype=torch.float64, device=dev)
+        x_dev = torch.zeros((L, d), dtype=torch.float64, device=dev); dx_dev = torch.zeros((L, 3, d), dtype=torch.float64, device=dev)
     rows = {}
-    for W in (16, 128):
+    for W in windows:
         Y = 0.5 * rng.standard_normal((W, M))
         for _ in range(warm):
             gp.update(p); gp.window_objective(Y, x, dx)
@@ -215,27 +230,44 @@ def run_c3learn(args, rank, world):
         t_upd /= steps; t_ev /= steps
         rows[W] = dict(update_ms=t_upd * 1e3, window_eval_ms=t_ev * 1e3, evaluation_ms=(t_upd + t_ev) * 1e3,
                        kalman_steps_per_s=L * W / (t_upd + t_ev), loss=float(loss))
-    W = 128
+        if have_dev:
+            for _ in range(warm):
+                gp.update_dev(p_dev); gp.window_objective_dev(x_dev, dx_dev, loss_dev, g_dev)
+            torch.cuda.synchronize()
+            t_upd = t_ev = 0.0
+            for _ in range(steps):
+                t0 = time.perf_counter(); gp.update_dev(p_dev); torch.cuda.synchronize(); t1 = time.perf_counter()
+                gp.window_objective_dev(x_dev, dx_dev, loss_dev, g_dev); torch.cuda.synchronize(); t2 = time.perf_counter()
+                t_upd += t1 - t0; t_ev += t2 - t1
+            t_upd /= steps; t_ev /= steps
+            rows[W]["device_resident"] = dict(update_ms=t_upd * 1e3, window_eval_ms=t_ev * 1e3, evaluation_ms=(t_upd + t_ev) * 1e3,
+                                              kalman_steps_per_s=L * W / (t_upd + t_ev), loss=float(loss_dev.item()),
+                                              grad_max_abs_diff_vs_host_path=float((g_dev.cpu().numpy() - grad).__abs__().max()))
+    W = windows[-1]
     # roofline of the dominant part: the fp64 MFMA GEMMs of the polar factor (Newton-Schulz: per step one symmetric Gram 2 M L^2 / 2
     # upper tiles + one product 2 M L^2) and of the window (projection, U U^T y, U-gradient: 3 x 2 W M L)
-    from multioutputihgp_amd import load_library
     ns_steps = max(1, int(load_library().moihgp_polar_iterations(gp.handle)))   # what the last update() actually took
     flops = ns_steps * (1.0 * M * L * L + 2.0 * M * L * L) + 3 * 2.0 * W * M * L
-    t = rows[W]["evaluation_ms"] * 1e-3
+    best = rows[W]["device_resident"] if have_dev else rows[W]
+    t = best["evaluation_ms"] * 1e-3
     out = {
         "metric": "Kalman steps/sec (M outputs x T ticks) + NLL rel-err vs CPU oracle",
-        "value": rows[W]["kalman_steps_per_s"], "unit": "Kalman steps/s", "n_gpus": 1, "steps": steps, "warmup": warm,
-        "ms_per_step": rows[W]["evaluation_ms"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "C3-learn: one objective evaluation of the online learner at M=L=4096, Matern-5/2 (d=3), window W=128: "
-                               "gp52_update (device polar factor + IHGP::update x 4096) + moihgp_window_eval (projection, sensitivity sweep, NLL gradient)",
+        "value": best["kalman_steps_per_s"], "unit": "Kalman steps/s", "n_gpus": 1, "steps": steps, "warmup": warm,
+        "ms_per_step": best["evaluation_ms"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"C3-learn: one objective evaluation of the online learner at M=L=4096, Matern-5/2 (d=3), window W={W}: "
+                               "gp52_update (device polar factor + IHGP::update x 4096) + moihgp_window_eval (projection, sensitivity sweep, NLL gradient)"
+                               + ("; parameters and gradient device-resident (moihgp_update_dev / moihgp_window_eval_dev)" if have_dev else ""),
                    "latents_total": L, "outputs": M, "window": W, "state_dim": d, "gradient_entries": int(gp.num_param)},
         "roofline": {"bound": "mfma", "achieved": flops / t / 1e12, "peak": 78.6, "unit": "TFLOP/s", "frac": flops / t / 1e12 / 78.6, "traffic": None,
                      "kernel": "gemm_mfma (polar factor Newton-Schulz + window GEMMs)", "kernel_ms": None,
+                     "update_ms": best["update_ms"], "window_eval_ms": best["window_eval_ms"],
+                     "host_path_evaluation_ms": rows[W]["evaluation_ms"],
                      "note": f"flops = {ns_steps} Newton-Schulz steps x (M L^2 Gram upper tiles + 2 M L^2 product) + 3 window GEMMs of 2 W M L, over the WALL time of a whole "
-                             "evaluation (host staging of the 134 MB parameter / gradient vectors over PCIe included); fp64 MFMA dense peak"},
+                             "evaluation" + (" (device-resident form; host_path_evaluation_ms = the reference ABI's form, 2 x 134 MB over PCIe included)" if have_dev
+                                             else " (host staging of the 134 MB parameter / gradient vectors over PCIe included)") + "; fp64 MFMA dense peak"},
         "windows": {str(k): v for k, v in rows.items()},
     }
-    if not args.no_cpu:
+    if cpu:
         # the oracle's own loop on a stated subsample: the reference's form is O(M^3 L^2) per tick (literal U-gradient) and its polar
         # factor an SVD; the oracle runs the closed-form U-gradient and a one-sided Jacobi SVD on 1 core
         from oracle import cref
@@ -254,28 +286,29 @@ def run_c3learn(args, rank, world):
                                    sample=f"one evaluation at M=L={Ms}, W={Ws} (update + {Ws} x (negLogLikelihood with gradient + step)), oracle/moihgp_oracle.c through ctypes, "
                                           "closed-form U-gradient; the GPU line is M=L=4096")
         out["speedup_vs_cpu_all_cores"] = None
-    print(json.dumps(out), flush=True)
+    del gp
+    return out
 
 
-def run_grad(args, rank, world):
+def grad_row(config, steps, warmup, cpu=True):
     """Mode G of SURVEY 8(d) over whole streams: the sensitivity / gradient sweep (ihgp.h:37-57 + :212-222 per tick: step with
     sensitivities, NLL and its gradient w.r.t. the latent's hyper-parameters), resident streams, one GPU.  c3grad: C3's shape
     (4096 x 10^4, Matern-5/2, d = 3, P = 3, fp32); c5grad: C5's (d = 12 stacked, P = 9, fp64).  A step = one sweep."""
     from multioutputihgp_amd.streams import LatentBank
-    L, T, dtype, kernel, _ = CONFIGS["c3" if args.config == "c3grad" else "c5"]
+    L, T, dtype, kernel, _ = CONFIGS["c3" if config == "c3grad" else "c5"]
     dev = torch.device("cuda", torch.cuda.current_device())
     prm = synth_params(L, 0, np.random.default_rng(SEED), kernel)
     bank = LatentBank(0.1, prm, kernel=kernel)
     Ty = synth_stream(L, 0, T, dtype, dev, SEED + 1)
     d, P = bank.d, bank.P
-    for _ in range(max(1, args.warmup)):
+    for _ in range(max(1, warmup)):
         r = bank.grad(Ty, T=T, want_yhat=False)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         r = bank.grad(Ty, T=T, want_yhat=False)
     torch.cuda.synchronize()
-    sec = (time.perf_counter() - t0) / args.steps
+    sec = (time.perf_counter() - t0) / steps
     steps_per_s = L * T / sec
     peak = 157.3 if dtype == torch.float32 else 78.6
     ref_flops = 2 * d * d + 4 * d + 5 + P * (4 * d * d + 6 * d + 8)              # SURVEY 8(d), mode G, the reference's dense form
@@ -289,19 +322,19 @@ def run_grad(args, rank, world):
         flops, form = ref_flops, "SURVEY 8(d) mode G count of the reference's form"
     out = {
         "metric": "Kalman steps/sec (M outputs x T ticks) + NLL rel-err vs CPU oracle",
-        "value": steps_per_s, "unit": "Kalman steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec * 1e3,
+        "value": steps_per_s, "unit": "Kalman steps/s", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": sec * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if dtype == torch.float32 else "f64", "data": "synthetic",
-        "config": {"workload": f"{args.config}: gradient sweep (step with sensitivities + NLL + dNLL/dtheta per tick) over L={L} latents x T={T} ticks, {kernel}, "
+        "config": {"workload": f"{config}: gradient sweep (step with sensitivities + NLL + dNLL/dtheta per tick) over L={L} latents x T={T} ticks, {kernel}, "
                                f"d={d}, P={P}; streams resident in HBM", "latents_total": L, "ticks": T, "state_dim": d, "hyper_parameters_per_latent": P},
         "roofline": {"bound": "valu", "achieved": steps_per_s * flops / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": steps_per_s * flops / 1e12 / peak,
                      "traffic": None, "kernel": "grad_scan_x_kernel" if bank.stacked else "grad_scan_kernel", "kernel_ms": sec * 1e3,
-                     "kernel_ms_from": f"wall clock over {args.steps} sweeps (one launch of the sweep kernel + the small continuation kernel each)",
+                     "kernel_ms_from": f"wall clock over {steps} sweeps (one launch of the sweep kernel + the small continuation kernel each)",
                      "flops_per_step": flops, "flop_count": form, "reference_form_flops_per_step": ref_flops,
                      "reference_form_equivalent_TFLOPs": steps_per_s * ref_flops / 1e12,
                      "note": "vector-ALU bound (no MFMA: per-latent matrices, d <= 12); HBM side: " + f"{steps_per_s * (4 if dtype == torch.float32 else 8) / 1e9:.0f} GB/s of 8000"},
         "nll_total": float(r["nll"].sum()),
     }
-    if not args.no_cpu:
+    if cpu:
         from oracle import cref
         okern = ORACLE_KERNEL.get(kernel, kernel)
         wide = cref.is_wide(okern)
@@ -320,7 +353,8 @@ def run_grad(args, rank, world):
         out["nll_rel_err"] = float(np.abs(n - o["nll_per_latent"]).max() / np.abs(o["nll_per_latent"]).max())
         out["grad_rel_err"] = float(np.abs(g - o["grad"]).max() / np.abs(o["grad"]).max())
         out["speedup_vs_cpu_all_cores"] = steps_per_s / out["cpu_baseline"]["value"]
-    print(json.dumps(out), flush=True)
+    del bank, Ty
+    return out
 
 
 def valu_side(d, dtype, steps_per_s):
@@ -332,6 +366,133 @@ def valu_side(d, dtype, steps_per_s):
     return {"flops_per_step": flops, "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak}
 
 
+def cold_leg(bank, Ty, yhat, x, x_zero, nll, T, alg_bytes, es):
+    """Cold-stream figure of a filter configuration: the timed passes sweep ONE resident stream, so between passes part of its input is
+    served by the 256 MiB Infinity Cache (and FETCH_SIZE counts those hits): roofline.frac is cache-assisted whenever the input fits.
+    Here the same launch rotates over enough distinct (input, output) pairs that nothing it reads can still be on chip."""
+    L = Ty.shape[0]
+    pair_bytes = 2 * es * L * Ty.shape[1]
+    nrot = max(2, min(8, int((3 * 256 * 2 ** 20 + pair_bytes - 1) // pair_bytes)))
+    try:
+        rot = [(Ty, yhat)] + [(Ty.clone(), torch.empty_like(yhat)) for _ in range(nrot - 1)]
+        for k in range(nrot):
+            bank.filter(rot[k][0], T=T, x=x, x_start=x_zero, yhat=rot[k][1], nll=nll)
+        bank.profile_enable(3 * nrot)
+        for k in range(3 * nrot):
+            bank.filter(rot[k % nrot][0], T=T, x=x, x_start=x_zero, yhat=rot[k % nrot][1], nll=nll)
+        cold_ms = float(np.mean(bank.profile_read()))
+        del rot
+        return {"frac_cold": alg_bytes / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "achieved_cold": alg_bytes / (cold_ms * 1e-3) / 1e9,
+                "kernel_ms_cold": cold_ms,
+                "cold_note": f"same launch rotating over {nrot} distinct stream pairs ({nrot * pair_bytes / 2 ** 20:.0f} MiB"
+                             + (" > 3 x the 256 MiB Infinity Cache)" if nrot * pair_bytes >= 3 * 256 * 2 ** 20 else ", capped at 8 pairs)")
+                             + "; `frac` is the resident-stream figure (cache-assisted when the input fits on chip)"}
+    except torch.cuda.OutOfMemoryError:
+        return {"frac_cold": None}
+
+
+def filter_row(name, device, passes=20):
+    """One of the other single-GPU filter configurations of BASELINE.json, measured the way the headline is: kernel-exact HIP event
+    pairs on every launch, the wall clock over the same passes (sweep + the pass's NLL total), and the cold-stream leg."""
+    from multioutputihgp_amd.streams import LatentBank
+    L2, T2, dt2, k2, desc2 = CONFIGS[name]
+    b2 = LatentBank(0.1, synth_params(L2, 0, np.random.default_rng(SEED), k2), kernel=k2)
+    Ty2 = synth_stream(L2, 0, T2, dt2, device, SEED + 1)
+    yh2 = torch.empty_like(Ty2); n2 = torch.empty((L2,), dtype=torch.float64, device=device)
+    x2 = torch.zeros((L2, b2.d), dtype=dt2, device=device)
+    x2z = torch.zeros_like(x2)
+    tot2 = torch.zeros((1,), dtype=torch.float64, device=device)
+    for _ in range(3):
+        b2.filter(Ty2, T=T2, x=x2, x_start=x2z, yhat=yh2, nll=n2, nll_total=tot2)
+    b2.profile_enable(passes)
+    torch.cuda.synchronize()
+    tw0 = time.perf_counter()
+    for _ in range(passes):            # the same pass as the headline's: sweep + the pass's NLL total, wall-clocked
+        b2.filter(Ty2, T=T2, x=x2, x_start=x2z, yhat=yh2, nll=n2, nll_total=tot2)
+    torch.cuda.synchronize()
+    wall2 = (time.perf_counter() - tw0) / passes
+    ms2 = float(np.mean(b2.profile_read()))
+    es2 = 4 if dt2 == torch.float32 else 8
+    alg = 2 * es2 * L2 * T2
+    row = {"workload": desc2, "state_dim": b2.d, "dtype": "f32" if dt2 == torch.float32 else "f64", "ms_per_step": wall2 * 1e3, "value": L2 * T2 / wall2,
+           "kernel": "filter_x_kernel" if b2.stacked else "filter_scan_kernel", "kernel_ms": ms2,
+           "steps_per_s_kernel_only": L2 * T2 / (ms2 * 1e-3), "bound": "hbm",
+           "achieved_GBps": alg / (ms2 * 1e-3) / 1e9, "frac": alg / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+           "vector_alu": valu_side(b2.d, dt2, L2 * T2 / (ms2 * 1e-3))}
+    if row["vector_alu"]["frac"] > row["frac"]:
+        row["bound"] = "valu"         # the d = 12 fp64 shape sits on the vector-ALU wall (SURVEY 8d): `frac` stays the HBM figure, vector_alu.frac the binding one
+    row.update(cold_leg(b2, Ty2, yh2, x2, x2z, n2, T2, alg, es2))
+    del b2, Ty2, yh2
+    return row
+
+
+def pmc_traffic(config):
+    """HBM bytes per launch from the PMC counters (tools/pmc_traffic.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes with the gfx950
+    correction), as committed under profiles/: a record of an earlier profiled run of this command, not a measurement of this run."""
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(pmc):
+        return None, None
+    try:
+        rec = json.load(open(pmc))
+        ent = rec.get(config, {})
+        return ent.get("hbm_bytes_per_launch"), {"file": "profiles/pmc_traffic.json", "collected_at_commit": rec.get("_commit"), "collected": rec.get("_collected"),
+                                                 "summary": ent.get("source"), "note": "PMC pass of an earlier run of this command (rocprofv3 --pmc cannot run inside the timed bench); "
+                                                                                         "stale if the kernel changed since that commit"}
+    except Exception:
+        return None, None
+
+
+class _StubBank:
+    """BENCH_REHEARSAL=stub only (tests/test_bench_launch.py): stands in for the HIP sweep so that the rank / launch / reduction logic of
+    this file runs on a box without a GPU.  It computes nothing of the path; a line produced with it says so and is not a measurement."""
+    d, stacked = 3, False
+
+    def __init__(self, L):
+        self.L = L
+
+    def filter(self, Ty, T=None, x=None, x_start=None, yhat=None, nll=None, nll_total=None, **kw):
+        if nll is not None:
+            nll.fill_(1.0)
+        if nll_total is not None:
+            nll_total.fill_(float(self.L))
+        return yhat, x, nll
+
+    def profile_enable(self, n, stride=1):
+        self._n = n
+
+    def profile_read(self):
+        return [1.0]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (torch.distributed.run), relay rank 0's JSON
+    line, return the children's code.  The parent has made no GPU call (importing torch does not initialise the device), and it
+    does not replace itself: on this pool an exec from a process that has touched the GPU takes the machine down."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in proc.stdout:
+        st = ln.strip()
+        if st.startswith("{") and '"metric"' in st:
+            line = st                                  # rank 0's result line (the only rank that prints one)
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    if rc == 0 and line is None:
+        sys.stderr.write("bench.py: the ranks exited cleanly but printed no result line\n")
+        rc = 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -340,39 +501,56 @@ def main():
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS) + ["c1", "c3learn", "c3grad", "c5grad"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / parity leg")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold-stream leg (roofline.frac_cold): profiled runs, so that a kernel trace holds the timed launches only")
+    ap.add_argument("--no-others", action="store_true", help="skip the other BASELINE configurations that the default line carries in other_configs")
     ap.add_argument("--sync-allreduce", action="store_true", help="N > 1: make every pass wait for its own NLL all-reduce (no overlap with the next sweep)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)             # before anything touches the GPU
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    assert torch.cuda.is_available(), "bench.py needs a GPU; there is no CPU fallback"
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N ranks for --gpus N (or plain `python bench.py --gpus N`, which starts them itself)")
     # Rehearsal on a 1-GPU box: BENCH_REHEARSAL=1 lets all ranks share device 0 and moves the 8-byte exchange to
-    # gloo (RCCL refuses two ranks on one device).  Never used for reported numbers.
-    rehearsal = os.environ.get("BENCH_REHEARSAL", "0") == "1"
-    dev_index = 0 if rehearsal else local_rank
-    torch.cuda.set_device(dev_index)
-    device = torch.device("cuda", dev_index)
-    if world > 1:
+    # gloo (RCCL refuses two ranks on one device); BENCH_REHEARSAL=stub additionally replaces the sweep by a stub on the CPU
+    # (launch / rank / reduction logic only, for the CPU test suite).  Never used for reported numbers.
+    rehearsal = os.environ.get("BENCH_REHEARSAL", "0")
+    stub = rehearsal == "stub"
+    rehearsal = rehearsal in ("1", "stub")
+    if stub:
+        device = torch.device("cpu")
+    else:
+        assert torch.cuda.is_available(), "bench.py needs a GPU; there is no CPU fallback"
+        dev_index = 0 if rehearsal else local_rank
+        torch.cuda.set_device(dev_index)
+        device = torch.device("cuda", dev_index)
+    # BENCH_FORCE_DIST=1: build the process group even for one rank (a 1-rank RCCL communicator: the -m gpu suite runs the N > 1 code
+    # of this file -- init with device_id, the overlapped all-reduce, max-over-ranks on the device -- on the one GPU it has)
+    force_dist = os.environ.get("BENCH_FORCE_DIST", "0") == "1"
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
+    from multioutputihgp_amd import sharded
     from multioutputihgp_amd.sharded import (allreduce_nll, allreduce_nll_async, allreduce_total, allreduce_total_async, max_over_ranks,
                                              run_pipelined, shard_bounds)
-    from multioutputihgp_amd.streams import LatentBank
+    if force_dist:
+        sharded.FORCE_COLLECTIVES = True     # lift the world == 1 short-cuts: the collectives really run
 
     if args.config == "c1":
         return run_c1(args, rank, world)
     if args.config == "c3learn":
-        return run_c3learn(args, rank, world)
+        print(json.dumps(learn_row(args.steps, args.warmup, cpu=not args.no_cpu)), flush=True)
+        return 0
     if args.config in ("c3grad", "c5grad"):
-        return run_grad(args, rank, world)
+        print(json.dumps(grad_row(args.config, args.steps, args.warmup, cpu=not args.no_cpu)), flush=True)
+        return 0
 
     Lg_per, T, dtype, kernel, desc = CONFIGS[args.config]
     slab = SLAB.get(args.config, T)
@@ -382,8 +560,13 @@ def main():
     L = hi - lo
     prm_all = synth_params(Lglobal, 0, np.random.default_rng(SEED), kernel)
     prm = prm_all[lo:hi]
-    bank = LatentBank(0.1, prm, kernel=kernel)
-    Ty = synth_stream(L, lo, T, dtype, device, SEED + 1 + rank)
+    if stub:
+        bank = _StubBank(L)
+        Ty = torch.zeros((L, 16), dtype=dtype)
+    else:
+        from multioutputihgp_amd.streams import LatentBank
+        bank = LatentBank(0.1, prm, kernel=kernel)
+        Ty = synth_stream(L, lo, T, dtype, device, SEED + 1 + rank)
     yhat = torch.empty_like(Ty)
     nll = torch.empty((L,), dtype=torch.float64, device=device)
     x = torch.zeros((L, bank.d), dtype=dtype, device=device)
@@ -413,17 +596,22 @@ def main():
             nll_acc.add_(nll)
         return reduce(nll_acc)
 
+    def sync():
+        if not stub:
+            torch.cuda.synchronize()
+
     for _ in range(args.warmup):
         total = one_pass()
     # kernel-exact durations: HIP event pairs attached to each filter dispatch of the timed region
     # (hipExtLaunchKernel, on the launch stream), read back after the region
     bank.profile_enable((args.steps * nslab + PROFILE_STRIDE - 1) // PROFILE_STRIDE, stride=PROFILE_STRIDE)
-    torch.cuda.synchronize()
-    if world > 1:
+    multi = world > 1 or force_dist
+    sync()
+    if multi:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
-    if args.sync_allreduce or world == 1:
+    if args.sync_allreduce or not multi:
         for k in range(args.steps):
             total = one_pass()
     else:
@@ -436,10 +624,10 @@ def main():
             sys.stderr.write(f"async all-reduce unavailable ({e}); continuing stream-ordered\n")
             for k in range(args.steps):
                 total = one_pass()
-    torch.cuda.synchronize()
-    if world > 1:
+    sync()
+    if multi:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
     elapsed = max_over_ranks(elapsed, device="cpu" if rehearsal else device)
     kern_samples = bank.profile_read()
@@ -451,13 +639,7 @@ def main():
         es = 4 if dtype == torch.float32 else 8
         alg_bytes = 2 * es * L * min(slab, T)           # per LAUNCH; SURVEY 8d mode F: read Ty + write Tyhat = 2*s B per Kalman step
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get(args.config, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, traffic_source = pmc_traffic(args.config)
         out = {
             "metric": "Kalman steps/sec (M outputs x T ticks) + NLL rel-err vs CPU oracle",
             "value": value, "unit": "Kalman steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -466,65 +648,48 @@ def main():
             "config": {"workload": desc, "latents_per_gpu": Lg_per, "latents_total": Lglobal, "ticks": T, "state_dim": bank.d,
                        "layout": "series-major [L][ld], HBM-resident", "sharding": f"latents x{world}, NLL scalar all-reduce per pass" + ("" if world == 1 else (" (stream-ordered)" if args.sync_allreduce else " (overlapped with the next pass)"))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic, "kernel": "filter_x_kernel" if bank.stacked else "filter_scan_kernel", "kernel_ms": kern_ms,
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": "filter_x_kernel" if bank.stacked else "filter_scan_kernel", "kernel_ms": kern_ms,
                          "kernel_ms_from": f"HIP event pairs on {len(kern_samples)} of the {args.steps * nslab} launches of the timed region",
                          "algorithmic_bytes_per_launch": alg_bytes, "frac_of_measured_copy_peak": achieved / HBM_COPY_GBPS,
                          # the other wall (mode F is 2 d^2 + 2 d flop per step; the d = 12 fp64 configuration sits on this one)
                          "vector_alu": valu_side(bank.d, dtype, L * min(slab, T) / (kern_ms * 1e-3))},
             "nll_total": float(total.item()),
         }
-        if world == 1 and nslab == 1 and not args.no_cold:
-            # Cold-stream figure: the timed passes above sweep ONE resident stream, so between passes part of its input is served by the
-            # 256 MiB Infinity Cache (and FETCH_SIZE counts those hits): roofline.frac is cache-assisted whenever the input fits.  Here the
-            # same launch rotates over enough distinct (input, output) pairs that nothing it reads can still be on chip.
-            pair_bytes = 2 * es * L * Ty.shape[1]
-            nrot = max(2, min(8, int((3 * 256 * 2 ** 20 + pair_bytes - 1) // pair_bytes)))
-            try:
-                rot = [(Ty, yhat)] + [(Ty.clone(), torch.empty_like(yhat)) for _ in range(nrot - 1)]
-                for k in range(nrot):
-                    bank.filter(rot[k][0], T=T, x=x, x_start=x_zero, yhat=rot[k][1], nll=nll)
-                bank.profile_enable(3 * nrot)
-                for k in range(3 * nrot):
-                    bank.filter(rot[k % nrot][0], T=T, x=x, x_start=x_zero, yhat=rot[k % nrot][1], nll=nll)
-                cold_ms = float(np.mean(bank.profile_read()))
-                out["roofline"].update({"frac_cold": alg_bytes / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "achieved_cold": alg_bytes / (cold_ms * 1e-3) / 1e9,
-                                        "kernel_ms_cold": cold_ms,
-                                        "cold_note": f"same launch rotating over {nrot} distinct stream pairs ({nrot * pair_bytes / 2 ** 20:.0f} MiB > 3 x the 256 MiB Infinity Cache); "
-                                                     "`frac` is the resident-stream figure (cache-assisted when the input fits on chip)"})
-                del rot
-            except torch.cuda.OutOfMemoryError:
-                out["roofline"]["frac_cold"] = None
-        if rehearsal:
+        if stub:
+            out["rehearsal"] = "BENCH_REHEARSAL=stub: the sweep is a stub on the CPU (launch / rank / reduction logic only): NOT a measurement"
+            out["roofline"]["frac"] = None; out["roofline"]["achieved"] = None
+        elif rehearsal:
             out["rehearsal"] = "all ranks on one GPU, gloo exchange: numbers are not comparable"
-        if world == 1 and not args.no_cpu:
-            # the other single-GPU configurations of BASELINE.json, measured the same way (kernel-exact events), for context
-            others = {}
-            for name in sorted(CONFIGS):
-                if name == args.config or name in SLAB:
-                    continue
-                L2, T2, dt2, k2, desc2 = CONFIGS[name]
-                b2 = LatentBank(0.1, synth_params(L2, 0, np.random.default_rng(SEED), k2), kernel=k2)
-                Ty2 = synth_stream(L2, 0, T2, dt2, device, SEED + 1)
-                yh2 = torch.empty_like(Ty2); n2 = torch.empty((L2,), dtype=torch.float64, device=device)
-                x2 = torch.zeros((L2, b2.d), dtype=dt2, device=device)
-                x2z = torch.zeros_like(x2)
-                tot2 = torch.zeros((1,), dtype=torch.float64, device=device)
-                for _ in range(3):
-                    b2.filter(Ty2, T=T2, x=x2, x_start=x2z, yhat=yh2, nll=n2, nll_total=tot2)
-                b2.profile_enable(20)
-                torch.cuda.synchronize()
-                tw0 = time.perf_counter()
-                for _ in range(20):            # the same pass as the headline's: sweep + the pass's NLL total, wall-clocked over 20 passes
-                    b2.filter(Ty2, T=T2, x=x2, x_start=x2z, yhat=yh2, nll=n2, nll_total=tot2)
-                torch.cuda.synchronize()
-                wall2 = (time.perf_counter() - tw0) / 20
-                ms2 = float(np.mean(b2.profile_read()))
-                es2 = 4 if dt2 == torch.float32 else 8
-                others[name] = {"workload": desc2, "state_dim": b2.d, "ms_per_step": wall2 * 1e3, "value": L2 * T2 / wall2, "kernel_ms": ms2,
-                                "steps_per_s_kernel_only": L2 * T2 / (ms2 * 1e-3),
-                                "achieved_GBps": 2 * es2 * L2 * T2 / (ms2 * 1e-3) / 1e9, "frac": 2 * es2 * L2 * T2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBPS}
-                del b2, Ty2, yh2
-            out["other_configs"] = others
+        if force_dist:
+            out["forced_dist"] = f"process group built for {world} rank(s) (backend {dist.get_backend()}): every pass ran its all-reduce"
+        if world == 1 and nslab == 1 and not args.no_cold and not stub:
+            out["roofline"].update(cold_leg(bank, Ty, yhat, x, x_zero, nll, T, alg_bytes, es))
+        if world == 1 and not args.no_cpu and not stub:
+            if not args.no_others and not force_dist:
+                # the other single-GPU rows of BASELINE.json / SURVEY 8, measured in the same run: the other filter shapes (kernel-exact
+                # events + wall clock + cold leg), the gradient sweeps (mode G) and configs[2]'s objective evaluation
+                others = {}
+                for name in sorted(CONFIGS):
+                    if name == args.config or name in SLAB:
+                        continue
+                    others[name] = filter_row(name, device)
+                for name in ("c3grad", "c5grad"):
+                    g = grad_row(name, 10, 2, cpu=False)
+                    others[name] = {"workload": g["config"]["workload"], "state_dim": g["config"]["state_dim"], "dtype": g["dtype"], "ms_per_step": g["ms_per_step"],
+                                    "value": g["value"], "kernel": g["roofline"]["kernel"], "kernel_ms": g["roofline"]["kernel_ms"],
+                                    "kernel_ms_from": g["roofline"]["kernel_ms_from"], "bound": "valu", "achieved_TFLOPs": g["roofline"]["achieved"],
+                                    "peak_TFLOPs": g["roofline"]["peak"], "frac": g["roofline"]["frac"], "flops_per_step": g["roofline"]["flops_per_step"],
+                                    "flop_count": g["roofline"]["flop_count"]}
+                try:
+                    lr = learn_row(3, 1, cpu=False, windows=(128,))
+                    others["c3learn"] = {"workload": lr["config"]["workload"], "dtype": "f64", "ms_per_step": lr["ms_per_step"], "value": lr["value"],
+                                         "bound": "mfma", "achieved_TFLOPs": lr["roofline"]["achieved"], "peak_TFLOPs": 78.6, "frac": lr["roofline"]["frac"],
+                                         "update_ms": lr["roofline"]["update_ms"], "window_eval_ms": lr["roofline"]["window_eval_ms"],
+                                         "host_path_evaluation_ms": lr["roofline"]["host_path_evaluation_ms"], "note": lr["roofline"]["note"]}
+                except Exception as e:             # (a context line: never let it take the headline down)
+                    others["c3learn"] = {"error": str(e)}
+                out["other_configs"] = others
             if nslab > 1:
                 yhat = torch.cat(yhat_slabs, dim=1)
             sub = np.arange(0, L, max(1, L // 64))[:64]
@@ -534,9 +699,10 @@ def main():
             out["filtered_mean_rel_err"] = mean_rel
             out["speedup_vs_cpu_all_cores"] = value / cb["value"]
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

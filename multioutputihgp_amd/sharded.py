@@ -14,6 +14,16 @@ import torch
 import torch.distributed as dist
 
 
+# Test hook (tests/test_gpu_configs.py, bench.py BENCH_FORCE_DIST=1): with a process group of ONE rank the helpers below normally return
+# early; set to True they issue their collectives anyway, so that the RCCL-only code (async all-reduce on the communicator's stream,
+# reduce_scatter_tensor with its padding, all_gather) runs on a one-GPU box.
+FORCE_COLLECTIVES = False
+
+
+def _collective(group=None) -> bool:
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or FORCE_COLLECTIVES)
+
+
 def shard_bounds(L: int, world_size: int, rank: int) -> Tuple[int, int]:
     """Contiguous balanced partition of L latents; the first L % world_size ranks get one extra."""
     q, r = divmod(L, world_size)
@@ -23,7 +33,7 @@ def shard_bounds(L: int, world_size: int, rank: int) -> Tuple[int, int]:
 
 def allreduce_total(total: torch.Tensor, group=None) -> torch.Tensor:
     """All-reduce (SUM) of a rank's fp64 NLL total -- a 1-element tensor, e.g. the `nll_total` of LatentBank.filter -- in place."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _collective(group):
         if total.is_cuda and dist.get_backend(group) == "gloo":      # CPU rehearsal of the exchange
             t = total.cpu()
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
@@ -56,7 +66,7 @@ class PendingSum:
 def allreduce_total_async(total: torch.Tensor, group=None) -> PendingSum:
     """As allreduce_total, but the collective runs on the communicator's own stream and the caller's stream does not wait for it.
     `total` must not be rewritten before `.wait()` (use a small ring of totals for passes in flight)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _collective(group):
         if total.is_cuda and dist.get_backend(group) == "gloo":      # CPU rehearsal of the exchange
             t = total.cpu()
             return PendingSum(total, dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True), host=t)
@@ -88,7 +98,7 @@ def run_pipelined(steps: int, one_pass_async, max_in_flight: int = 2):
 def max_over_ranks(seconds: float, device="cpu", group=None) -> float:
     """Wall time of the slowest rank (the bench contract: barrier + synchronize on both sides, then the MAX over ranks)."""
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _collective(group):
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
 
@@ -102,7 +112,7 @@ def time_slice_bounds(T: int, world_size: int, rank: int) -> Tuple[int, int]:
 def gather_latent_grads(grad_local: torch.Tensor, L: int, group=None) -> torch.Tensor:
     """Per-latent gradients are disjoint across shards: all-gather [L_r, P] blocks into [L, P]
     (mode G only; moihgp.h:608-609 packs them latent-major)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not _collective(group):
         return grad_local
     ws = dist.get_world_size(group)
     P = grad_local.shape[1]
@@ -115,7 +125,7 @@ def gather_latent_grads(grad_local: torch.Tensor, L: int, group=None) -> torch.T
     return torch.cat([o[:n] for o, n in zip(out, sizes)], dim=0)
 
 
-def missing_output_correction(U_r, sqrtS_r, Ty_r, missing, allreduce):
+def missing_output_correction(U_r, sqrtS_r, Ty_r, missing, allreduce, lmax=None, chunk_elems=2 ** 28):
     """Least-squares projection of partially observed ticks (moihgp.h:167-178, `(U0^T U0).ldlt().solve(U0^T y_obs)`) when the latents
     are split over ranks.  (U0^T U0)^-1 couples ALL latents, so a rank's column slice alone gives a different vector; but U is a polar
     factor (U^T U = I), hence U0^T U0 = I - Um^T Um with Um the k rows of U at the missing outputs, and by Woodbury
@@ -125,13 +135,17 @@ def missing_output_correction(U_r, sqrtS_r, Ty_r, missing, allreduce):
     and corrects its own rows.  (The unsharded device path does the same per tick: csrc/tick.hip ls_project_kernel.)
 
     U_r [M, L_r] fp64: this rank's columns;  sqrtS_r [L_r];  Ty_r [L_r, >= T]: S_r^-1/2 U_r^T y0_t in column t, corrected IN PLACE;
-    missing [T, M] bool;  allreduce: tensor -> its sum over the ranks."""
+    missing [T, M] bool;  allreduce: tensor -> its sum over the ranks.
+    lmax: the width of the WIDEST shard, ceil(L / world) -- the same number on every rank.  The affected ticks are processed in chunks
+    (<= chunk_elems gathered doubles at a time) and every chunk is one all-reduce, so the chunking must not depend on the local shard
+    width: shard_bounds hands out widths that differ by one, and ranks that cut the ticks differently would call the collective a
+    different number of times with different shapes.  Without lmax the chunk size falls back to a fixed tick count."""
     aff = missing.any(dim=1).nonzero().flatten()
     if aff.numel() == 0:
         return Ty_r
     kmax = int(missing[aff].sum(dim=1).max())
-    Lr = U_r.shape[1]
-    step = max(1, int(2 ** 28 // max(1, kmax * Lr)))                          # <= 2 GiB of gathered rows at a time
+    # <= 2 GiB of gathered rows at a time; derived from rank-invariant quantities only (kmax comes from `missing`, replicated)
+    step = max(1, int(chunk_elems // max(1, kmax * int(lmax)))) if lmax is not None else max(1, int(chunk_elems // max(1, kmax * 65536)))
     eye = torch.eye(kmax, dtype=torch.float64, device=U_r.device)[None]
     for a in range(0, aff.numel(), step):
         ticks = aff[a:a + step]
@@ -209,7 +223,7 @@ class ShardedMOIHGP:
         return self._full.params
 
     def _allreduce(self, t):
-        if self.world == 1:
+        if self.world == 1 and not FORCE_COLLECTIVES:
             return t
         if t.is_cuda and dist.get_backend(self.group) == "gloo":     # CPU rehearsal of the exchange
             c = t.cpu()
@@ -224,7 +238,7 @@ class ShardedMOIHGP:
         has no reduce-scatter: all-reduce, then slice."""
         T = t.shape[1]
         lo, hi = time_slice_bounds(T, self.world, self.rank)
-        if self.world == 1:
+        if self.world == 1 and not FORCE_COLLECTIVES:
             return t
         if dist.get_backend(self.group) == "gloo":
             c = t.cpu() if t.is_cuda else t
@@ -252,7 +266,7 @@ class ShardedMOIHGP:
         dev = Y.device
         U = torch.from_numpy(self._full.params[:self.M * self.L].reshape(self.M, self.L)[:, self.lo:self.hi].copy()).to(dev)   # [M, L_r] fp64
         sqrtS = torch.from_numpy(self.S[self.lo:self.hi] ** 0.5).to(dev)
-        missing_output_correction(U, sqrtS, Ty, missing, self._allreduce)
+        missing_output_correction(U, sqrtS, Ty, missing, self._allreduce, lmax=(self.L + self.world - 1) // self.world)
         return Ty
 
     def filter(self, Y: torch.Tensor, scatter: bool = False):
@@ -266,7 +280,7 @@ class ShardedMOIHGP:
         import math
         T = Y.shape[0]
         missing = torch.isnan(Y)
-        if self.world > 1 and bool(missing.any()):
+        if (self.world > 1 or FORCE_COLLECTIVES) and bool(missing.any()):
             Ty = self._project_with_missing_outputs(Y, missing)
         else:
             Ty = project_stream(self._shard, Y)

@@ -148,3 +148,53 @@ def test_sharded_rejects_more_ranks_than_latents(monkeypatch):
     monkeypatch.setattr(sharded.dist, "get_rank", lambda group=None: 3)
     with pytest.raises(ValueError, match="at least one latent"):
         sharded.ShardedMOIHGP(0.1, 8, 3)
+
+
+# ------------------------------------------------------------------------------------------ uneven shards, several chunks of affected ticks
+def _worker_chunks(rank, ws, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    from multioutputihgp_amd.sharded import missing_output_correction
+    M, L, T = 23, 7, 40                                                  # 7 latents over 2 ranks: widths 4 and 3
+    rng = np.random.default_rng(5)
+    Uf, _ = np.linalg.qr(rng.standard_normal((M, L)))
+    S = rng.uniform(0.5, 2.0, L)
+    Y = rng.standard_normal((T, M))
+    for t in range(0, T, 2):                                             # 20 affected ticks, 1-3 missing outputs each
+        Y[t, rng.choice(M, size=1 + t % 3, replace=False)] = np.nan
+    lo, hi = shard_bounds(L, ws, rank)
+    calls = []
+
+    def allreduce(t):
+        calls.append(tuple(t.shape))
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t
+
+    Ty = torch.from_numpy((Uf[:, lo:hi].T @ np.nan_to_num(Y).T) / np.sqrt(S[lo:hi])[:, None])
+    # chunk cap of 3 * lmax * kmax gathered doubles: 3 ticks per chunk -> 7 collectives; a step derived from the LOCAL width would give
+    # rank 0 (width 4) 3 ticks per chunk and rank 1 (width 3) 4: different counts and shapes, i.e. a hang or a corrupted sum
+    lmax = (L + ws - 1) // ws
+    missing_output_correction(torch.from_numpy(Uf[:, lo:hi].copy()), torch.from_numpy(np.sqrt(S[lo:hi])), Ty, torch.from_numpy(np.isnan(Y)),
+                              allreduce, lmax=lmax, chunk_elems=3 * lmax * 3)
+    want = np.empty((L, T))
+    for t in range(T):
+        obs = ~np.isnan(Y[t])
+        U0 = Uf[obs]
+        want[:, t] = np.linalg.solve(U0.T @ U0, U0.T @ Y[t, obs]) / np.sqrt(S)
+    ok = bool(np.abs(Ty.numpy() - want[lo:hi]).max() < 1e-11)
+    q.put((rank, ok, calls))
+    dist.destroy_process_group()
+
+
+def test_missing_output_correction_chunks_agree_across_uneven_shards():
+    """the chunking of the affected ticks must be the same on every rank although shard widths differ by one."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_chunks, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs: p.join(timeout=60)
+    assert res[0][1] and res[1][1]
+    assert res[0][2] == res[1][2] and len(res[0][2]) == 7               # same number and shapes of collectives on both ranks
