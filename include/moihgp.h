@@ -1,6 +1,6 @@
 /* moihgp.h -- C ABI of libmoihgp.so (MI355X / gfx950 HIP implementation).
  *
- * Part 1 is the drop-in boundary: the exact 28 symbols the reference exports from
+ * Part 1 is the drop-in boundary: the exact 26 symbols the reference exports from
  * moihgp/src/wrapper.cpp and that moihgp/pywrapper.py binds through ctypes
  * (pywrapper.py:28-94).  Signatures, buffer layouts and ownership are the reference's:
  * every pointer is a caller-owned host buffer of C-contiguous doubles, valid for the
@@ -16,8 +16,8 @@
  * reference entries prints the error and aborts -- they are all void / value returns, the
  * reference ABI has no status channel (wrapper.cpp:31-326).  The additive entries of part 2
  * that return int report it instead: rc 1 = invalid argument, 2 = HIP failure, 3 = unsupported
- * input (window with NaN), 4 = host memory; moihgp_last_error() holds the text.  Nothing ever
- * unwinds across the ABI.
+ * input (a window whose missing outputs exceed the limits of moihgp_project_stream), 4 = host memory; moihgp_last_error() holds
+ * the text.  Nothing ever unwinds across the ABI.
  *
  * Part 2 is additive: batched entry points over whole time streams (the per-tick ABI costs one
  * FFI crossing + several launches per tick and cannot amortise them), taking DEVICE pointers.
@@ -162,6 +162,22 @@ int         moihgp_get_latent(moihgp_gp* gp, size_t l, double* A, double* K, dou
  * partial sums): batched work of ONE handle must be ordered among itself -- keep it on one stream, or order the streams with events.
  * Different handles are independent. */
 
+/* Hand a stream back before destroying it.  The handle remembers (by value) every stream that carried batched work since its last
+ * table rewrite and records an event on each of them at the next rewrite; a stream destroyed in between would be a dangling handle
+ * there.  moihgp_release_stream orders the handle's own stream behind everything enqueued on `stream` so far and forgets it.  Streams
+ * that live as long as the handle (torch's pool, the default stream) never need this. */
+int moihgp_release_stream(moihgp_gp* gp, void* stream);
+
+/* Options of a handle (tuning / test hooks; defaults come from the environment variables of the same meaning, read ONCE when the
+ * handle is created -- nothing below consults the environment per launch):
+ *   "filter_split"    0 = automatic time split for few latents, 1 = off, n > 1 = n slices      (env MOIHGP_FILTER_SPLIT)
+ *   "filter_maxlinks" -1 = automatic; chunks with a gap per segment that the stacked filter's second pass takes as broken links
+ *                                                                                               (env MOIHGP_FILTER_MAXLINKS)
+ *   "filter_variant"  kernel tiling probes; accepted only by a library built with -DMOIHGP_TUNING (make TUNING=1), rc 1 otherwise:
+ *                     the probe instantiations (some of which do no arithmetic) are not part of the shipped library.
+ * Returns 0, or 1 for an unknown name / a value out of range. */
+int moihgp_set_option(moihgp_gp* gp, const char* name, long value);
+
 /* ---- batched recursion over pre-projected streams (DEVICE pointers) -------------------------
  * The stream is SERIES-MAJOR: Ty[l*ld + t], l < L (latents owned by gp), t < T, element type per
  * `dtype`.  Requirements: base pointers 16-byte aligned; ld*sizeof(elem) a multiple of 16 and
@@ -210,9 +226,9 @@ int moihgp_grad_stream(moihgp_gp* gp, int dtype, const void* Ty, size_t T, size_
  * A tick whose observation vector holds NaN (missing outputs) is projected as the reference does it, by least squares over the observed
  * rows (moihgp.h:167-178): Ty[:, t] = S^-1/2 (U0^T U0)^-1 U0^T y_obs -- evaluated through the k x k system of the k missing rows
  * (U^T U = I for the polar factor update() installs: U0^T U0 = I - U_miss^T U_miss), the same vector to rounding.  It needs
- * orthonormal columns (checked when the mixing comes from moihgp_set_mixing), at most 64 missing outputs in the tick and at least L
- * observed ones; otherwise the NaN propagates into Ty[:, t], i.e. the recursion treats the whole tick as missing (use the per-tick ABI
- * for such ticks). */
+ * orthonormal columns (checked when the mixing comes from moihgp_set_mixing), at most 64 missing outputs in the tick, at least L
+ * observed ones, and L <= 15040 (the tick's U^T y lives in the workgroup's LDS); otherwise the NaN propagates into Ty[:, t], i.e. the
+ * recursion treats the whole tick as missing (use the per-tick ABI for such ticks). */
 int moihgp_project_stream(moihgp_gp* gp, int dtype, const void* Y, size_t T, void* Ty, size_t ld, void* stream);
 int moihgp_unproject_stream(moihgp_gp* gp, int dtype, const void* Tyhat, size_t T, size_t ld, void* Yhat, void* stream);
 
@@ -222,16 +238,38 @@ int moihgp_unproject_stream(moihgp_gp* gp, int dtype, const void* Tyhat, size_t 
  * with the object's current parameters (set them with gpXX_update first, moihgp_online.h:43).  `loss` is the sum of what
  * gpXX_lik1 returns per tick, i.e. it follows the object's `threading` flag (moihgp.h:590 vs :597-607, see gp32_new).
  * moihgp_window_set uploads the window Y [W][M] (tick-major, already de-meaned by the caller) once; it stays
- * resident for all evaluations of one L-BFGS solve.  Returns 3 if Y contains NaN (missing outputs need the
- * per-tick least-squares projection, moihgp.h:167-178: use the per-tick ABI for such windows).
+ * resident for all evaluations of one L-BFGS solve.
+ * Ticks with missing outputs (NaN in y_t) are projected by least squares over the observed rows, as moihgp_project_stream does it
+ * (moihgp.h:485-494, same k x k Woodbury form and the same limits: at most 64 missing outputs per tick, at least L observed, orthonormal
+ * mixing, L <= 15040; moihgp_window_set returns 3 beyond them: use the per-tick ABI for such windows).  Everything else of such a tick is
+ * the reference's own arithmetic on a vector that holds NaN (moihgp.h:499-563: (I - U U^T) y, y^T U dU^T y, pv with raw y(l) are dense
+ * products with y): the loss and the U / S / sigma part of the gradient come out NaN, the per-latent part (which only sees the projected
+ * stream, moihgp.h:565-607) and the carried state are finite -- exactly what gpXX_lik1 / gpXX_step1 return tick by tick.
  * moihgp_window_eval:  x [L][d], dx [L][P][d] state before the window;  *loss, grad [M*L+L+1+L*P] summed over the
  * W ticks;  xnew / dxnew (may be NULL) state after the window. */
 int moihgp_window_set(moihgp_gp* gp, const double* Y, size_t W);
 int moihgp_window_eval(moihgp_gp* gp, const double* x, const double* dx, double* loss, double* grad, double* xnew, double* dxnew);
 
+/* ---- the same objective without PCIe in the optimiser's inner loop (DEVICE pointers, fp64) ------------------------------------
+ * gpXX_update and moihgp_window_eval move the parameter and gradient vectors (8 (M L + ..) bytes each: 134 MB at M = L = 4096) across
+ * PCIe on every objective evaluation.  An optimiser that keeps theta, its gradient and its correction pairs on the device calls these
+ * instead: params / grad are DEVICE arrays laid out exactly as the host ones ([U row-major | S | sigma | P values per latent],
+ * moihgp.h:93); x, dx, xnew, dxnew, loss are DEVICE arrays / a DEVICE scalar.  moihgp_update_dev == gpXX_update (moihgp.h:431-457; the
+ * small tail S | sigma | per-latent values is mirrored to the host for getParams, the mixing is not copied until somebody asks);
+ * moihgp_window_eval_dev == moihgp_window_eval on the window moihgp_window_set installed.  Both run on the handle's own stream and
+ * return when the results are complete (like their host forms), so the caller's streams need no extra ordering.
+ * Same values as the host forms, bit for bit (same kernels). */
+int moihgp_update_dev(moihgp_gp* gp, const double* params_dev);
+int moihgp_window_eval_dev(moihgp_gp* gp, const double* x_dev, const double* dx_dev, double* loss_dev, double* grad_dev,
+                           double* xnew_dev, double* dxnew_dev);
+/* getParams (moihgp.h:721-738) into a DEVICE array [num_param]. */
+int moihgp_get_params_dev(moihgp_gp* gp, double* params_dev);
+
 /* Kernel-exact timing of moihgp_filter_stream launches (bench / diagnosis).  After
  * moihgp_profile_enable(gp, n) the next n launches on this handle are bracketed by a HIP event pair
- * attached to the dispatch itself (hipExtLaunchKernel), not to the stream.  moihgp_profile_read waits
+ * attached to the dispatch itself (hipExtLaunchKernel), not to the stream.  The pair brackets the sweep's FIRST (dominant) kernel --
+ * the one rocprofv3 lists as filter_scan_kernel / filter_x_kernel; the small kernels queued behind it (the NLL total, the slice sums,
+ * and for streams with missing ticks the second pass of the stacked filter) are outside it: time such streams with the wall clock.  moihgp_profile_read waits
  * for them, writes the per-launch durations in milliseconds, rearms the slots and returns the count.
  * moihgp_profile_enable(gp, 0) turns it off.  An event pair makes the dispatch it brackets wait for its predecessor and costs
  * 3-6 us of launch overlap; moihgp_profile_stride(gp, k) attaches pairs to every k-th launch only (default 1), so a timed loop

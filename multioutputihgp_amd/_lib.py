@@ -22,11 +22,17 @@ ADDITIVE_SYMBOLS = [
     "moihgp_update_latents", "moihgp_set_mixing", "moihgp_get_latent", "moihgp_filter_stream", "moihgp_filter_stream_io", "moihgp_filter_stream_v2", "moihgp_grad_stream",
     "moihgp_project_stream", "moihgp_unproject_stream", "moihgp_stream_sync",
     "moihgp_profile_enable", "moihgp_profile_stride", "moihgp_profile_read", "moihgp_window_set", "moihgp_window_eval", "moihgp_pin_host_buffer",
+    "moihgp_update_dev", "moihgp_window_eval_dev", "moihgp_get_params_dev", "moihgp_set_option", "moihgp_release_stream",
 ]
 
 
 class MoihgpError(RuntimeError):
-    pass
+    """A failed libmoihgp call; `.rc` holds the entry's return code when it has one (include/moihgp.h: 1 invalid argument, 2 HIP
+    failure, 3 unsupported input, 4 host memory)."""
+
+    def __init__(self, msg, rc=None):
+        super().__init__(msg)
+        self.rc = rc
 
 
 def library_path() -> str:
@@ -108,6 +114,16 @@ def load_library():
     lib.moihgp_window_eval.argtypes = [C.c_void_p] + [c_double_p] * 6
     lib.moihgp_pin_host_buffer.restype = C.c_int
     lib.moihgp_pin_host_buffer.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.moihgp_update_dev.restype = C.c_int
+    lib.moihgp_update_dev.argtypes = [C.c_void_p, C.c_void_p]
+    lib.moihgp_window_eval_dev.restype = C.c_int
+    lib.moihgp_window_eval_dev.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+    lib.moihgp_get_params_dev.restype = C.c_int
+    lib.moihgp_get_params_dev.argtypes = [C.c_void_p, C.c_void_p]
+    lib.moihgp_set_option.restype = C.c_int
+    lib.moihgp_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
+    lib.moihgp_release_stream.restype = C.c_int
+    lib.moihgp_release_stream.argtypes = [C.c_void_p, C.c_void_p]
     lib.moihgp_stream_sync.restype = C.c_int
     lib.moihgp_stream_sync.argtypes = [C.c_void_p]
     _LIB = lib

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <exception>
 #include <random>
+#include <string>
 #include <vector>
 
 namespace moihgp {
@@ -74,6 +75,12 @@ struct moihgp_gp {
     double* dpolar = nullptr;  // M*L + 2*L*L + 8, lazily (device polar factor)
     int* dfallback = nullptr;  // [2 L + 1] flags of the latents the gradient sweep leaves to its later passes, their compact list, its length
     double* dlink = nullptr;   // [L][144] stacked filter: where the second (broken-link) pass resumes a latent (on first use)
+    bool hp_valid = false;     // dhp matches the current tables (cleared by every IHGP::update)
+    // options (moihgp_set_option; defaults from the environment, read once in gp_create)
+    int opt_filter_split = 0, opt_filter_variant = 0, opt_filter_maxlinks = -1;
+    int* dwinmiss = nullptr;   // [W] window objective: 1 where the tick's observation vector holds NaN (on first use)
+    size_t winmiss_cap = 0;
+    bool win_has_nan = false;
     int polar_its = 0;         // Newton-Schulz steps of the last device polar factor (0: single-workgroup kernel / none yet)
     double* dhp = nullptr;     // [L][gradx_hp_len(d)] HA AKHA^k rows of the stacked models' time-parallel gradient sweep (on first use)
     double* dxscratch = nullptr; // stacked kernels, few latents: per-slice NLL partials
@@ -105,7 +112,7 @@ struct moihgp_gp {
 
 static void gp_free(moihgp_gp* g) {
     if (!g) return;
-    void* ptrs[] = {g->dU, g->dS, g->dsqrtS, g->dinvsqrtS, g->dsigma, g->dparams, g->cb64, g->cb32, g->dx, g->dpart, g->dTy, g->dUty, g->dTyhat, g->dloss, g->dgrad, g->dscratch, g->dwork, g->dpolar, g->dfallback, g->dwin, g->dunstable, g->dxscratch, g->cbd64, g->dU32, g->dhp, g->dlink};
+    void* ptrs[] = {g->dU, g->dS, g->dsqrtS, g->dinvsqrtS, g->dsigma, g->dparams, g->cb64, g->cb32, g->dx, g->dpart, g->dTy, g->dUty, g->dTyhat, g->dloss, g->dgrad, g->dscratch, g->dwork, g->dpolar, g->dfallback, g->dwin, g->dunstable, g->dxscratch, g->cbd64, g->dU32, g->dhp, g->dlink, g->dwinmiss};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (void* p : g->pinned) (void)hipHostUnregister(p);
@@ -155,6 +162,7 @@ static void upload_mixing(moihgp_gp* g) {
 
 static void run_ihgp_update(moihgp_gp* g) {
     order_after_sweeps(g);
+    g->hp_valid = false;
     MOIHGP_HIP_FATAL(hipMemcpyAsync(g->dparams, g->igp.data(), sizeof(double) * g->L * g->P, hipMemcpyHostToDevice, g->stream));
     if (kernel_stack(g->kernel)) {
         // the sensitivities cost nine more 100-iteration Lyapunov solves per latent at d = 12: only for handles that use them
@@ -206,6 +214,12 @@ static moihgp_gp* gp_create(int kernel, double dt, size_t M, size_t L, bool late
     g->kernel = kernel; g->dt = dt; g->M = M; g->L = L; g->latents_only = latents_only;
     g->threading = (L < 2) ? false : threading;                          // moihgp.h:128-135
     { const char* fl = std::getenv("MOIHGP_LIK1_FULL_LOSS"); g->lik1_full = fl && fl[0] == '1'; }
+    // tuning / test hooks: the environment is consulted here, once; moihgp_set_option changes them per handle afterwards
+    if (const char* e = std::getenv("MOIHGP_FILTER_SPLIT")) g->opt_filter_split = std::atoi(e);
+    if (const char* e = std::getenv("MOIHGP_FILTER_MAXLINKS")) g->opt_filter_maxlinks = std::atoi(e);
+#ifdef MOIHGP_TUNING
+    if (const char* e = std::getenv("MOIHGP_FILTER_VARIANT")) g->opt_filter_variant = std::atoi(e);
+#endif
     g->d = (kbase == MOIHGP_MATERN32) ? 2 : 3;                           // matern32ss.h:95, matern52ss.h:106
     if (kstack) { g->d *= kstack; g->P = 2 * kstack + 1; }               // (magnitude_j, lengthscale_j) x J, noise
     g->num_param = M * L + L + 1 + L * g->P;                             // moihgp.h:93
@@ -303,6 +317,7 @@ static void wait_flag(moihgp_gp* g, unsigned long long seq) {
 static void do_step(moihgp_gp* g, const double* x, const double* y, const double* dx, double* xnew, double* yhat, double* dxnew) {
     if (g->latents_only) { set_last_error("per-tick ABI needs a full MOIHGP object"); std::fprintf(stderr, "%s\n", g_last_error); std::abort(); }
     const size_t L = g->L, d = g->d, P = g->P, M = g->M;
+    order_after_sweeps(g);                       // handle-owned scratch (flags, partial sums) is shared with sweeps still in flight on caller streams
     if (dx) ensure_sensitivities(g);             // (stacked kernels compute dAKHA, dK, .. from the first call that needs them on)
     double* o_x = g->hout;                       // mapped host block: [xnew | yhat | dxnew | loss]
     double* o_y = o_x + L * d;
@@ -336,6 +351,7 @@ static void do_step(moihgp_gp* g, const double* x, const double* y, const double
 static double do_lik(moihgp_gp* g, const double* x, const double* y, const double* dx, double* grad) {
     if (g->latents_only) { set_last_error("per-tick ABI needs a full MOIHGP object"); std::fprintf(stderr, "%s\n", g_last_error); std::abort(); }
     const size_t L = g->L, d = g->d, P = g->P, M = g->M;
+    order_after_sweeps(g);
     if (dx) ensure_sensitivities(g);
     double* o_loss = g->hout + L * d + M + L * P * d;
     const bool small_grad = g->hgrad != nullptr;                         // gradient written straight to mapped host memory
@@ -363,15 +379,15 @@ static double do_lik(moihgp_gp* g, const double* x, const double* y, const doubl
 // U = polar(Uparam) (moihgp.h:433-447), always on the device: Newton-Schulz on the MFMA GEMMs (polar.hip), or, for small
 // matrices (the 8 x 4 demo of example.py, a 64 x 16 mixing), the same iteration as a single workgroup in LDS -- one launch.
 // MOIHGP_POLAR=gemm forces the multi-kernel path.  The host mirror of U is refreshed lazily (getParams).
-static bool compute_polar(moihgp_gp* g, const double* Uparam);
+static bool compute_polar(moihgp_gp* g, const double* Uparam, bool from_device = false);
 static bool compute_polar_fwd(moihgp_gp* g, const double* Uparam) { return compute_polar(g, Uparam); }
-static bool compute_polar(moihgp_gp* g, const double* Uparam) {
+static bool compute_polar(moihgp_gp* g, const double* Uparam, bool from_device) {
     const size_t M = g->M, L = g->L;
     bool small = polar_small_fits(M, L);
     if (const char* e = std::getenv("MOIHGP_POLAR")) { if (e[0] == 'g') small = false; }
     order_after_sweeps(g);
     g->u32_valid = false;
-    MOIHGP_HIP_FATAL(hipMemcpyAsync(g->dU, Uparam, sizeof(double) * M * L, hipMemcpyHostToDevice, g->stream));
+    MOIHGP_HIP_FATAL(hipMemcpyAsync(g->dU, Uparam, sizeof(double) * M * L, from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, g->stream));
     int its = 0;
     if (small) {
         // asynchronous: the kernel leaves its verdict in mapped host memory (and NaN in U if the input is rank deficient);
@@ -391,17 +407,28 @@ static bool compute_polar(moihgp_gp* g, const double* Uparam) {
     return true;
 }
 
-static void do_update(moihgp_gp* g, const double* params) {          // moihgp.h:431-457
+static void do_update(moihgp_gp* g, const double* params, bool from_device = false) {          // moihgp.h:431-457
     const size_t M = g->M, L = g->L, sizeU = M * L;
-    if (!compute_polar(g, params)) {
+    std::vector<double> tail;
+    if (from_device) {
+        // device-resident parameters (moihgp_update_dev): the mixing part goes device -> device into the polar factor; the small tail
+        // [S | sigma | per-latent values] is mirrored to the host (getParams, the per-tick bookkeeping) -- 8 (L + 1 + L P) bytes
+        tail.resize(L + 1 + L * (size_t)g->P);
+        order_after_sweeps(g);
+        MOIHGP_HIP_FATAL(hipMemcpyAsync(tail.data(), params + sizeU, sizeof(double) * tail.size(), hipMemcpyDeviceToHost, g->stream));
+    }
+    const bool polar_ok = compute_polar(g, params, from_device);
+    if (from_device) MOIHGP_HIP_FATAL(hipStreamSynchronize(g->stream));   // (the tail has arrived; the multi-kernel polar factor has synchronised already)
+    const double* tp = from_device ? tail.data() : params + sizeU;       // [S | sigma | per-latent values]
+    if (!polar_ok) {
         set_last_error("update: mixing matrix is rank deficient");
         std::fprintf(stderr, "libmoihgp: %s\n", g_last_error);
         for (auto& u : g->U) u = std::nan("");
         g->U_host_stale = false;
     }
-    for (size_t l = 0; l < L; l++) g->S[l] = params[sizeU + l];          // moihgp.h:448
-    g->sigma = params[sizeU + L];                                        // moihgp.h:449
-    for (size_t i = 0; i < L * (size_t)g->P; i++) g->igp[i] = params[sizeU + L + 1 + i];   // moihgp.h:450-456
+    for (size_t l = 0; l < L; l++) g->S[l] = tp[l];                      // moihgp.h:448
+    g->sigma = tp[L];                                                    // moihgp.h:449
+    for (size_t i = 0; i < L * (size_t)g->P; i++) g->igp[i] = tp[L + 1 + i];   // moihgp.h:450-456
     upload_mixing(g);
     run_ihgp_update(g);                                                  // ends with a stream synchronisation
     if (g->polar_pending) {
@@ -645,8 +672,7 @@ static int filter_stream_io_impl(moihgp_gp* gp, int dtype, const void* Ty, size_
             return 1;
         }
     }
-    const char* ve = std::getenv("MOIHGP_FILTER_VARIANT");   // tuning hook: kernel tiling variant
-    const int variant = ve ? std::atoi(ve) : 0;
+    const int variant = gp->opt_filter_variant;              // tuning probes: only a -DMOIHGP_TUNING build accepts a non-zero value
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (!gp->prof_ev.empty() && 2 * (size_t)(gp->prof_n + 1) <= gp->prof_ev.size() && (gp->prof_seen++ % gp->prof_stride) == 0) {
         e0 = gp->prof_ev[2 * gp->prof_n];
@@ -656,17 +682,17 @@ static int filter_stream_io_impl(moihgp_gp* gp, int dtype, const void* Ty, size_
     if (kernel_stack(gp->kernel)) {
         const size_t slen = gp->L < 1024 ? gp->L * 16 : 0;              // per-slice NLL partials of the time split (few latents only)
         if (slen && !gp->dxscratch) gp->dxscratch = dev_alloc<double>(slen);
-        const char* fs = std::getenv("MOIHGP_FILTER_SPLIT");            // tuning / test hook, as for the reference models: 1 = off, n = slices
         if (gp->L >= 1024 && !gp->dlink) gp->dlink = dev_alloc<double>(gp->L * 144);     // hand-over records of the second (broken-link) pass
         int rc = launch_filter_stream_x(gp->kernel, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cb32, x_in, x, yhat, nll, (hipStream_t)stream, e0, e1,
-                                        gp->dxscratch, slen, fs ? std::atoi(fs) : 0, ld_out, gp->L >= 1024 ? gp->dfallback : nullptr, gp->dlink, nll ? nll_total : nullptr);
+                                        gp->dxscratch, slen, gp->opt_filter_split /* test hook: 1 = off, n = slices */, ld_out, gp->L >= 1024 ? gp->dfallback : nullptr, gp->dlink, nll ? nll_total : nullptr,
+                                        gp->opt_filter_maxlinks);
         return rc;
     }
     // time split across the wavefronts of a workgroup when there are too few latents to fill the chip
     int nsplit = 1, nbig = 1; size_t Tslice = T;
     filter_split_plan(dtype, T, gp->L, &nsplit, &Tslice, &nbig);
-    if (const char* se = std::getenv("MOIHGP_FILTER_SPLIT")) {          // tuning hook: force the slice count (1 = off)
-        int n = std::atoi(se);
+    if (gp->opt_filter_split != 0) {                                    // test / tuning hook: force the slice count (1 = off)
+        int n = gp->opt_filter_split;
         const size_t seg = 64 * (size_t)(dtype == 0 ? kChunk64 : kChunk32);
         if (n <= 1 || T == 0) { nsplit = 1; Tslice = T; nbig = 1; }
         else {
@@ -742,7 +768,11 @@ static int grad_stream_impl(moihgp_gp* gp, int dtype, const void* Ty, size_t T, 
     if (kernel_stack(gp->kernel))
         {
         if (!gp->dhp) gp->dhp = dev_alloc<double>(gp->L * gradx_hp_len(gp->d));    // table of the time-parallel sweep (grad_scan_x.hip)
-        return launch_grad_stream_x(gp->kernel, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cbd64, x, dx, yhat, nll, grad, (hipStream_t)stream, 1, gp->dfallback, gp->dhp);
+        // (the table only changes with the hyper-parameters: rebuilt on the first sweep after an update, in this sweep's stream order)
+        const int rc = launch_grad_stream_x(gp->kernel, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cbd64, x, dx, yhat, nll, grad, (hipStream_t)stream, 1, gp->dfallback, gp->dhp,
+                                            gp->hp_valid ? 0 : 1);
+        if (rc == 0) gp->hp_valid = true;
+        return rc;
     }
     return launch_grad_stream(gp->d, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cb32, x, dx, yhat, nll, grad, gp->dfallback, (hipStream_t)stream);
 }
@@ -771,7 +801,8 @@ static int project_stream_impl(moihgp_gp* gp, int dtype, const void* Y, size_t T
     if (int rc = launch_project_stream(dtype, Y, T, gp->M, gp->L, gp->dU, dtype == MOIHGP_F64 ? nullptr : mixing_f32(gp), gp->dinvsqrtS, Ty, ld,
                                        (hipStream_t)stream)) return rc;
     // partially observed ticks: least squares over the observed rows (moihgp.h:167-178), one workgroup per tick behind the GEMM
-    if (gp->mix_ortho && gp->L <= 16384) return launch_project_stream_missing(dtype, Y, T, gp->M, gp->L, gp->dU, gp->dinvsqrtS, Ty, ld, (hipStream_t)stream);
+    // (beyond ls_project_fits the NaN column stands, as include/moihgp.h documents: the recursion treats the tick as missing)
+    if (gp->mix_ortho && ls_project_fits(gp->L)) return launch_project_stream_missing(dtype, Y, T, gp->M, gp->L, gp->dU, gp->dinvsqrtS, Ty, ld, (hipStream_t)stream);
     return 0;
 }
 
@@ -795,11 +826,25 @@ static int window_set_impl(moihgp_gp* gp, const double* Y, size_t W) {
     if (!gp || gp->latents_only) { set_last_error("window_set needs a full MOIHGP object"); return 1; }
     if (!Y || W == 0) { set_last_error("window_set: empty window"); return 1; }
     const size_t M = gp->M, L = gp->L, d = gp->d, P = gp->P, ldw = (W + 1) / 2 * 2;
-    for (size_t i = 0; i < W * M; i++)
-        if (Y[i] != Y[i]) { set_last_error("window_set: missing outputs (NaN) are not supported by the batched objective; use the per-tick ABI"); return 3; }
+    // ticks with missing outputs (moihgp.h:462-494): projected by least squares over the observed rows with the stream path's k x k
+    // kernel; its limits are checked here, on the host, so that a window it cannot take is refused (rc 3) instead of evaluated wrongly
+    std::vector<int> tmiss(W, 0);
+    bool any = false;
+    for (size_t t = 0; t < W; t++) {
+        size_t k = 0;
+        for (size_t m = 0; m < M; m++) k += (Y[t * M + m] != Y[t * M + m]) ? 1 : 0;
+        if (k == 0) continue;
+        any = true; tmiss[t] = 1;
+        if (k > (size_t)kLsMaxMissing || M - k < L || !gp->mix_ortho || !ls_project_fits(L)) {
+            set_last_error("window_set: tick %zu has %zu of %zu outputs missing (the batched objective takes at most %d per tick, at least %zu observed, "
+                           "orthonormal mixing, L <= 15040); use the per-tick ABI", t, k, M, kLsMaxMissing, L);
+            return 3;
+        }
+    }
     const size_t need = 2 * W * M + 3 * L * ldw + W + 2 * L + L * P + L * d + L * P * d + 16;
+    order_after_sweeps(gp);
     if (gp->win_cap < need) {
-        if (gp->dwin) MOIHGP_HIP_FATAL(hipFree(gp->dwin));
+        if (gp->dwin) { MOIHGP_HIP_FATAL(hipStreamSynchronize(gp->stream)); MOIHGP_HIP_FATAL(hipFree(gp->dwin)); gp->dwin = nullptr; gp->win_cap = 0; gp->win.W = 0; }
         gp->dwin = dev_alloc<double>(need);
         gp->win_cap = need;
     }
@@ -810,6 +855,17 @@ static int window_set_impl(moihgp_gp* gp, const double* Y, size_t W) {
     w.Ty = p; p += L * ldw;  w.hx = p; p += L * ldw;  w.Z = p; p += L * ldw;
     w.rt = p; p += W;  w.spu = p; p += L;  w.nll = p; p += L;  w.gl = p; p += L * P;
     w.x = p; p += L * d;  w.dx = p; p += L * P * d;
+    w.tmiss = nullptr;
+    gp->win_has_nan = any;
+    if (any) {
+        if (gp->winmiss_cap < W) {
+            if (gp->dwinmiss) { MOIHGP_HIP_FATAL(hipStreamSynchronize(gp->stream)); MOIHGP_HIP_FATAL(hipFree(gp->dwinmiss)); gp->dwinmiss = nullptr; gp->winmiss_cap = 0; }
+            gp->dwinmiss = dev_alloc<int>(W);
+            gp->winmiss_cap = W;
+        }
+        MOIHGP_HIP_FATAL(hipMemcpyAsync(gp->dwinmiss, tmiss.data(), sizeof(int) * W, hipMemcpyHostToDevice, gp->stream));
+        w.tmiss = gp->dwinmiss;
+    }
     MOIHGP_HIP_FATAL(hipMemcpyAsync(w.Y, Y, sizeof(double) * W * M, hipMemcpyHostToDevice, gp->stream));
     MOIHGP_HIP_FATAL(hipStreamSynchronize(gp->stream));
     return 0;
@@ -819,25 +875,93 @@ int moihgp_window_set(moihgp_gp* gp, const double* Y, size_t W) {
     return guard_rc([&] { return window_set_impl(gp, Y, W); });
 }
 
-static int window_eval_impl(moihgp_gp* gp, const double* x, const double* dx, double* loss, double* grad, double* xnew, double* dxnew) {
+// dev == false: the reference-shaped form (host vectors in and out); dev == true: every pointer is a device pointer (moihgp_window_eval_dev)
+static int window_eval_impl(moihgp_gp* gp, const double* x, const double* dx, double* loss, double* grad, double* xnew, double* dxnew, bool dev) {
     if (!gp || gp->latents_only || gp->win.W == 0) { set_last_error("window_eval: call moihgp_window_set first"); return 1; }
     if (!x || !dx || !loss || !grad) { set_last_error("window_eval: null argument"); return 1; }
     const size_t L = gp->L, d = gp->d, P = gp->P;
     WindowBufs& w = gp->win;
-    MOIHGP_HIP_FATAL(hipMemcpyAsync(w.x, x, sizeof(double) * L * d, hipMemcpyHostToDevice, gp->stream));
-    MOIHGP_HIP_FATAL(hipMemcpyAsync(w.dx, dx, sizeof(double) * L * P * d, hipMemcpyHostToDevice, gp->stream));
+    order_after_sweeps(gp);        // the sweep below shares the handle's flag / list scratch with sweeps that may still be in flight on caller streams
+    const hipMemcpyKind in = dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, out = dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    MOIHGP_HIP_FATAL(hipMemcpyAsync(w.x, x, sizeof(double) * L * d, in, gp->stream));
+    MOIHGP_HIP_FATAL(hipMemcpyAsync(w.dx, dx, sizeof(double) * L * P * d, in, gp->stream));
     ensure_sensitivities(gp);
-    if (int rc = launch_window_objective(gp->tick(), gp->cb64, gp->cb32, w, gp->dfallback, gp->dloss, gp->dgrad, gp->stream, gp->kernel)) return rc;
-    MOIHGP_HIP_FATAL(hipMemcpyAsync(loss, gp->dloss, sizeof(double), hipMemcpyDeviceToHost, gp->stream));
-    MOIHGP_HIP_FATAL(hipMemcpyAsync(grad, gp->dgrad, sizeof(double) * gp->num_param, hipMemcpyDeviceToHost, gp->stream));
-    if (xnew) MOIHGP_HIP_FATAL(hipMemcpyAsync(xnew, w.x, sizeof(double) * L * d, hipMemcpyDeviceToHost, gp->stream));
-    if (dxnew) MOIHGP_HIP_FATAL(hipMemcpyAsync(dxnew, w.dx, sizeof(double) * L * P * d, hipMemcpyDeviceToHost, gp->stream));
+    // device form: the kernels write the loss and the gradient straight into the caller's arrays
+    if (int rc = launch_window_objective(gp->tick(), gp->cb64, gp->cb32, w, gp->dfallback, dev ? loss : gp->dloss, dev ? grad : gp->dgrad, gp->stream, gp->kernel)) return rc;
+    if (!dev) {
+        MOIHGP_HIP_FATAL(hipMemcpyAsync(loss, gp->dloss, sizeof(double), hipMemcpyDeviceToHost, gp->stream));
+        MOIHGP_HIP_FATAL(hipMemcpyAsync(grad, gp->dgrad, sizeof(double) * gp->num_param, hipMemcpyDeviceToHost, gp->stream));
+    }
+    if (xnew) MOIHGP_HIP_FATAL(hipMemcpyAsync(xnew, w.x, sizeof(double) * L * d, out, gp->stream));
+    if (dxnew) MOIHGP_HIP_FATAL(hipMemcpyAsync(dxnew, w.dx, sizeof(double) * L * P * d, out, gp->stream));
     MOIHGP_HIP_FATAL(hipStreamSynchronize(gp->stream));
     return 0;
 }
 
 int moihgp_window_eval(moihgp_gp* gp, const double* x, const double* dx, double* loss, double* grad, double* xnew, double* dxnew) {
-    return guard_rc([&] { return window_eval_impl(gp, x, dx, loss, grad, xnew, dxnew); });
+    return guard_rc([&] { return window_eval_impl(gp, x, dx, loss, grad, xnew, dxnew, false); });
+}
+
+int moihgp_window_eval_dev(moihgp_gp* gp, const double* x_dev, const double* dx_dev, double* loss_dev, double* grad_dev, double* xnew_dev, double* dxnew_dev) {
+    return guard_rc([&] { return window_eval_impl(gp, x_dev, dx_dev, loss_dev, grad_dev, xnew_dev, dxnew_dev, true); });
+}
+
+int moihgp_update_dev(moihgp_gp* gp, const double* params_dev) {
+    return guard_rc([&] {
+        if (!gp || gp->latents_only || !params_dev) { set_last_error("update_dev: needs a full MOIHGP object and a device parameter vector"); return 1; }
+        do_update(gp, params_dev, true);
+        return 0;
+    });
+}
+
+int moihgp_get_params_dev(moihgp_gp* gp, double* params_dev) {
+    return guard_rc([&] {
+        if (!gp || gp->latents_only || !params_dev) { set_last_error("get_params_dev: needs a full MOIHGP object and a device array"); return 1; }
+        const size_t M = gp->M, L = gp->L, sizeU = M * L;
+        order_after_sweeps(gp);
+        if (gp->U_host_stale) MOIHGP_HIP_FATAL(hipMemcpyAsync(params_dev, gp->dU, sizeof(double) * sizeU, hipMemcpyDeviceToDevice, gp->stream));
+        else MOIHGP_HIP_FATAL(hipMemcpyAsync(params_dev, gp->U.data(), sizeof(double) * sizeU, hipMemcpyHostToDevice, gp->stream));
+        std::vector<double> tail(L + 1 + L * (size_t)gp->P);
+        std::memcpy(tail.data(), gp->S.data(), sizeof(double) * L);
+        tail[L] = gp->sigma;
+        std::memcpy(tail.data() + L + 1, gp->igp.data(), sizeof(double) * L * gp->P);
+        MOIHGP_HIP_FATAL(hipMemcpyAsync(params_dev + sizeU, tail.data(), sizeof(double) * tail.size(), hipMemcpyHostToDevice, gp->stream));
+        MOIHGP_HIP_FATAL(hipStreamSynchronize(gp->stream));
+        return 0;
+    });
+}
+
+int moihgp_release_stream(moihgp_gp* gp, void* stream) {
+    return guard_rc([&] {
+        if (!gp) { set_last_error("null handle"); return 1; }
+        hipStream_t s = (hipStream_t)stream;
+        for (size_t i = 0; i < gp->user_streams.size(); i++) {
+            if (gp->user_streams[i] != s) continue;
+            if (!gp->order_ev) MOIHGP_HIP_FATAL(hipEventCreateWithFlags(&gp->order_ev, hipEventDisableTiming));
+            MOIHGP_HIP_FATAL(hipEventRecord(gp->order_ev, s));
+            MOIHGP_HIP_FATAL(hipStreamWaitEvent(gp->stream, gp->order_ev, 0));
+            gp->user_streams.erase(gp->user_streams.begin() + (long)i);
+            break;
+        }
+        return 0;
+    });
+}
+
+int moihgp_set_option(moihgp_gp* gp, const char* name, long value) {
+    if (!gp || !name) { set_last_error("set_option: null argument"); return 1; }
+    const std::string n(name);
+    if (n == "filter_split") { if (value < 0 || value > 64) { set_last_error("filter_split: 0 (automatic), 1 (off) or a slice count"); return 1; } gp->opt_filter_split = (int)value; return 0; }
+    if (n == "filter_maxlinks") { if (value < -1 || value > 64) { set_last_error("filter_maxlinks: -1 (automatic) .. 64"); return 1; } gp->opt_filter_maxlinks = (int)value; return 0; }
+    if (n == "filter_variant") {
+#ifdef MOIHGP_TUNING
+        gp->opt_filter_variant = (int)value; return 0;
+#else
+        if (value == 0) return 0;
+        set_last_error("filter_variant: the tuning probes are compiled only with -DMOIHGP_TUNING (make TUNING=1)"); return 1;
+#endif
+    }
+    set_last_error("set_option: unknown option '%s'", name);
+    return 1;
 }
 
 static int pin_host_buffer_impl(moihgp_gp* gp, void* ptr, size_t bytes) {

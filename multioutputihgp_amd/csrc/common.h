@@ -126,7 +126,8 @@ int launch_filter_stream_x(int kernel, int dtype, const void* Ty, size_t T, size
                            const void* xin, void* x, void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
                            double* scratch = nullptr /* [scratch_len] per-slice NLL partials of the time split */, size_t scratch_len = 0,
                            int force_slices = 0 /* tuning / test hook: 1 = no split, n > 1 = n slices */, size_t ld_out = 0 /* row stride of yhat; 0 = ld */,
-                           int* link_flags = nullptr /* [L] */, double* link_state = nullptr /* [L][144] */, double* total = nullptr /* sum of nll[] */
+                           int* link_flags = nullptr /* [L] */, double* link_state = nullptr /* [L][144] */, double* total = nullptr /* sum of nll[] */,
+                           int max_links = -1 /* -1: automatic */
                            /* scratch; with both (L >= 1024): segments with few gaps are handled as broken links by a second pass instead of
                               being walked tick by tick */);
 
@@ -138,12 +139,13 @@ int launch_grad_stream_x(int kernel, int dtype, const void* Ty, size_t T, size_t
                          void* x, void* dx, void* yhat, double* nll, double* grad, hipStream_t stream,
                          int out_mode = 1 /* 1: yhat holds filtered means, 2: predicted means HA x_t (pre-step state) */,
                          int* flags = nullptr /* device [L] */, double* hp = nullptr /* device [L][gradx_hp_len(d)] */
-                         /* with both scratch areas, streams of >= 512 ticks take the time-parallel sweep */);
+                         /* with both scratch areas, streams of >= 512 ticks take the time-parallel sweep */,
+                         int hp_build = 1 /* 0: hp already holds the table of the current hyper-parameters */);
 constexpr size_t gradx_hp_len(int d) { return (size_t)(kChunkX * d + 15) / 16 * 16; }
 // grad_scan_x.hip: the same sweep parallel in time over the stream's whole 32-tick chunks [0, Tpar); flags[l] = 1 marks latents left
 // untouched (missing ticks, unusable scan tables), for the others (x, dx, nll, grad) hold the state after / sums over those ticks.
 int launch_grad_scan_x(int kernel, int dtype, const void* Ty, size_t Tpar, size_t ld, size_t L, const double* cb64, const double* cbd64,
-                       void* x, void* dx, void* yhat, double* nll, double* grad, int* flags, double* hp, hipStream_t stream, int out_mode);
+                       void* x, void* dx, void* yhat, double* nll, double* grad, int* flags, double* hp, hipStream_t stream, int out_mode, int hp_build = 1);
 
 // recursion.hip: batched sweeps over series-major streams.
 int launch_filter_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, size_t L,
@@ -182,6 +184,10 @@ void launch_project_tick(const TickArgs& a, const double* y, double* Ty, double*
 void launch_project_tick_missing(const TickArgs& a, const double* y, double* Ty, double* work /*L*L+L*/, hipStream_t s);
 // whole streams: re-project the ticks whose observation vector holds NaN by least squares over the observed rows (moihgp.h:167-178),
 // behind launch_project_stream; needs U^T U = I (a polar factor).  Y [T][M], Ty [L][ld] of `dtype`.
+constexpr int kLsMaxMissing = 64;          // missing outputs per tick the k x k system is built for (one wavefront eliminates it, lane = row)
+// the least-squares kernel keeps r = U^T y0 [L] and the augmented k x (k + 1) system in the workgroup's LDS: L <= 15040
+constexpr size_t ls_project_lds_bytes(size_t L) { return (L + (size_t)kLsMaxMissing * (kLsMaxMissing + 1)) * sizeof(double); }
+constexpr bool ls_project_fits(size_t L) { return ls_project_lds_bytes(L) <= 150 * 1024; }
 int launch_project_stream_missing(int dtype, const void* Y, size_t T, size_t M, size_t L, const double* U, const double* invsqrtS, void* Ty, size_t ld,
                                    hipStream_t s);
 void launch_ortho_defect(const double* G /* L x L */, size_t L, double* out /* device scalar: max |G - I| */, hipStream_t s);
@@ -235,6 +241,7 @@ struct WindowBufs {
     double* gl;               // [L][P]
     double* x;                // [L][d]
     double* dx;               // [L][P][d]
+    const int* tmiss = nullptr;   // [W] 1 where y_t holds NaN (missing outputs), or NULL when the window holds none
 };
 int launch_window_objective(const TickArgs& a, const double* cb64, const float* cb32, const WindowBufs& w, int* fallback,
                             double* loss /* device scalar */, double* grad /* device [M*L+L+1+L*P] */, hipStream_t s,

@@ -515,9 +515,9 @@ grad_scan_x_kernel(const TS* __restrict__ Ty, size_t Tpar /* whole chunks */, si
 
 template <typename TS, int DB, int J>
 int launch_gsx(const void* Ty, size_t Tpar, size_t ld, size_t L, const double* cb64, const double* cbd64, void* x, void* dx, void* yhat,
-               double* nll, double* grad, int* flags, double* hp, hipStream_t stream, int out_mode) {
+               double* nll, double* grad, int* flags, double* hp, hipStream_t stream, int out_mode, int hp_build) {
     dim3 block(64 * kGxWaves), grid((unsigned)((L + kGxWaves - 1) / kGxWaves));
-    hipLaunchKernelGGL((hp_table_kernel<DB * J>), dim3((unsigned)L), dim3(64), 0, stream, cb64, hp, L);
+    if (hp_build) hipLaunchKernelGGL((hp_table_kernel<DB * J>), dim3((unsigned)L), dim3(64), 0, stream, cb64, hp, L);
 #define MOIHGP_GSX_LAUNCH(W_) hipLaunchKernelGGL((grad_scan_x_kernel<TS, DB, J, W_>), grid, block, 0, stream, (const TS*)Ty, Tpar, ld, L, cb64, cbd64, \
                                                  (TS*)x, (TS*)dx, (TS*)yhat, nll, grad, flags, (const double*)hp)
     if (yhat && out_mode == 2) MOIHGP_GSX_LAUNCH(2);
@@ -534,13 +534,13 @@ int launch_gsx(const void* Ty, size_t Tpar, size_t ld, size_t L, const double* c
 // The whole chunks [0, Tpar) of every latent's stream; flags[l] = 1 where the latent was left untouched (missing ticks, unusable scan
 // tables), 0 where (x, dx, nll, grad) now hold the state after / the sums over those Tpar ticks.
 int launch_grad_scan_x(int kernel, int dtype, const void* Ty, size_t Tpar, size_t ld, size_t L, const double* cb64, const double* cbd64,
-                       void* x, void* dx, void* yhat, double* nll, double* grad, int* flags, double* hp, hipStream_t stream, int out_mode) {
+                       void* x, void* dx, void* yhat, double* nll, double* grad, int* flags, double* hp, hipStream_t stream, int out_mode, int hp_build) {
     if (L == 0) return 0;
     const int base = kernel_base(kernel), J = kernel_stack(kernel);
 #define MOIHGP_GSX_CASE(DBB, JJ)                                                                                                        \
     if (base == (DBB == 2 ? 0 : 1) && J == JJ)                                                                                          \
-        return dtype == 0 ? launch_gsx<double, DBB, JJ>(Ty, Tpar, ld, L, cb64, cbd64, x, dx, yhat, nll, grad, flags, hp, stream, out_mode)  \
-                          : launch_gsx<float, DBB, JJ>(Ty, Tpar, ld, L, cb64, cbd64, x, dx, yhat, nll, grad, flags, hp, stream, out_mode)
+        return dtype == 0 ? launch_gsx<double, DBB, JJ>(Ty, Tpar, ld, L, cb64, cbd64, x, dx, yhat, nll, grad, flags, hp, stream, out_mode, hp_build)  \
+                          : launch_gsx<float, DBB, JJ>(Ty, Tpar, ld, L, cb64, cbd64, x, dx, yhat, nll, grad, flags, hp, stream, out_mode, hp_build)
     MOIHGP_GSX_CASE(2, 2); MOIHGP_GSX_CASE(2, 3); MOIHGP_GSX_CASE(2, 4);
     MOIHGP_GSX_CASE(3, 2); MOIHGP_GSX_CASE(3, 3); MOIHGP_GSX_CASE(3, 4);
 #undef MOIHGP_GSX_CASE

@@ -136,7 +136,7 @@ int launch_gx(const void* Ty, size_t Tlen, size_t ld, size_t L, const double* cb
 }  // namespace
 
 int launch_grad_stream_x(int kernel, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* cb64, const double* cbd64,
-                         void* x, void* dx, void* yhat, double* nll, double* grad, hipStream_t stream, int out_mode, int* flags, double* hp) {
+                         void* x, void* dx, void* yhat, double* nll, double* grad, hipStream_t stream, int out_mode, int* flags, double* hp, int hp_build) {
     if (L == 0) return 0;
     // long streams: the time-parallel sweep (grad_scan_x.hip) takes the whole 32-tick chunks of every latent it can; what it leaves
     // (flags[l] = 1: missing ticks, unusable scan tables; the last T mod 32 ticks of the others) is walked tick by tick here
@@ -145,7 +145,7 @@ int launch_grad_stream_x(int kernel, int dtype, const void* Ty, size_t T, size_t
     size_t t_cont = 0;
     if (flags && hp && T >= scan_from) {
         t_cont = T / kChunkX * kChunkX;
-        if (int rc = launch_grad_scan_x(kernel, dtype, Ty, t_cont, ld, L, cb64, cbd64, x, dx, yhat, nll, grad, flags, hp, stream, out_mode)) return rc;
+        if (int rc = launch_grad_scan_x(kernel, dtype, Ty, t_cont, ld, L, cb64, cbd64, x, dx, yhat, nll, grad, flags, hp, stream, out_mode, hp_build)) return rc;
         only = flags;
     }
     const int base = kernel_base(kernel), J = kernel_stack(kernel);

@@ -688,27 +688,31 @@ int launch_filter_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, 
     } while (0)
     // register caps: fp32 <= 128 VGPRs (4 waves/SIMD: all 4096 wavefronts of a 4096-latent shard resident),
     // fp64 uncapped (188 VGPRs, 2 waves/SIMD: capping it to 168 spills and is 35 % slower)
+#ifdef MOIHGP_TUNING
+    // Tuning probes (make TUNING=1 -> lib/libmoihgp_tuning.so; tools/kbench.py): other register caps (1), plain stores (2), nontemporal
+    // loads (4), both (6), and the staging-only kernel (9), which does NO arithmetic.  None of them is part of the shipped library.
+    if (variant == 1 && dtype == 0 && d == 3) MOIHGP_FILTER_CASE(double, 3, kChunk64, 3, cb64);
+    if (dtype == 1 && d == 3 && (variant == 2 || variant == 4 || variant == 6 || variant == 9)) {
+        dim3 block(64 * kWavesPerBlock), grid((unsigned)((L + kWavesPerBlock - 1) / kWavesPerBlock));
+        const size_t sm = (size_t)kWavesPerBlock * (64 * 5 * 16 + 36 * 4);
+#define MOIHGP_PROBE(MW, DBG_) hipExtLaunchKernelGGL((filter_scan_kernel<float, 3, kChunk32, true, true, MW, false, DBG_>), grid, block, sm, stream, ev0, ev1, 0, \
+                                                     (const float*)Ty, T, ld, L, cb32, cb64, (const float*)xin, (float*)x, (float*)yhat, nll, 1, T, 1, ldo)
+        if (variant == 2) MOIHGP_PROBE(4, 2);
+        else if (variant == 4) MOIHGP_PROBE(4, 4);
+        else if (variant == 6) MOIHGP_PROBE(4, 6);
+        else MOIHGP_PROBE(1, 1);
+#undef MOIHGP_PROBE
+        return 0;
+    }
+    if (variant == 1 && dtype == 1 && d == 3) MOIHGP_FILTER_CASE(float, 3, kChunk32, 1, cb32);
+#else
+    if (variant != 0) { set_last_error("filter variant %d: tuning probes are compiled only with -DMOIHGP_TUNING", variant); return 1; }
+#endif
     if (dtype == 0) {
         if (d == 2) MOIHGP_FILTER_CASE(double, 2, kChunk64, 1, cb64);
-        if (variant == 1) MOIHGP_FILTER_CASE(double, 3, kChunk64, 3, cb64);
         MOIHGP_FILTER_CASE(double, 3, kChunk64, 1, cb64);
     }
     if (d == 2) MOIHGP_FILTER_CASE(float, 2, kChunk32, 4, cb32);
-    if (variant == 2 || variant == 4 || variant == 6) {   // tuning probes: plain stores (2), nontemporal loads (4), both (6)
-        dim3 block(64 * kWavesPerBlock), grid((unsigned)((L + kWavesPerBlock - 1) / kWavesPerBlock));
-        const size_t sm = (size_t)kWavesPerBlock * (64 * 5 * 16 + 36 * 4);
-        if (variant == 2) hipExtLaunchKernelGGL((filter_scan_kernel<float, 3, kChunk32, true, true, 4, false, 2>), grid, block, sm, stream, ev0, ev1, 0, (const float*)Ty, T, ld, L, cb32, cb64, (const float*)xin, (float*)x, (float*)yhat, nll, 1, T, 1, ldo);
-        else if (variant == 4) hipExtLaunchKernelGGL((filter_scan_kernel<float, 3, kChunk32, true, true, 4, false, 4>), grid, block, sm, stream, ev0, ev1, 0, (const float*)Ty, T, ld, L, cb32, cb64, (const float*)xin, (float*)x, (float*)yhat, nll, 1, T, 1, ldo);
-        else hipExtLaunchKernelGGL((filter_scan_kernel<float, 3, kChunk32, true, true, 4, false, 6>), grid, block, sm, stream, ev0, ev1, 0, (const float*)Ty, T, ld, L, cb32, cb64, (const float*)xin, (float*)x, (float*)yhat, nll, 1, T, 1, ldo);
-        return 0;
-    }
-    if (variant == 9) {   // tuning probe (staging only)
-        dim3 block(64 * kWavesPerBlock), grid((unsigned)((L + kWavesPerBlock - 1) / kWavesPerBlock));
-        hipExtLaunchKernelGGL((filter_scan_kernel<float, 3, kChunk32, true, true, 1, false, 1>), grid, block, (size_t)kWavesPerBlock * (64 * 5 * 16 + 36 * 4), stream, ev0, ev1, 0,
-                              (const float*)Ty, T, ld, L, cb32, cb64, (const float*)xin, (float*)x, (float*)yhat, nll, 1, T, 1, ldo);
-        return 0;
-    }
-    if (variant == 1) MOIHGP_FILTER_CASE(float, 3, kChunk32, 1, cb32);
     MOIHGP_FILTER_CASE(float, 3, kChunk32, 4, cb32);
 #undef MOIHGP_FILTER_CASE
 }

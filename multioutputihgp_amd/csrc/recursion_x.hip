@@ -656,12 +656,11 @@ int launch_x(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, con
 template <typename T, int DB, int J>
 int launch_xd(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, const double* cb64, const void* xin, void* x, void* yhat, double* nll,
               hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, double* scratch, size_t scratch_len, int force_slices, size_t ldo,
-              int* link_flags, double* link_state, double* total) {
+              int* link_flags, double* link_state, double* total, int env_links) {
     constexpr size_t SEG = 64 * (size_t)kChunkX;
     if (L >= 1024) {
         // chunks with a gap per segment up to which the broken-link stages of the second pass beat the tick-by-tick walk (measured,
         // tools/filternan.py: a stage costs one scan + one replay, the second pass of the fp64 d = 12 kernel runs one wave per SIMD)
-        static const int env_links = [] { const char* e = std::getenv("MOIHGP_FILTER_MAXLINKS"); return e ? std::atoi(e) : -1; }();
         const int max_links = env_links >= 0 ? env_links : (DB * J <= kPairMaxDim ? 64 : ((sizeof(T) == 8 && DB * J > 9) ? 3 : 32));
         return launch_x<T, DB, J, 4, false>(Ty, Tlen, ld, L, cbT, cb64, xin, x, yhat, nll, stream, ev0, ev1, 1, max_links, nullptr, ldo,
                                             (max_links > 0 && link_state) ? link_flags : nullptr, link_state, total);
@@ -689,14 +688,14 @@ int launch_xd(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, co
 
 int launch_filter_stream_x(int kernel, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* cb64, const float* cb32,
                            const void* xin, void* x, void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1,
-                           double* scratch, size_t scratch_len, int force_slices, size_t ldo, int* link_flags, double* link_state, double* total) {
+                           double* scratch, size_t scratch_len, int force_slices, size_t ldo, int* link_flags, double* link_state, double* total, int max_links) {
     if (L == 0) return 0;
     if (ldo == 0) ldo = ld;
     const int base = kernel_base(kernel), J = kernel_stack(kernel);
 #define MOIHGP_X_CASE(DBB, JJ)                                                                                        \
     if (base == (DBB == 2 ? 0 : 1) && J == JJ)                                                                        \
-        return dtype == 0 ? launch_xd<double, DBB, JJ>(Ty, T, ld, L, cb64, cb64, xin, x, yhat, nll, stream, ev0, ev1, scratch, scratch_len, force_slices, ldo, link_flags, link_state, total) \
-                          : launch_xd<float, DBB, JJ>(Ty, T, ld, L, cb32, cb64, xin, x, yhat, nll, stream, ev0, ev1, scratch, scratch_len, force_slices, ldo, link_flags, link_state, total)
+        return dtype == 0 ? launch_xd<double, DBB, JJ>(Ty, T, ld, L, cb64, cb64, xin, x, yhat, nll, stream, ev0, ev1, scratch, scratch_len, force_slices, ldo, link_flags, link_state, total, max_links) \
+                          : launch_xd<float, DBB, JJ>(Ty, T, ld, L, cb32, cb64, xin, x, yhat, nll, stream, ev0, ev1, scratch, scratch_len, force_slices, ldo, link_flags, link_state, total, max_links)
 #ifndef MOIHGP_X_ONLY_D12        // (development: -DMOIHGP_X_ONLY_D12 builds the d = 12 kernels alone, for quick resource checks)
     MOIHGP_X_CASE(2, 2); MOIHGP_X_CASE(2, 3); MOIHGP_X_CASE(2, 4);
     MOIHGP_X_CASE(3, 2); MOIHGP_X_CASE(3, 3);

@@ -341,7 +341,6 @@ __global__ void ugrad_kernel(size_t M, size_t L, const double* __restrict__ S, c
 // One workgroup per tick; a tick without NaN costs one pass over its M observations and leaves at once.  fp64 inside whatever the
 // stream type.  k > kLsMaxMissing or fewer observed outputs than latents: the column stays NaN (the recursion then treats the tick as
 // missing; the reference would factor a singular matrix there).
-constexpr int kLsMaxMissing = 64;
 
 template <typename T>
 __global__ void __launch_bounds__(256) ls_project_kernel(const T* __restrict__ Y, size_t Tn, size_t M, size_t L, const double* __restrict__ U,
@@ -462,8 +461,8 @@ void launch_ortho_defect(const double* G, size_t L, double* out, hipStream_t s) 
 int launch_project_stream_missing(int dtype, const void* Y, size_t T, size_t M, size_t L, const double* U, const double* invsqrtS, void* Ty, size_t ld,
                                    hipStream_t s) {
     if (T == 0 || L == 0) return 0;
-    const size_t smem = (L + (size_t)kLsMaxMissing * (kLsMaxMissing + 1)) * sizeof(double);
-    if (smem > 150 * 1024) { set_last_error("project_stream: %zu latents exceed the least-squares kernel's LDS", L); return 1; }
+    if (!ls_project_fits(L)) return 0;                 // (the NaN columns stand: include/moihgp.h)
+    const size_t smem = ls_project_lds_bytes(L);
     if (dtype == 0) {
         if (smem > 48 * 1024) MOIHGP_HIP_FATAL(hipFuncSetAttribute(reinterpret_cast<const void*>(ls_project_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         hipLaunchKernelGGL(ls_project_kernel<double>, dim3((unsigned)T), dim3(256), smem, s, (const double*)Y, T, M, L, U, invsqrtS, (double*)Ty, ld);

@@ -13,7 +13,11 @@
 //                with threading on: the serial branch of the gradient overload drops the per-latent losses, moihgp.h:590 vs :597-607)
 //     grad_S_l = W/(2 S_l) - 1/2 S_l^-3/2 sum_t pv (U^T y) - sigma/S_l^2 g_l[noise]                     (moihgp.h:555-561, :604)
 //     grad_sigma = sum_t 1/2 (m_n - r_t/sigma)/sigma + sum_l g_l[noise]/S_l                             (moihgp.h:563, :605)
-// all fp64.  Ticks with missing outputs (NaN) are not supported here (the caller falls back to the per-tick ABI).
+// all fp64.  A tick with missing outputs (NaN in y_t; tmiss[t] = 1): its column of Ty is re-projected by least squares over the observed
+// rows (moihgp.h:485-494; tick.hip ls_project_kernel, the stream path's kernel), which is all the per-latent terms see (:565-607).  The
+// other terms are, in the reference, dense products with a y_t that holds NaN -- U^T y_t (all NaN), (I - U U^T) y_t, pv with raw y(l)
+// -- so for such a tick (U^T y_t)_l is NaN here too and everything downstream of it follows by arithmetic: loss, grad_U, grad_S,
+// grad_sigma NaN; per-latent gradient and carried state finite.
 #include "common.h"
 
 namespace moihgp {
@@ -26,7 +30,8 @@ template <int D>
 __global__ void __launch_bounds__(256) window_z_kernel(size_t M, size_t L, size_t W, size_t ldw, const double* __restrict__ cb,
                                                        const double* __restrict__ S, const double* __restrict__ sigma_p,
                                                        const double* __restrict__ Y, const double* __restrict__ Ty,
-                                                       const double* __restrict__ hx, double* __restrict__ Z, double* __restrict__ spu) {
+                                                       const double* __restrict__ hx, double* __restrict__ Z, double* __restrict__ spu,
+                                                       const int* __restrict__ tmiss) {
     using Lay = CB<D>;
     const int lane = threadIdx.x & 63;
     const size_t l = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -38,7 +43,7 @@ __global__ void __launch_bounds__(256) window_z_kernel(size_t M, size_t L, size_
     double acc = 0.0;
     for (size_t t = lane; t < W; t += 64) {
         const double pv = (Y[t * M + l] - hx[l * ldw + t]) * f;          // moihgp.h:510-511
-        const double uty = Ty[l * ldw + t] * sq;                          // (U^T y_t)_l
+        const double uty = (tmiss && tmiss[t]) ? __builtin_nan("") : Ty[l * ldw + t] * sq;   // (U^T y_t)_l: a dense product with y_t (moihgp.h:544)
         Z[l * ldw + t] = pv * (1.0 / sq) - uty / sigma;
         acc += pv * uty;
     }
@@ -50,7 +55,8 @@ __global__ void __launch_bounds__(256) window_z_kernel(size_t M, size_t L, size_
 __global__ void __launch_bounds__(256) window_z_x_kernel(size_t M, size_t L, size_t W, size_t ldw, int d, const double* __restrict__ cb,
                                                          const double* __restrict__ S, const double* __restrict__ sigma_p,
                                                          const double* __restrict__ Y, const double* __restrict__ Ty,
-                                                         const double* __restrict__ hx, double* __restrict__ Z, double* __restrict__ spu) {
+                                                         const double* __restrict__ hx, double* __restrict__ Z, double* __restrict__ spu,
+                                                         const int* __restrict__ tmiss) {
     const int lane = threadIdx.x & 63;
     const size_t l = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (l >= L) return;
@@ -63,7 +69,7 @@ __global__ void __launch_bounds__(256) window_z_x_kernel(size_t M, size_t L, siz
     double acc = 0.0;
     for (size_t t = lane; t < W; t += 64) {
         const double pv = (Y[t * M + l] - hx[l * ldw + t]) * f;          // moihgp.h:510-511
-        const double uty = Ty[l * ldw + t] * sq;
+        const double uty = (tmiss && tmiss[t]) ? __builtin_nan("") : Ty[l * ldw + t] * sq;
         Z[l * ldw + t] = pv * (1.0 / sq) - uty / sigma;
         acc += pv * uty;
     }
@@ -129,15 +135,16 @@ int launch_window_objective(const TickArgs& a, const double* cb64, const float* 
                             double* grad, hipStream_t s, int kernel) {
     int rc;
     if ((rc = launch_project_stream(0, w.Y, w.W, a.M, a.L, a.U, nullptr, a.invsqrtS, w.Ty, w.ldw, s))) return rc;
+    if (w.tmiss && (rc = launch_project_stream_missing(0, w.Y, w.W, a.M, a.L, a.U, a.invsqrtS, w.Ty, w.ldw, s))) return rc;   // moihgp.h:485-494
     if (a.d > 3) { if ((rc = launch_grad_stream_x(kernel, 0, w.Ty, w.W, w.ldw, a.L, cb64, a.cbd64, w.x, w.dx, w.hx, w.nll, w.gl, s, /*out_mode=*/2))) return rc; }
     else if ((rc = launch_grad_stream(a.d, 0, w.Ty, w.W, w.ldw, a.L, cb64, cb32, w.x, w.dx, w.hx, w.nll, w.gl, fallback, s, /*out_mode=*/2))) return rc;
     dim3 b256(256);
     if (a.d > 3)
-        hipLaunchKernelGGL(window_z_x_kernel, dim3((unsigned)((a.L + 3) / 4)), b256, 0, s, a.M, a.L, w.W, w.ldw, a.d, cb64, a.S, a.sigma, w.Y, w.Ty, w.hx, w.Z, w.spu);
+        hipLaunchKernelGGL(window_z_x_kernel, dim3((unsigned)((a.L + 3) / 4)), b256, 0, s, a.M, a.L, w.W, w.ldw, a.d, cb64, a.S, a.sigma, w.Y, w.Ty, w.hx, w.Z, w.spu, w.tmiss);
     else if (a.d == 2)
-        hipLaunchKernelGGL(window_z_kernel<2>, dim3((unsigned)((a.L + 3) / 4)), b256, 0, s, a.M, a.L, w.W, w.ldw, cb64, a.S, a.sigma, w.Y, w.Ty, w.hx, w.Z, w.spu);
+        hipLaunchKernelGGL(window_z_kernel<2>, dim3((unsigned)((a.L + 3) / 4)), b256, 0, s, a.M, a.L, w.W, w.ldw, cb64, a.S, a.sigma, w.Y, w.Ty, w.hx, w.Z, w.spu, w.tmiss);
     else
-        hipLaunchKernelGGL(window_z_kernel<3>, dim3((unsigned)((a.L + 3) / 4)), b256, 0, s, a.M, a.L, w.W, w.ldw, cb64, a.S, a.sigma, w.Y, w.Ty, w.hx, w.Z, w.spu);
+        hipLaunchKernelGGL(window_z_kernel<3>, dim3((unsigned)((a.L + 3) / 4)), b256, 0, s, a.M, a.L, w.W, w.ldw, cb64, a.S, a.sigma, w.Y, w.Ty, w.hx, w.Z, w.spu, w.tmiss);
     if ((rc = launch_ugrad_gemm(w.Y, w.W, a.M, w.Z, w.ldw, a.L, grad, s))) return rc;                         // grad[0 .. M*L) = U-gradient
     if ((rc = launch_unproject_stream(0, w.Ty, w.W, w.ldw, a.M, a.L, a.U, nullptr, a.sqrtS, w.UU, s))) return rc;           // U (U^T y_t)
     hipLaunchKernelGGL(window_resid_kernel, dim3((unsigned)((w.W + 3) / 4)), b256, 0, s, a.M, w.W, w.Y, w.UU, w.rt);

@@ -11,8 +11,9 @@ Same constructor, `step(y)`, `covariance`, `params`.  Per tick (online_learning.
      gamma/2 * dtheta^T H^-1 dtheta + sum over the window of the NLL, H^-1 being the previous solve's
      inverse-Hessian estimate.
 The optimiser stays on the host (BASELINE.json north_star); the window sum -- the hot loop -- is ONE device call
-(`MOIHGP.window_objective`, include/moihgp.h `moihgp_window_*`) whenever the window holds no missing outputs, and the
-reference's tick-by-tick loop otherwise.
+(`MOIHGP.window_objective`, include/moihgp.h `moihgp_window_*`), missing outputs included (least-squares projection of such
+ticks on the device, moihgp.h:485-494); only a window beyond that kernel's limits (more than 64 outputs missing in one tick, fewer
+observed outputs than latents) falls back to the reference's tick-by-tick loop.
 
 The proximal term needs the dense inverse Hessian of all M*L + L + 1 + 3L parameters, as in the reference; that is a
 small-model construct (it is quadratic in the parameter count).
@@ -72,9 +73,13 @@ class MOIHGPOnlineLearning:
         """sum over the buffered window of the NLL (and its gradient) from the carried window-start state."""
         Yw = np.array(self.buffer) - self.ma
         gp = self.moihgp
-        if want_grad and hasattr(gp, "window_objective") and not np.isnan(Yw).any():
-            loss, grad, _, _ = gp.window_objective(Yw, self.xinit, self.dxinit)
-            return loss, grad
+        if want_grad and hasattr(gp, "window_objective"):
+            try:
+                loss, grad, _, _ = gp.window_objective(Yw, self.xinit, self.dxinit)
+                return loss, grad
+            except RuntimeError as e:
+                if getattr(e, "rc", None) != 3:          # 3: missing outputs beyond the batched kernel's limits -> the loop below
+                    raise
         xt, dxt = self.xinit, self.dxinit
         loss, grad = 0.0, (np.zeros(gp.num_param) if want_grad else None)
         for yt in Yw:

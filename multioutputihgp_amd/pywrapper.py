@@ -146,21 +146,64 @@ class MOIHGP(object):
         """The learners' windowed objective in ONE call (include/moihgp.h `moihgp_window_*`): equivalent to
         `for y in Y: (xn, _, dxn) = step(x, y, dx); l, g = negLogLikelihood(x, y, dx); loss += l; grad += g; x, dx = xn, dxn`
         (online_learning.py:83-89).  Returns (loss, grad, xnew, dxnew); `grad` is a persistent buffer that the next call
-        overwrites (copy it to keep it).  Raises if Y holds NaN."""
+        overwrites (copy it to keep it).  Ticks with missing outputs (NaN) are projected on the device by least squares over the
+        observed rows like the per-tick path (and, as there, make the loss and the mixing part of the gradient NaN: moihgp.h:499-563);
+        a window beyond that kernel's limits raises MoihgpError with rc == 3."""
         lib = self.__lib
         if set_window:
             Yc = np.ascontiguousarray(Y, dtype=np.float64).reshape(-1, self.num_output)
             rc = lib.moihgp_window_set(self.__obj, Yc.ctypes.data_as(c_double_p), Yc.shape[0])
             if rc != 0:
-                raise MoihgpError(last_error(lib) or "moihgp_window_set failed")
+                raise MoihgpError(last_error(lib) or "moihgp_window_set failed", rc)
         xc = np.ascontiguousarray(x, dtype=np.float64).reshape(self.num_latent, self.igp_dim)
         dxc = np.ascontiguousarray(dx, dtype=np.float64).reshape(self.num_latent, self.num_igp_param, self.igp_dim)
         loss = np.zeros(1); xn = np.zeros_like(xc); dxn = np.zeros_like(dxc)
         rc = lib.moihgp_window_eval(self.__obj, xc.ctypes.data_as(c_double_p), dxc.ctypes.data_as(c_double_p), loss.ctypes.data_as(c_double_p),
                                     self.__wgrad.ctypes.data_as(c_double_p), xn.ctypes.data_as(c_double_p), dxn.ctypes.data_as(c_double_p))
         if rc != 0:
-            raise MoihgpError(last_error(lib) or "moihgp_window_eval failed")
+            raise MoihgpError(last_error(lib) or "moihgp_window_eval failed", rc)
         return float(loss[0]), self.__wgrad, xn, dxn      # persistent (page-locked) buffer: overwritten by the next call
+
+    # ---- device-resident forms (include/moihgp.h "without PCIe in the optimiser's inner loop"): torch CUDA float64 tensors -----------
+    @staticmethod
+    def __dev_ptr(t, n, what):
+        import torch
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and t.numel() == n):
+            raise ValueError(f"{what}: a contiguous CUDA float64 tensor of {n} elements is required")
+        from ctypes import c_void_p
+        return c_void_p(t.data_ptr())
+
+    def update_dev(self, params_dev):
+        """`update` (pywrapper.py:199-201) from a parameter vector that lives on the device: no 8 (M L + ..)-byte host copy."""
+        rc = self.__lib.moihgp_update_dev(self.__obj, self.__dev_ptr(params_dev, self.num_param, "params_dev"))
+        if rc != 0:
+            raise MoihgpError(last_error(self.__lib) or "moihgp_update_dev failed", rc)
+
+    def params_dev(self, out):
+        """`params` into a device vector."""
+        rc = self.__lib.moihgp_get_params_dev(self.__obj, self.__dev_ptr(out, self.num_param, "out"))
+        if rc != 0:
+            raise MoihgpError(last_error(self.__lib) or "moihgp_get_params_dev failed", rc)
+        return out
+
+    def set_window(self, Y):
+        """Install the window Y [W, M] (host) for `window_objective(..., set_window=False)` / `window_objective_dev`."""
+        Yc = np.ascontiguousarray(Y, dtype=np.float64).reshape(-1, self.num_output)
+        rc = self.__lib.moihgp_window_set(self.__obj, Yc.ctypes.data_as(c_double_p), Yc.shape[0])
+        if rc != 0:
+            raise MoihgpError(last_error(self.__lib) or "moihgp_window_set failed", rc)
+
+    def window_objective_dev(self, x_dev, dx_dev, loss_dev, grad_dev, xnew_dev=None, dxnew_dev=None):
+        """`window_objective` on the installed window with every operand on the device: state in, loss (1-element tensor) and gradient
+        [num_param] out, optionally the state after the window."""
+        L, d, P = self.num_latent, self.igp_dim, self.num_igp_param
+        rc = self.__lib.moihgp_window_eval_dev(
+            self.__obj, self.__dev_ptr(x_dev, L * d, "x_dev"), self.__dev_ptr(dx_dev, L * P * d, "dx_dev"), self.__dev_ptr(loss_dev, 1, "loss_dev"),
+            self.__dev_ptr(grad_dev, self.num_param, "grad_dev"),
+            None if xnew_dev is None else self.__dev_ptr(xnew_dev, L * d, "xnew_dev"),
+            None if dxnew_dev is None else self.__dev_ptr(dxnew_dev, L * P * d, "dxnew_dev"))
+        if rc != 0:
+            raise MoihgpError(last_error(self.__lib) or "moihgp_window_eval_dev failed", rc)
 
     @property
     def num_output(self):

@@ -30,7 +30,7 @@ _DT = {torch.float64: 0, torch.float32: 1}
 
 def _check(rc, lib):
     if rc != 0:
-        raise MoihgpError(last_error(lib) or f"libmoihgp call failed (rc={rc})")
+        raise MoihgpError(last_error(lib) or f"libmoihgp call failed (rc={rc})", rc)
 
 
 def _stream_ptr(stream=None):
@@ -93,6 +93,11 @@ class LatentBank:
                 self._h = None
         except Exception:
             pass
+
+    def set_option(self, name: str, value: int):
+        """Per-handle tuning / test hooks (include/moihgp.h moihgp_set_option): "filter_split" (0 automatic, 1 off, n slices),
+        "filter_maxlinks", "filter_variant" (tuning builds only)."""
+        _check(self._lib.moihgp_set_option(self._h, name.encode(), int(value)), self._lib)
 
     def update(self, params_LP):
         p = np.ascontiguousarray(np.asarray(params_LP, dtype=np.float64).reshape(self.L, self.P))

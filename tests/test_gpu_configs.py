@@ -208,3 +208,192 @@ def test_gradient_sweep_at_full_size(env, kern, dtype):
     d = (err((a["nll"] + b["nll"]).cpu().numpy(), r["nll"].cpu().numpy()), err((a["grad"] + b["grad"]).cpu().numpy(), r["grad"].cpu().numpy()),
          err(b["x"].cpu().numpy(), r["x"].cpu().numpy()), err(b["dx"].double().cpu().numpy(), r["dx"].double().cpu().numpy()))
     assert max(d) < tol, d
+
+
+# ------------------------------------------------------------------------------------------ configs[2] at its worded size
+def test_c3_learning_loop_at_full_size(env):
+    """BASELINE.json configs[2] as worded -- "M=4096 outputs, T=10000, Matern-5/2, fp32, online-learning L-BFGS outer loop" -- at
+    M = L = 4096: what the optimiser calls per line-search point (moihgp_online.h:40-72) is MOIHGP::update (moihgp.h:431-457: polar
+    factor of the 4096 x 4096 mixing + IHGP::update of every latent) and the window loop of step + negLogLikelihood with gradient
+    (16.8 M entries); then the filter over the real 10^4-tick observation stream (project -> sweep in fp32 -> unproject).
+      (1) update:  ||U^T U - I||  and  U against the LAPACK-SVD polar factor svdU svdV^T (moihgp.h:438-446);
+      (2) moihgp_window_eval over W = 2 ticks == this handle's own gp52_lik1 / gp52_step1 tick by tick, both `threading` values;
+      (3) W = 16: per-latent gradient block, per-latent losses and carried state of ALL latents against the oracle's gradient sweep
+          over the host-projected window; sampled grad_U[r, c] against the closed form evaluated on the host; the device-resident
+          entries (moihgp_update_dev / moihgp_window_eval_dev) against the host forms;
+      (4) project_stream -> filter (fp32) -> unproject_stream on Y [10^4][4096] against the oracle's per-latent loop on the
+          host-projected stream, compared on 16 outputs (1e-3: north_star's fp32 bar)."""
+    import ctypes as C
+    import scipy.linalg
+    from multioutputihgp_amd import load_library
+    from multioutputihgp_amd.streams import LatentBank, project_stream, unproject_stream
+    cref = env["cref"]
+    lib = load_library()
+    M = L = 4096; d = 3; P = 3
+    rng = np.random.default_rng(SEED + 2)
+    gp = env["MOIHGP"](0.1, M, L, kernel="Matern52ss")
+    A0 = np.eye(M, L) + 0.004 * rng.standard_normal((M, L))            # singular values in about [0.5, 1.5]: the scaled Newton-Schulz start
+    S = rng.uniform(0.5, 2.0, L); sigma = 0.04
+    igp = synth_params(L, rng)
+    p = np.concatenate([A0.ravel(), S, [sigma], igp.ravel()])
+    gp.update(p)
+    # ---- (1) the polar factor
+    U = gp.params[:M * L].reshape(M, L).copy()
+    G = U.T @ U - np.eye(L)
+    assert np.abs(G).max() < 1e-12 and np.abs(G).sum(axis=1).max() < 1e-10, (np.abs(G).max(), np.abs(G).sum(axis=1).max())
+    u, _, vt = scipy.linalg.svd(A0, full_matrices=False, lapack_driver="gesdd")
+    assert np.abs(U - u @ vt).max() < 1e-9
+    del u, vt, G
+    assert np.array_equal(gp.params[M * L:M * L + L], S) and gp.params[M * L + L] == sigma
+    # the learner's case: previous factor + an L-BFGS step of norm 0.1 (moihgp_online.h:156): the unscaled start, fewer steps
+    dU = rng.standard_normal((M, L)); p2 = p.copy(); p2[:M * L] = (U + 0.1 * dU / np.linalg.norm(dU)).ravel()
+    its_general = lib.moihgp_polar_iterations(gp.handle)
+    gp.update(p2)
+    assert 0 < lib.moihgp_polar_iterations(gp.handle) < its_general
+    U = gp.params[:M * L].reshape(M, L).copy()
+    assert np.abs(U.T @ U - np.eye(L)).max() < 1e-12
+    # ---- (2) W = 2 window == two ticks of the per-tick reference ABI on the same handle
+    igps = cref.ihgp_array("Matern52", 0.1, igp)
+    x0 = 0.2 * rng.standard_normal((L, d)); dx0 = 0.05 * rng.standard_normal((L, P, d))
+    Y2 = 0.5 * rng.standard_normal((2, M))
+    for threading in (0, 1):
+        lib.moihgp_set_threading(gp.handle, threading)
+        loss_w, grad_w, xw, dxw = gp.window_objective(Y2, x0, dx0)
+        grad_w = grad_w.copy()
+        x, dx, loss_t, grad_t = x0, dx0, 0.0, np.zeros(gp.num_param)
+        for t in range(2):
+            l1, g1 = gp.negLogLikelihood(x, Y2[t], dx)
+            xn, _, dxn = gp.step(x, Y2[t], dx)
+            loss_t += l1; grad_t += g1; x, dx = xn, dxn
+        assert abs(loss_w - loss_t) < 1e-9 * abs(loss_t), (threading, loss_w, loss_t)
+        assert rel_err(grad_w, grad_t) < 1e-9 and rel_err(grad_w[M * L:], grad_t[M * L:]) < 1e-9
+        assert rel_err(xw, x) < 1e-12 and rel_err(dxw, dx) < 1e-11
+        if threading == 0:
+            loss_off = loss_w
+        else:                                                          # moihgp.h:590: the threaded branch adds the per-latent losses
+            Ty2 = (U.T @ Y2.T) / np.sqrt(S)[:, None]
+            o2 = cref.grad_stream(igps, Ty2, x0=x0, dx0=dx0, want_yhat=False, nthreads=8)
+            assert abs((loss_w - loss_off) - o2["nll"]) < 1e-9 * abs(o2["nll"])
+    lib.moihgp_set_threading(gp.handle, 0)
+    del grad_t, g1
+    # ---- (3) W = 16 against the oracle, all latents
+    W = 16
+    Y = 0.5 * rng.standard_normal((W, M))
+    loss, grad, xT, dxT = gp.window_objective(Y, x0, dx0)
+    grad = grad.copy()
+    Ty = (U.T @ Y.T) / np.sqrt(S)[:, None]                             # moihgp.h:181 on the host
+    o = cref.grad_stream(igps, Ty, x0=x0, dx0=dx0, want_yhat=False, nthreads=8)
+    gl = grad[M * L + L + 1:].reshape(L, P)
+    assert rel_err(gl, o["grad"]) < 1e-9                               # moihgp.h:608-609: the per-latent blocks
+    assert rel_err(xT, o["x"]) < 1e-9 and rel_err(dxT, o["dx"]) < 1e-8
+    # global terms of the loss (moihgp.h:503, threading off: no per-latent losses) and the sigma / S entries (moihgp.h:555-563, :604-605)
+    UUY = (U @ (U.T @ Y.T)).T
+    rt = np.linalg.norm(Y - UUY, axis=1)
+    m_n = max(M - L, 0)
+    assert abs(loss - (W * (0.5 * np.log(S.sum()) + 0.5 * m_n * np.log(sigma)) + 0.5 * rt.sum() / sigma)) < 1e-9 * abs(loss)
+    # closed-form U-gradient  grad_U[r, c] = sum_t y_t[r] (pv_{c,t} / sqrt(S_c) - (U^T y_t)_c / sigma),  pv = (y_t[c] - HA x_{c,t}) (1 - HA K) / S_igp
+    cols = np.sort(rng.choice(L, size=12, replace=False)); rows = np.sort(rng.choice(M, size=12, replace=False))
+    Uty = U.T @ Y.T                                                    # [L][W]
+    gU = grad[:M * L].reshape(M, L)
+    spu = np.zeros(L)
+    for c in cols:
+        Ai, Ki, HAi, Si = igps[c].mat("A"), igps[c].mat("K"), igps[c].mat("HA"), float(igps[c].mat("S"))
+        xc = x0[c].copy(); z = np.empty(W)
+        for t in range(W):
+            hx = HAi @ xc
+            pv = (Y[t, c] - hx) * (1 - HAi @ Ki) / Si                  # moihgp.h:510-511 (raw y(c), sic)
+            z[t] = pv / np.sqrt(S[c]) - Uty[c, t] / sigma
+            spu[c] += pv * Uty[c, t]
+            xc = Ai @ xc + Ki * (Ty[c, t] - hx)
+        want = Y[:, rows].T @ z
+        assert rel_err(gU[rows, c], want) < 1e-9, c
+        gS = W * 0.5 / S[c] - 0.5 * S[c] ** -1.5 * spu[c] - gl[c, 2] * sigma / S[c] ** 2          # moihgp.h:555-561, :604
+        assert abs(grad[M * L + c] - gS) < 1e-9 * max(1.0, abs(gS)), c
+    g_sigma = 0.5 * (W * m_n - rt.sum() / sigma) / sigma + (gl[:, 2] / S).sum()                  # moihgp.h:563, :605
+    assert abs(grad[M * L + L] - g_sigma) < 1e-9 * abs(g_sigma)
+    # ---- the device-resident entries: same kernels, same values
+    dev = torch.device("cuda", 0)
+    p_dev = torch.from_numpy(p2).to(dev); g_dev = torch.empty_like(p_dev); l_dev = torch.zeros(1, dtype=torch.float64, device=dev)
+    xn_dev = torch.empty((L, d), dtype=torch.float64, device=dev); dxn_dev = torch.empty((L, P, d), dtype=torch.float64, device=dev)
+    gp.update_dev(p_dev)
+    assert lib.moihgp_polar_iterations(gp.handle) > 0
+    gp.window_objective_dev(torch.from_numpy(x0).to(dev), torch.from_numpy(dx0).to(dev), l_dev, g_dev, xn_dev, dxn_dev)
+    assert l_dev.item() == loss and torch.equal(g_dev.cpu(), torch.from_numpy(grad))
+    assert np.array_equal(xn_dev.cpu().numpy(), xT) and np.array_equal(dxn_dev.cpu().numpy(), dxT)
+    back = torch.empty_like(p_dev)
+    gp.params_dev(back)
+    assert np.array_equal(back.cpu().numpy(), gp.params)
+    del p_dev, g_dev, back, grad, gU
+    # ---- (4) the filter over the real stream: Y [10^4][4096] fp32
+    T = 10000
+    t_ax = np.arange(T)[:, None]
+    Yr = (np.sin(0.05 * t_ax * (1 + np.arange(M)[None, :] % 7)) + 0.1 * rng.standard_normal((T, M))).astype(np.float32)
+    Yd = torch.from_numpy(Yr).cuda()
+    Tyd = project_stream(gp, Yd)
+    yl, xe, nll = LatentBank.from_handle(gp).filter(Tyd, T=T)
+    Yhat = unproject_stream(gp, yl, T)
+    torch.cuda.synchronize()
+    Ty_h = (U.T @ Yr.astype(np.float64).T) / np.sqrt(S)[:, None]      # [L][T] fp64 on the host
+    assert rel_err_rows(Tyd[:, :T].double().cpu().numpy(), Ty_h) < 1e-3
+    of = cref.filter_stream(igps, Ty_h, nthreads=16)
+    outs = np.sort(rng.choice(M, size=16, replace=False))
+    want = (U[outs] * np.sqrt(S)[None, :]) @ of["yhat"]                # moihgp.h:222-225 for 16 outputs: [16][T]
+    got = Yhat[:, outs].double().cpu().numpy().T
+    e_mean = rel_err_rows(got, want)
+    e_nll = abs(nll.sum().item() - of["nll"]) / abs(of["nll"])
+    print(f"configs[2] filter at M=L=4096, T=1e4, fp32: filtered means (16 outputs) {e_mean:.2e}, NLL {e_nll:.2e}")
+    assert e_mean < 1e-3 and e_nll < 1e-3
+
+
+# ------------------------------------------------------------------------------------------ RCCL-only code on the one GPU of the test box
+def _clean_env(**extra):
+    import os
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "BENCH_REHEARSAL", "BENCH_FORCE_DIST"):
+        env.pop(k, None)
+    env.update(extra)
+    return env
+
+
+def _free_port():
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return str(p)
+
+
+def test_rccl_only_code_on_a_one_rank_communicator(env):
+    """No multi-GPU box is available to the build: the branches only an RCCL communicator takes (async all-reduce on its stream,
+    reduce_scatter_tensor with padding, all_gather, init with device_id) run here on a ONE-rank communicator, the world == 1
+    short-cuts lifted (sharded.FORCE_COLLECTIVES); in a process of its own (tests/rccl_one_rank.py)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "rccl_one_rank.py")], capture_output=True, text=True, timeout=600,
+                       env=_clean_env(MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port()))
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_bench_multi_gpu_code_on_a_one_rank_communicator(env):
+    """bench.py's N > 1 code (process group on the RCCL backend, every pass ending in its all-reduce, overlapped with the next sweep,
+    max over ranks on the device) on one rank: BENCH_FORCE_DIST=1."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "10", "--warmup", "2", "--no-cpu", "--no-cold"],
+                       capture_output=True, text=True, timeout=600,
+                       env=_clean_env(BENCH_FORCE_DIST="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port()))
+    assert r.returncode == 0, r.stderr[-4000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and "nccl" in out["forced_dist"] and out["value"] > 1e11 and np.isfinite(out["nll_total"])
+
+
+def test_bench_rehearsal_two_ranks_on_one_gpu(env):
+    """`python bench.py --gpus 2` exactly as the driver runs it (no launcher): the parent starts the ranks itself.  Both ranks share
+    the one GPU here (BENCH_REHEARSAL=1: exchange on gloo), real sweeps."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--no-cpu"],
+                       capture_output=True, text=True, timeout=900, env=_clean_env(BENCH_REHEARSAL="1"))
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["latents_total"] == 8192 and out["steps"] == 5 and "rehearsal" in out

@@ -401,10 +401,7 @@ def test_time_split_matches_unsplit(env, dtype, L, T, nan, monkeypatch):
     Tyd = to_dev(Ty, dtype)
     res = {}
     for split in ("1", "0", "5"):                  # off, automatic (slices of uneven length: the same number of segments per SIMD), forced 5 equal slices
-        if split == "0":
-            monkeypatch.delenv("MOIHGP_FILTER_SPLIT", raising=False)
-        else:
-            monkeypatch.setenv("MOIHGP_FILTER_SPLIT", split)
+        bank.set_option("filter_split", int(split))        # per-handle hook (include/moihgp.h moihgp_set_option)
         yhat, xT, nll = bank.filter(Tyd, T=T, x=torch.from_numpy(x0).to(dtype).cuda())
         _, xT2, _ = bank.filter(Tyd, T=T, x=torch.from_numpy(x0).to(dtype).cuda(), want_yhat=False, want_nll=False)
         torch.cuda.synchronize()
@@ -530,10 +527,29 @@ def test_window_objective_vs_oracle_loop(env, kern, M, L, W):
         lp += l1; x, dx = xn, dxn
     l4, _, x4, _ = gp.window_objective(Y[:min(W, 4)], x0, dx0)
     assert abs(l4 - lp) < 1e-10 * abs(lp) and rel_err(x4, x) < 1e-10
-    from multioutputihgp_amd import MoihgpError
-    Yn = Y.copy(); Yn[0, 0] = np.nan
-    with pytest.raises(MoihgpError):
-        gp.window_objective(Yn, x0, dx0)
+    # missing outputs: least-squares projection of the affected ticks on the device (moihgp.h:485-494); the loss and the mixing part of
+    # the gradient are NaN as in the reference (dense products with a y that holds NaN, moihgp.h:499-563), the per-latent part and the
+    # carried state finite: all of it equal to the oracle's tick loop
+    if M - 3 >= L:
+        Yn = Y.copy(); Yn[0, 0] = np.nan; Yn[W // 2, [1, M - 1, M // 2]] = np.nan
+        loss_n, grad_n, xTn, dxTn = gp.window_objective(Yn, x0, dx0)
+        x, dx, lref, gref = x0, dx0, 0.0, np.zeros(gp.num_param)
+        for t in range(W):
+            l1, g1 = ref.negLogLikelihood(x, Yn[t], dx)
+            xn, _, dxn = ref.step(x, Yn[t], dx)
+            lref += l1; gref += g1; x, dx = xn, dxn
+        assert np.isnan(lref) and np.isnan(loss_n)
+        assert np.array_equal(np.isnan(grad_n), np.isnan(gref))
+        fin = ~np.isnan(gref)
+        assert fin[M * L + L + 1:].all() and not fin[:M * L + L + 1].any()
+        assert rel_err(grad_n[fin], gref[fin]) < 1e-8
+        assert rel_err(xTn, x) < 1e-9 and rel_err(dxTn, dx) < 1e-8
+    else:                                               # fewer observed outputs than latents: refused (rc 3), the caller loops per tick
+        from multioutputihgp_amd import MoihgpError
+        Yn = Y.copy(); Yn[0, 0] = np.nan
+        with pytest.raises(MoihgpError) as ei:
+            gp.window_objective(Yn, x0, dx0)
+        assert ei.value.rc == 3
 
 
 # ------------------------------------------------------------------------------------------ N1: sharded real-data pipeline
@@ -644,10 +660,7 @@ def test_unstable_latents_take_the_sequential_path(env, dtype, T, split, monkeyp
     """With the reference's literal DARE (utils/dare.h:23, A un-transposed) parts of the learner's own parameter box give
     rho(AKHA) > 1.  The recursion then grows like rho^t; the scan tables would overflow, so such latents are flagged at
     update() and filtered sequentially.  Results must still equal the oracle's tick loop while they are finite."""
-    if split == "1":
-        monkeypatch.setenv("MOIHGP_FILTER_SPLIT", "1")
-    else:
-        monkeypatch.delenv("MOIHGP_FILTER_SPLIT", raising=False)
+    monkeypatch.delenv("MOIHGP_FILTER_SPLIT", raising=False)
     prm = np.array([[99.2440457, 4.06889466, 2.55306111e-03],      # rho(AKHA) = 1.47 (Matern-3/2, dt = 0.1)
                     [1.0, 1.0, 0.1],                                 # stable
                     [0.927049235, 1.63239037, 4.34082530e-04],      # rho = 1.17
@@ -658,6 +671,7 @@ def test_unstable_latents_take_the_sequential_path(env, dtype, T, split, monkeyp
     rng = np.random.default_rng(3)
     Ty = synth(L, T, rng, 0.02)
     bank = env["streams"].LatentBank(0.1, prm, kernel="Matern32")
+    bank.set_option("filter_split", int(split))
     o = env["cref"].filter_stream(igps, Ty)
     yhat, xT, nll = bank.filter(to_dev(Ty, dtype), T=T)
     torch.cuda.synchronize()
@@ -990,14 +1004,11 @@ def test_stacked_time_split_matches_unsplit(env, kern, dtype, monkeypatch):
     Ty[3, rng.random(T) < 0.02] = np.nan
     Tyd = to_dev(Ty, dtype)
     x0 = torch.from_numpy(0.3 * rng.standard_normal((L, bank.d))).to(dtype).cuda()
-    monkeypatch.setenv("MOIHGP_FILTER_SPLIT", "1")
+    bank.set_option("filter_split", 1)
     y1, x1, n1 = bank.filter(Tyd, T=T, x=x0.clone())
     torch.cuda.synchronize()
     for ns in ("0", "3", "5"):
-        if ns == "0":
-            monkeypatch.delenv("MOIHGP_FILTER_SPLIT")
-        else:
-            monkeypatch.setenv("MOIHGP_FILTER_SPLIT", ns)
+        bank.set_option("filter_split", int(ns))
         y2, x2, n2 = bank.filter(Tyd, T=T, x=x0.clone())
         torch.cuda.synchronize()
         tol = 1e-12 if dtype == torch.float64 else 1e-5

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Kernel-level A/B of the filter_scan_kernel tiling variants (MOIHGP_FILTER_VARIANT), one process,
+"""Kernel-level A/B of the filter_scan_kernel tiling probes (option "filter_variant"), one process,
 interleaved rounds, kernel-exact durations from dispatch-attached HIP events (moihgp_profile_*).
+The probes exist only in a tuning build:  make -C multioutputihgp_amd/csrc TUNING=1  and  MOIHGP_LIB=multioutputihgp_amd/lib/libmoihgp_tuning.so.
 usage: python tools/kbench.py [--dtype f32|f64] [--L 4096] [--T 10000] [--variants 0,1,2,...] [--rounds 5] [--nan 0.0]"""
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -32,7 +33,7 @@ times = {v: [] for v in variants}; ref = None
 bank.profile_enable(a.per)
 for rnd in range(a.rounds):
     for v in variants:
-        os.environ["MOIHGP_FILTER_VARIANT"] = str(v)
+        bank.set_option("filter_variant", v)
         for _ in range(a.per):
             if a.cold:
                 evict.add_(1.0)
