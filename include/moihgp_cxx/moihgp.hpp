@@ -172,6 +172,25 @@ private:
     std::vector<double> _x, _xnew, _dx, _dxnew, _y, _yhat, _p;
 };
 
+// The learners' window loop (moihgp_online.h:61-70, moihgp_regression.h:42-50) through the per-tick reference ABI, for windows the
+// batched objective refuses (moihgp_window_set rc 3: a tick with more missing outputs than its least-squares kernel takes):
+//     for t < W:  loss += gpXX_lik1(x, y_t, dx, g);  grad += g;  (x, dx) <- gpXX_step2(x, y_t, dx)
+// Y is [W][M] tick-major, x [L][d] and dx [L][P][d] the state before the window (left untouched); grad must hold num_param entries.
+inline double window_loop_per_tick(moihgp_gp* gp, const double* Y, size_t W, size_t M, const std::vector<double>& x0, const std::vector<double>& dx0,
+                                   std::vector<double>& grad) {
+    std::vector<double> x(x0), dx(dx0), xn(x0.size()), dxn(dx0.size()), g(grad.size()), y(M);
+    double loss = 0.0;
+    for (size_t i = 0; i < grad.size(); i++) grad[i] = 0.0;
+    for (size_t t = 0; t < W; t++) {
+        for (size_t m = 0; m < M; m++) y[m] = Y[t * M + m];
+        loss += gp32_lik1(gp, x.data(), y.data(), dx.data(), g.data());          // (the entry points dispatch on the handle's own model)
+        for (size_t i = 0; i < grad.size(); i++) grad[i] += g[i];
+        gp32_step2(gp, x.data(), y.data(), dx.data(), xn.data(), dxn.data());
+        x.swap(xn); dx.swap(dxn);
+    }
+    return loss;
+}
+
 }  // namespace moihgp
 
 #endif

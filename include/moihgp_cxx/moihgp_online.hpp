@@ -3,7 +3,8 @@
 // same constructor arguments, same members (`x`, `dx`, `Y`, `ma`, `oldparams`, `bfgs_mat`), same window / carry semantics,
 // same proximal term, same bounds and solver settings.  Differences, all on the host side:
 //   * containers are std::vector<double> (flat [L][d] / [L][P][d] states), not Eigen types;
-//   * the objective's loop over the window (moihgp_online.h:61-70) is ONE device call (moihgp_window_set / moihgp_window_eval);
+//   * the objective's loop over the window (moihgp_online.h:61-70) is ONE device call (moihgp_window_set / moihgp_window_eval), windows
+//     with missing outputs included; only a window beyond that call's limits (rc 3) runs the loop through the per-tick ABI;
 //   * the optimiser is this repo's projected L-BFGS (lbfgsb.hpp), not LBFGS++: same problem, different iterates.
 // To run the reference's own learner header (with LBFGS++ and Eigen) on top of this library instead, see
 // include/moihgp_cxx/compat/ and INTEGRATION.md.
@@ -55,13 +56,15 @@ public:
                 size_t t = 0;
                 for (std::list<Vector>::iterator it = Y.begin(); it != Y.end(); ++it, ++t)
                     for (size_t m = 0; m < _num_output; m++) _Yflat[t * _num_output + m] = (*it)[m] - ma[m];   // :63
-                if (moihgp_window_set(_gp->handle(), _Yflat.data(), Y.size()) != 0)
-                    throw std::runtime_error(std::string("moihgp_window_set: ") + moihgp_last_error());
+                const int rc = moihgp_window_set(_gp->handle(), _Yflat.data(), Y.size());
+                if (rc != 0 && rc != 3) throw std::runtime_error(std::string("moihgp_window_set: ") + moihgp_last_error());
+                _per_tick = rc == 3;      // missing outputs beyond the batched kernel's limits: the reference's loop, tick by tick
                 _window_dirty = false;
             }
             double wloss = 0.0;
             _g.resize(_num_param);
-            if (moihgp_window_eval(_gp->handle(), _x.data(), _dx.data(), &wloss, _g.data(), nullptr, nullptr) != 0)   // :61-70
+            if (_per_tick) wloss = window_loop_per_tick(_gp->handle(), _Yflat.data(), Y.size(), _num_output, _x, _dx, _g);
+            else if (moihgp_window_eval(_gp->handle(), _x.data(), _dx.data(), &wloss, _g.data(), nullptr, nullptr) != 0)   // :61-70
                 throw std::runtime_error(std::string("moihgp_window_eval: ") + moihgp_last_error());
             loss += wloss;
             for (size_t i = 0; i < _num_param; i++) grad[i] += _g[i];
@@ -98,7 +101,7 @@ private:
     double _gamma;
     MOIHGP<StateSpace>* _gp;
     Vector _x, _dx, _Yflat, _g;
-    bool _window_dirty = true;
+    bool _window_dirty = true, _per_tick = false;
 };
 
 template <typename StateSpace>

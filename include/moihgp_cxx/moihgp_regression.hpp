@@ -38,11 +38,13 @@ public:
         if (_dirty) {
             _Yflat.resize(Y.size() * _num_output);
             for (size_t t = 0; t < Y.size(); t++) for (size_t m = 0; m < _num_output; m++) _Yflat[t * _num_output + m] = Y[t][m];
-            if (moihgp_window_set(_gp->handle(), _Yflat.data(), Y.size()) != 0)
-                throw std::runtime_error(std::string("moihgp_window_set: ") + moihgp_last_error());
+            const int rc = moihgp_window_set(_gp->handle(), _Yflat.data(), Y.size());
+            if (rc != 0 && rc != 3) throw std::runtime_error(std::string("moihgp_window_set: ") + moihgp_last_error());
+            _per_tick = rc == 3;          // missing outputs beyond the batched kernel's limits: the reference's loop, tick by tick
             _dirty = false;
         }
         Vector x(_num_latent * _dim, 0.0), dx(_num_latent * _igp_num_param * _dim, 0.0);            // :38-39 zero start
+        if (_per_tick) return window_loop_per_tick(_gp->handle(), _Yflat.data(), Y.size(), _num_output, x, dx, grad);
         double loss = 0.0;
         if (moihgp_window_eval(_gp->handle(), x.data(), dx.data(), &loss, grad.data(), nullptr, nullptr) != 0)
             throw std::runtime_error(std::string("moihgp_window_eval: ") + moihgp_last_error());
@@ -56,7 +58,7 @@ private:
     size_t _dim, _num_param, _igp_num_param, _num_latent, _num_output, _num_data;
     MOIHGP<StateSpace>* _gp;
     Vector _Yflat;
-    bool _dirty = true;
+    bool _dirty = true, _per_tick = false;
 };
 
 template <typename StateSpace>
