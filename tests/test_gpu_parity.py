@@ -546,7 +546,7 @@ def test_window_objective_vs_oracle_loop(env, kern, M, L, W):
         assert rel_err(xTn, x) < 1e-9 and rel_err(dxTn, dx) < 1e-8
     else:                                               # fewer observed outputs than latents: refused (rc 3), the caller loops per tick
         from multioutputihgp_amd import MoihgpError
-        Yn = Y.copy(); Yn[0, 0] = np.nan
+        Yn = Y.copy(); Yn[0, :M - L + 1] = np.nan          # L - 1 observed outputs
         with pytest.raises(MoihgpError) as ei:
             gp.window_objective(Yn, x0, dx0)
         assert ei.value.rc == 3
