@@ -25,6 +25,14 @@
 namespace moihgp {
 namespace {
 
+// Tuning probes (-DMOIHGP_TUNING -DMOIHGP_X_SKIP=bits, experiment libraries only): leave out the chunk response (1), the scan levels (2)
+// or the replay (4) of the clean path, to attribute the kernel's time to its phases.  Results are wrong by construction.
+#if defined(MOIHGP_TUNING) && defined(MOIHGP_X_SKIP)
+constexpr int kXSkip = MOIHGP_X_SKIP;
+#else
+constexpr int kXSkip = 0;
+#endif
+
 // One instantiation serves full, ragged and warm-up segments alike (a second, masked one took part in the kernel's register
 // allocation and cost the full segments 10 %), and the tick loop carries no per-lane masking: every lane walks its whole chunk,
 // lanes past the end compute on zero padding nobody reads.  What a ragged end needs is taken at the one tick where the stream
@@ -151,8 +159,21 @@ constexpr int kPairMaxDim = 6;       // state dims up to which the second pass c
 constexpr int kPairFrom = 2;         // ... and does so for windows with more than this many chunks with a gap
 constexpr int kLinkState = 144;      // doubles per latent in link_state: x [D], segment start; from 16 on the per-lane sums of v^2 [64], n_obs [64]
 
+// Waves per SIMD the register allocation must allow (second argument of __launch_bounds__ under HIP).
+#ifndef MOIHGP_X_MINW_F32
+#define MOIHGP_X_MINW_F32 1
+#endif
+#ifndef MOIHGP_X_MINW_F64
+#define MOIHGP_X_MINW_F64 1
+#endif
+template <typename T, int D, bool SPLIT, bool LINKS>
+constexpr int x_min_waves() {
+    if (SPLIT || LINKS) return 1;
+    return sizeof(T) == 4 ? MOIHGP_X_MINW_F32 : MOIHGP_X_MINW_F64;
+}
+
 template <typename T, int DB, int J, bool WRITE, bool NLL, int WPB, bool SPLIT, bool LINKS>
-__global__ void __launch_bounds__(64 * WPB)
+__global__ void __launch_bounds__(64 * WPB, (x_min_waves<T, DB * J, SPLIT, LINKS>()))
 filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, const T* __restrict__ cbT, const double* __restrict__ cb64,
                 const T* xin0 /* start state */, T* x /* end state; may be the same buffer */, T* __restrict__ yhat, double* __restrict__ nll,
                 int nslice, int segs_per_slice, double* __restrict__ nll_part, size_t ldo /* row stride of yhat */,
@@ -281,6 +302,7 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
             static_for<EPV>([&](auto qq) {
                 constexpr int k = kv * EPV + decltype(qq)::value;
                 bad = bad || (yv[decltype(qq)::value] != yv[decltype(qq)::value]);
+                if constexpr (kXSkip & 1) { z[k % D] += yv[decltype(qq)::value]; return; }
                 static_for<D>([&](auto ii) {
                     constexpr int e = k * D + decltype(ii)::value, sl = e / 16;
                     if constexpr (sl < NSG0) fmac_bc<e % 16>(z[decltype(ii)::value], g0[sl], yv[decltype(qq)::value]);
@@ -532,7 +554,7 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
             for (int i = 0; i < D; i++) z[i] += (lane == 0) ? t[i] : T(0);
 #pragma unroll
             for (int lv = 0; lv < 6; lv++) {
-                if (lv >= nlev) break;                               // uniform: the remaining powers are negligible
+                if (lv >= nlev || (kXSkip & 2)) break;               // uniform: the remaining powers are negligible
                 const int s = 1 << lv, addr = ((lane - s) & 63) * 4;
 #pragma unroll
                 for (int i = 0; i < D; i++) { const T m = bperm<T>(addr, z[i]); t[i] = lane >= s ? m : T(0); }
@@ -553,6 +575,10 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
             __builtin_amdgcn_sched_barrier(0);
             fetch(t0 + SEG, nnext);                                  // next segment's stream, in flight during the replay
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (kXSkip & 4) {
+#pragma unroll
+                for (int i = 0; i < D; i++) xc[i] = read_lane(xs[i], 63);
+            } else
             replay<T, DB, J, WRITE, NLL>(ablk, ha, kk, tile_lane, carries[wave], lane, n, head, xs, xc, acc, nobs);
         }
         // ---- stage out ----
@@ -696,11 +722,13 @@ int launch_filter_stream_x(int kernel, int dtype, const void* Ty, size_t T, size
     if (base == (DBB == 2 ? 0 : 1) && J == JJ)                                                                        \
         return dtype == 0 ? launch_xd<double, DBB, JJ>(Ty, T, ld, L, cb64, cb64, xin, x, yhat, nll, stream, ev0, ev1, scratch, scratch_len, force_slices, ldo, link_flags, link_state, total, max_links) \
                           : launch_xd<float, DBB, JJ>(Ty, T, ld, L, cb32, cb64, xin, x, yhat, nll, stream, ev0, ev1, scratch, scratch_len, force_slices, ldo, link_flags, link_state, total, max_links)
-#ifndef MOIHGP_X_ONLY_D12        // (development: -DMOIHGP_X_ONLY_D12 builds the d = 12 kernels alone, for quick resource checks)
+#ifdef MOIHGP_X_ONLY_DBJ         // (development: -DMOIHGP_X_ONLY_DBJ=32 builds the DB = 3, J = 2 kernels alone: quick resource checks, A/B builds)
+    MOIHGP_X_CASE(MOIHGP_X_ONLY_DBJ / 10, MOIHGP_X_ONLY_DBJ % 10);
+#else
     MOIHGP_X_CASE(2, 2); MOIHGP_X_CASE(2, 3); MOIHGP_X_CASE(2, 4);
     MOIHGP_X_CASE(3, 2); MOIHGP_X_CASE(3, 3);
-#endif
     MOIHGP_X_CASE(3, 4);
+#endif
 #undef MOIHGP_X_CASE
     set_last_error("stacked kernel id %d is not built", kernel);
     return 1;
