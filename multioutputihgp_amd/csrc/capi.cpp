@@ -77,7 +77,7 @@ struct moihgp_gp {
     double* dlink = nullptr;   // [L][144] stacked filter: where the second (broken-link) pass resumes a latent (on first use)
     bool hp_valid = false;     // dhp matches the current tables (cleared by every IHGP::update)
     // options (moihgp_set_option; defaults from the environment, read once in gp_create)
-    int opt_filter_split = 0, opt_filter_variant = 0, opt_filter_maxlinks = -1;
+    int opt_filter_split = 0, opt_filter_variant = 0, opt_filter_maxlinks = -1, opt_filter_team = -1;
     int* dwinmiss = nullptr;   // [W] window objective: 1 where the tick's observation vector holds NaN (on first use)
     size_t winmiss_cap = 0;
     bool win_has_nan = false;
@@ -217,6 +217,7 @@ static moihgp_gp* gp_create(int kernel, double dt, size_t M, size_t L, bool late
     // tuning / test hooks: the environment is consulted here, once; moihgp_set_option changes them per handle afterwards
     if (const char* e = std::getenv("MOIHGP_FILTER_SPLIT")) g->opt_filter_split = std::atoi(e);
     if (const char* e = std::getenv("MOIHGP_FILTER_MAXLINKS")) g->opt_filter_maxlinks = std::atoi(e);
+    if (const char* e = std::getenv("MOIHGP_FILTER_TEAM")) g->opt_filter_team = std::atoi(e);
 #ifdef MOIHGP_TUNING
     if (const char* e = std::getenv("MOIHGP_FILTER_VARIANT")) g->opt_filter_variant = std::atoi(e);
 #endif
@@ -685,7 +686,7 @@ static int filter_stream_io_impl(moihgp_gp* gp, int dtype, const void* Ty, size_
         if (gp->L >= 1024 && !gp->dlink) gp->dlink = dev_alloc<double>(gp->L * 144);     // hand-over records of the second (broken-link) pass
         int rc = launch_filter_stream_x(gp->kernel, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cb32, x_in, x, yhat, nll, (hipStream_t)stream, e0, e1,
                                         gp->dxscratch, slen, gp->opt_filter_split /* test hook: 1 = off, n = slices */, ld_out, gp->L >= 1024 ? gp->dfallback : nullptr, gp->dlink, nll ? nll_total : nullptr,
-                                        gp->opt_filter_maxlinks);
+                                        gp->opt_filter_maxlinks, gp->opt_filter_team);
         return rc;
     }
     // time split across the wavefronts of a workgroup when there are too few latents to fill the chip
@@ -951,6 +952,7 @@ int moihgp_set_option(moihgp_gp* gp, const char* name, long value) {
     if (!gp || !name) { set_last_error("set_option: null argument"); return 1; }
     const std::string n(name);
     if (n == "filter_split") { if (value < 0 || value > 64) { set_last_error("filter_split: 0 (automatic), 1 (off) or a slice count"); return 1; } gp->opt_filter_split = (int)value; return 0; }
+    if (n == "filter_team") { if (value < -1 || value > 1) { set_last_error("filter_team: -1 (automatic), 0 (never), 1 (whenever the stream fits)"); return 1; } gp->opt_filter_team = (int)value; return 0; }
     if (n == "filter_maxlinks") { if (value < -1 || value > 64) { set_last_error("filter_maxlinks: -1 (automatic) .. 64"); return 1; } gp->opt_filter_maxlinks = (int)value; return 0; }
     if (n == "filter_variant") {
 #ifdef MOIHGP_TUNING

@@ -51,6 +51,7 @@ constexpr int cb_size(int d) { return d == 2 ? CB<2>::SIZE : CB<3>::SIZE; }
 // time-parallel segment solve of recursion_x.hip.  Both the fp64 and the fp32 copy use kChunkX ticks per lane.
 constexpr int kChunkX = 32;          // ticks per lane per segment (2048-tick segments)
 constexpr int kMaxStackDim = 12;
+constexpr int kPkMax = 2 * 2 * (3 * 3 + 2 * 3);     // (two block pairs of DB = 3: the largest PK table of any stacked model)
 template <int D>
 struct XC {
     static constexpr int AKHA   = 0;                // [D*D]
@@ -72,7 +73,10 @@ struct XC {
     static constexpr int K16    = HA16 + 16;                   // [16]  K, zero padded
     static constexpr int G      = K16 + 16;         // [GN]  g_k = AKHA^(CK-1-k) K, row-major [k][i]
     static constexpr int SP     = G + GN;           // [6][LS]  M^(1,2,4,8,16,32), M = AKHA^CK: levels of a 64-lane Kogge-Stone scan
-    static constexpr int SIZE   = SP + 6 * LS;      // a multiple of 16: every latent's tables stay 16-aligned
+    // coefficient pairs of the packed fp32 replay (recursion_x.hip): per pair p of diagonal blocks (2p, 2p + 1; an odd count pairs its last
+    // block with zeros), DB*DB + 2 DB pairs [A_rq | HA_q | K_r], each pair = (value of block 2p, value of block 2p + 1)
+    static constexpr int PK     = SP + 6 * LS;
+    static constexpr int SIZE   = (PK + kPkMax + 15) / 16 * 16;   // a multiple of 16: every latent's tables stay 16-aligned
 };
 // Sensitivity block of a stacked latent (fp64 only; gradient sweeps read it): ihgp.h:136-200 for P = 2J + 1 hyper-parameters.
 template <int D, int P>
@@ -127,7 +131,7 @@ int launch_filter_stream_x(int kernel, int dtype, const void* Ty, size_t T, size
                            double* scratch = nullptr /* [scratch_len] per-slice NLL partials of the time split */, size_t scratch_len = 0,
                            int force_slices = 0 /* tuning / test hook: 1 = no split, n > 1 = n slices */, size_t ld_out = 0 /* row stride of yhat; 0 = ld */,
                            int* link_flags = nullptr /* [L] */, double* link_state = nullptr /* [L][144] */, double* total = nullptr /* sum of nll[] */,
-                           int max_links = -1 /* -1: automatic */
+                           int max_links = -1 /* -1: automatic */, int team_mode = -1 /* few latents: -1 automatic, 0 never, 1 always use the team kernel */
                            /* scratch; with both (L >= 1024): segments with few gaps are handled as broken links by a second pass instead of
                               being walked tick by tick */);
 

@@ -33,14 +33,60 @@ constexpr int kXSkip = MOIHGP_X_SKIP;
 constexpr int kXSkip = 0;
 #endif
 
+// ---- the replay: every lane walks its chunk of kChunkX ticks from its true start state, in innovation form
+//          v = y - HA x;   x <- A x + K v   (== AKHA x + K y, ihgp.h:90);   yhat = x(0) (ihgp.h:91);   sum of v^2 for ihgp.h:207
+// A is block diagonal (J blocks of DB x DB).  Three forms of the wave-uniform operands, by what the register files hold:
+//   PK  (fp32): the state travels as PAIRS across two components, X_q = (x_q of block 2p, x_q of block 2p + 1), and every
+//        multiply-add on a pair is ONE v_pk_fma_f32 with the coefficient pair in an SGPR pair (table XC::PK, written by the update kernel):
+//        18 vector instructions per tick at d = 6 where the scalar form takes 38 (an odd J pairs its last block with zeros);
+//   SOP (fp64, d <= 8): HA, K and the blocks of A as plain scalar operands: no zero-initialised partial sums, no DPP issue cost
+//        (a lone wave issues a DPP multiply-add every ~9 cycles, a scalar-operand one every ~4.5: tools/micro/fma_rate.hip);
+//   DPP (fp64, d = 9, 12): HA and K as slabs read through row_newbcast, the blocks of A as scalar operands (all three would be 90+
+//        SGPRs at d = 9).
+// The chunk is read and written 16 bytes at a time (2 / 4 ticks), and the next group's read is issued before this group's arithmetic:
+// a tick no longer waits for its own LDS read.
 // One instantiation serves full, ragged and warm-up segments alike (a second, masked one took part in the kernel's register
 // allocation and cost the full segments 10 %), and the tick loop carries no per-lane masking: every lane walks its whole chunk,
 // lanes past the end compute on zero padding nobody reads.  What a ragged end needs is taken at the one tick where the stream
 // ends -- tick klast of lane jl, a wave-uniform test: that lane parks its state in LDS (the carry-out) and adds its running sum
 // of squared innovations to the total there.  head (warm-up ticks of a time slice, not counted) is a multiple of the chunk length, so a
 // lane's chunk counts as a whole or not at all.
+template <typename T, int DB, int J>
+struct ReplayConst {
+    static constexpr int D = DB * J;
+    static constexpr bool PK = sizeof(T) == 4, SOP = sizeof(T) == 8 && D <= 8;
+    static constexpr int NPAIR = (J + 1) / 2, NPK = NPAIR * (DB * DB + 2 * DB);
+    typedef T T2 __attribute__((ext_vector_type(2)));
+    T a[PK ? 1 : J * DB * DB];                     // diagonal blocks of A
+    T has[SOP ? D : 1], ks[SOP ? D : 1];           // HA, K as scalars
+    T ha, kk;                                      // HA, K as slabs (DPP form)
+    T2 pk[PK ? NPK : 1];                           // per block pair: A (row-major), HA, K as coefficient pairs
+};
+
+template <typename T, int DB, int J, typename P>
+__device__ inline void load_replay_const(P cu /* uniform view of the latent's block */, const T* __restrict__ c, int lane, ReplayConst<T, DB, J>& rc) {
+    using RC = ReplayConst<T, DB, J>;
+    using Lay = XC<DB * J>;
+    if constexpr (RC::PK) {
+#pragma unroll
+        for (int i = 0; i < RC::NPK; i++) { rc.pk[i].x = cu[Lay::PK + 2 * i]; rc.pk[i].y = cu[Lay::PK + 2 * i + 1]; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < J * DB * DB; i++) rc.a[i] = cu[Lay::AB + i];
+        if constexpr (RC::SOP) {
+#pragma unroll
+            for (int i = 0; i < DB * J; i++) { rc.has[i] = cu[Lay::HA + i]; rc.ks[i] = cu[Lay::K + i]; }
+        } else {
+            rc.ha = c[Lay::HA16 + (lane & 15)];
+            rc.kk = c[Lay::K16 + (lane & 15)];
+        }
+    }
+}
+
+// DPP form (fp64, d = 9 and 12): tick by tick, HA and K through slabs; the d = 12 instantiation sits at 256 registers exactly (two waves
+// per SIMD), which the grouped form below would overflow.
 template <typename T, int DB, int J, bool WRITE, bool NLL>
-__device__ inline void replay(const T (&a)[J * DB * DB], const T& ha, const T& kk, T* tile_lane, T* carry, int lane, int n, int head,
+__device__ inline void replay_dpp(const T (&a)[J * DB * DB], const T& ha, const T& kk, T* tile_lane, T* carry, int lane, int n, int head,
                               T (&xs)[DB * J], T (&xc)[DB * J], double& acc, unsigned& nobs) {
     constexpr int D = DB * J;
     const int jl = (n - 1) / kChunkX, klast = (n - 1) % kChunkX;      // lane and tick of the last tick of the segment
@@ -84,6 +130,123 @@ __device__ inline void replay(const T (&a)[J * DB * DB], const T& ha, const T& k
         }
     }
     if (NLL) {
+        acc += (counted && lane < jl) ? part : 0.0;
+        nobs += counted ? (lane < jl ? (unsigned)kChunkX : (lane == jl ? (unsigned)(klast + 1) : 0u)) : 0u;
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int i = 0; i < D; i++) xc[i] = carry[i];                    // one broadcast read per entry
+    wave_lds_fence();
+}
+
+template <typename T, int DB, int J, bool WRITE, bool NLL>
+__device__ inline void replay(const ReplayConst<T, DB, J>& rc, T* tile_lane, T* carry, int lane, int n, int head,
+                              T (&xs)[DB * J], T (&xc)[DB * J], double& acc, unsigned& nobs) {
+    using RC = ReplayConst<T, DB, J>;
+    using V = typename VecOf<T>::type;
+    constexpr int D = DB * J, EPV = 16 / sizeof(T), NG = kChunkX / EPV;
+    if constexpr (!RC::PK && !RC::SOP) {
+        replay_dpp<T, DB, J, WRITE, NLL>(rc.a, rc.ha, rc.kk, tile_lane, carry, lane, n, head, xs, xc, acc, nobs);
+        return;
+    }
+    const int jl = (n - 1) / kChunkX, klast = (n - 1) % kChunkX;      // lane and tick of the last tick of the segment
+    const bool counted = lane * kChunkX >= head;
+    // the state: scalars, or pairs across two components (PK)
+    typedef typename RC::T2 T2;
+    T2 X[RC::PK ? RC::NPAIR * DB : 1];
+    if constexpr (RC::PK) {
+#pragma unroll
+        for (int p = 0; p < RC::NPAIR; p++)
+#pragma unroll
+            for (int q = 0; q < DB; q++) { X[p * DB + q].x = xs[(2 * p) * DB + q]; X[p * DB + q].y = (2 * p + 1 < J) ? xs[(2 * p + 1 < J ? 2 * p + 1 : 0) * DB + q] : T(0); }
+    }
+    T partf = 0;                    // PK: sum of v^2 over the chunk in stream precision (32 terms), added to the fp64 total once
+    double part = 0.0;
+    V cur = *reinterpret_cast<const V*>(tile_lane);
+#pragma unroll 2
+    for (int g = 0; g < NG; g++) {
+        const V nxt = *reinterpret_cast<const V*>(tile_lane + (g + 1 < NG ? g + 1 : g) * EPV);    // in flight during this group's ticks
+        T y[EPV], o[EPV];
+        unpack<T>(cur, y);
+#pragma unroll
+        for (int e = 0; e < EPV; e++) {
+            const int k = g * EPV + e;
+            if constexpr (RC::PK) {
+                constexpr int PB = DB * DB + 2 * DB;                   // coefficient pairs per block pair: A, then HA, then K
+                T2 H = rc.pk[DB * DB] * X[0];
+#pragma unroll
+                for (int p = 0; p < RC::NPAIR; p++)
+#pragma unroll
+                    for (int q = 0; q < DB; q++) if (p + q > 0) H = rc.pk[p * PB + DB * DB + q] * X[p * DB + q] + H;
+                const T v = y[e] - (H.x + H.y);
+                if (NLL) partf = fma(v, v, partf);
+                const T2 vv = {v, v};
+                T2 XN[RC::NPAIR * DB];
+#pragma unroll
+                for (int p = 0; p < RC::NPAIR; p++)
+#pragma unroll
+                    for (int r = 0; r < DB; r++) {
+                        T2 sacc = rc.pk[p * PB + r * DB] * X[p * DB];
+#pragma unroll
+                        for (int q = 1; q < DB; q++) sacc = rc.pk[p * PB + r * DB + q] * X[p * DB + q] + sacc;
+                        XN[p * DB + r] = rc.pk[p * PB + DB * DB + DB + r] * vv + sacc;
+                    }
+#pragma unroll
+                for (int i = 0; i < RC::NPAIR * DB; i++) X[i] = XN[i];
+                o[e] = XN[0].x;                                        // ihgp.h:91 `yhat = xnew(0, 0)`, literally
+                if (k == klast) {                                      // wave-uniform
+                    if (lane == jl) {
+                        if (NLL && counted) acc += (double)partf;
+#pragma unroll
+                        for (int p = 0; p < RC::NPAIR; p++)
+#pragma unroll
+                            for (int q = 0; q < DB; q++) {
+                                carry[(2 * p) * DB + q] = XN[p * DB + q].x;
+                                if (2 * p + 1 < J) carry[(2 * p + 1 < J ? 2 * p + 1 : 0) * DB + q] = XN[p * DB + q].y;
+                            }
+                    }
+                }
+            } else {
+                T v;
+                {
+                    T h0 = fma(rc.has[0], xs[0], -y[e]), h1 = rc.has[1] * xs[1];
+#pragma unroll
+                    for (int i = 2; i < D; i++) { if (i % 2 == 0) h0 = fma(rc.has[i], xs[i], h0); else h1 = fma(rc.has[i], xs[i], h1); }
+                    v = -(h0 + h1);                                    // (the negation folds into the uses below as a source modifier)
+                }
+                if (NLL) {
+                    const double vd = (double)v;
+                    part = fma(vd, vd, part);                          // ihgp.h:206-207, pre-step state
+                }
+                T xn[D];
+#pragma unroll
+                for (int j = 0; j < J; j++)
+#pragma unroll
+                    for (int r = 0; r < DB; r++) {
+                        T sum = rc.a[j * DB * DB + r * DB] * xs[j * DB];
+#pragma unroll
+                        for (int q = 1; q < DB; q++) sum = fma(rc.a[j * DB * DB + r * DB + q], xs[j * DB + q], sum);
+                        xn[j * DB + r] = sum;
+                    }
+#pragma unroll
+                for (int i = 0; i < D; i++) xn[i] = fma(rc.ks[i], v, xn[i]);                        // ihgp.h:90 as A x + K (y - HA x)
+#pragma unroll
+                for (int i = 0; i < D; i++) xs[i] = xn[i];
+                o[e] = xn[0];                                          // ihgp.h:91 `yhat = xnew(0, 0)`, literally
+                if (k == klast) {                                      // wave-uniform
+                    if (lane == jl) {
+                        if (NLL && counted) acc += part;
+#pragma unroll
+                        for (int i = 0; i < D; i++) carry[i] = xn[i];
+                    }
+                }
+            }
+        }
+        if (WRITE) *reinterpret_cast<V*>(tile_lane + g * EPV) = pack<T>(o);
+        cur = nxt;
+    }
+    if (NLL) {
+        if constexpr (RC::PK) part = (double)partf;
         acc += (counted && lane < jl) ? part : 0.0;
         nobs += counted ? (lane < jl ? (unsigned)kChunkX : (lane == jl ? (unsigned)(klast + 1) : 0u)) : 0u;
     }
@@ -169,28 +332,27 @@ constexpr int kLinkState = 144;      // doubles per latent in link_state: x [D],
 template <typename T, int D, bool SPLIT, bool LINKS>
 constexpr int x_min_waves() {
     if (SPLIT || LINKS) return 1;
+    // fp32 up to d = 9: 128 registers, i.e. 4 waves per SIMD = all 4096 wavefronts of a 4096-latent bank resident at once (at 137 registers
+    // three fit, and the fourth thousand of wavefronts ran as a second round at one wave per SIMD: d = 6 104.8 -> 94.7 us, d = 9 138 -> 127;
+    // d = 12 spills under the cap and lost: 160 -> 166 us)
+    if (sizeof(T) == 4 && D <= 9 && MOIHGP_X_MINW_F32 == 1) return 4;
     return sizeof(T) == 4 ? MOIHGP_X_MINW_F32 : MOIHGP_X_MINW_F64;
 }
 
-template <typename T, int DB, int J, bool WRITE, bool NLL, int WPB, bool SPLIT, bool LINKS>
-__global__ void __launch_bounds__(64 * WPB, (x_min_waves<T, DB * J, SPLIT, LINKS>()))
-filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, const T* __restrict__ cbT, const double* __restrict__ cb64,
+// The sweep of ONE wavefront over (a slice of) one latent's stream: the body of filter_x_kernel, and the fallback of the team kernel
+// below (one latent per workgroup), which hands a latent it cannot take to this code.  `tile` is the wave's padded LDS tile
+// (64 x (kChunkX + 16 bytes)), `carry` its D-entry carry-out slot.
+template <typename T, int DB, int J, bool WRITE, bool NLL, bool SPLIT, bool LINKS>
+__device__ __forceinline__ void filter_x_body(const T* __restrict__ Ty, size_t Tlen, size_t ld, const T* __restrict__ cbT, const double* __restrict__ cb64,
                 const T* xin0 /* start state */, T* x /* end state; may be the same buffer */, T* __restrict__ yhat, double* __restrict__ nll,
                 int nslice, int segs_per_slice, double* __restrict__ nll_part, size_t ldo /* row stride of yhat */,
-                int* __restrict__ link_flags /* [L] or NULL */, double* __restrict__ link_state /* [L][kLinkState] */) {
+                int* __restrict__ link_flags /* [L] or NULL */, double* __restrict__ link_state /* [L][kLinkState] */,
+                const size_t l, const int slice, const int lane, T* __restrict__ tile, T* __restrict__ carry) {
     constexpr int D = DB * J;
     using V = typename VecOf<T>::type;
     using Lay = XC<D>;
     constexpr int CK = kChunkX, EPV = 16 / sizeof(T), STRIDE = CK + EPV, SEG = 64 * CK;
-    __shared__ __attribute__((aligned(16))) T tiles[WPB][64 * STRIDE];
-    __shared__ T carries[WPB][D];                                    // carry-out of a segment (written by the lane that holds its last tick)
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const size_t l = SPLIT ? (size_t)blockIdx.x : (size_t)blockIdx.x * WPB + wave;   // SPLIT: grid = (latents, slices)
-    const int slice = SPLIT ? (int)blockIdx.y : 0;
-    if (l >= L) return;                                              // no workgroup barrier below
     const T* __restrict__ c = cbT + l * Lay::SIZE;
-    T* tile = tiles[wave];
     T* tile_lane = tile + lane * STRIDE;
     const T* row = Ty + l * ld;
     T* orow = WRITE ? yhat + l * ldo : nullptr;
@@ -272,9 +434,11 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
         T g0[NSG0], g1[NSG1];
         load_slabs<T, NSG0>(cu + Lay::G, lane, g0);
         load_slabs<T, NSG1>(cu + Lay::G + NSG0 * 16, lane, g1);
-        T ablk[J * DB * DB];
+        T ablk[J * DB * DB];                                        // (the paths with gaps walk with these; the clean path's replay has its own set, rc)
 #pragma unroll
         for (int i = 0; i < J * DB * DB; i++) ablk[i] = cu[Lay::AB + i];
+        ReplayConst<T, DB, J> rc;
+        load_replay_const<T, DB, J>(cu, c, lane, rc);
         // ---- stage in: coalesced 16-byte loads, chunk-major into the padded tile ----
 #pragma unroll
         for (int r = 0; r < CK / EPV; r++) {
@@ -528,7 +692,7 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
                     if (WRITE && act) tile_lane[k] = xn[0];
                     if (k == klast && lane == jl && act) {             // the state after the segment's last tick
 #pragma unroll
-                        for (int i = 0; i < D; i++) carries[wave][i] = xn[i];
+                        for (int i = 0; i < D; i++) carry[i] = xn[i];
                     }
                 }
                 if (hi >= jl) break;
@@ -538,7 +702,7 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
             }
             wave_lds_fence();
 #pragma unroll
-            for (int i = 0; i < D; i++) xc[i] = carries[wave][i];
+            for (int i = 0; i < D; i++) xc[i] = carry[i];
             wave_lds_fence();
             if (NLL) { acc += part; nobs += cnt; }
             __builtin_amdgcn_sched_barrier(0);
@@ -579,7 +743,7 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
 #pragma unroll
                 for (int i = 0; i < D; i++) xc[i] = read_lane(xs[i], 63);
             } else
-            replay<T, DB, J, WRITE, NLL>(ablk, ha, kk, tile_lane, carries[wave], lane, n, head, xs, xc, acc, nobs);
+            replay<T, DB, J, WRITE, NLL>(rc, tile_lane, carry, lane, n, head, xs, xc, acc, nobs);
         }
         // ---- stage out ----
         if (WRITE) {
@@ -608,6 +772,209 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
             const double* c64 = cb64 + l * Lay::SIZE;
             const double v = 0.5 * (acc / c64[Lay::S] + (double)nobs * c64[Lay::LOGS]);
             if (SPLIT) nll_part[l * nslice + slice] = v; else nll[l] = v;
+        }
+    }
+}
+
+template <typename T, int DB, int J, bool WRITE, bool NLL, int WPB, bool SPLIT, bool LINKS>
+__global__ void __launch_bounds__(64 * WPB, (x_min_waves<T, DB * J, SPLIT, LINKS>()))
+filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, const T* __restrict__ cbT, const double* __restrict__ cb64,
+                const T* xin0, T* x, T* __restrict__ yhat, double* __restrict__ nll, int nslice, int segs_per_slice, double* __restrict__ nll_part, size_t ldo,
+                int* __restrict__ link_flags, double* __restrict__ link_state) {
+    constexpr int D = DB * J, STRIDE = kChunkX + 16 / (int)sizeof(T);
+    __shared__ __attribute__((aligned(16))) T tiles[WPB][64 * STRIDE];
+    __shared__ T carries[WPB][D];                                    // carry-out of a segment (written by the lane that holds its last tick)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t l = SPLIT ? (size_t)blockIdx.x : (size_t)blockIdx.x * WPB + wave;   // SPLIT: grid = (latents, slices)
+    const int slice = SPLIT ? (int)blockIdx.y : 0;
+    if (l >= L) return;                                              // no workgroup barrier below
+    filter_x_body<T, DB, J, WRITE, NLL, SPLIT, LINKS>(Ty, Tlen, ld, cbT, cb64, xin0, x, yhat, nll, nslice, segs_per_slice, nll_part, ldo, link_flags, link_state,
+                                                      l, slice, lane, tiles[wave], carries[wave]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// TEAM: few latents (BASELINE.json configs[1]: 256 latents x 10^4 ticks).  One WORKGROUP per latent, one wavefront per segment of
+// 64 x 32 ticks, every segment of the stream at once (the stream holds at most kTeamWaves segments), the stream read ONCE and no tick
+// replayed twice (the time slices of the SPLIT kernel above start from a zero state a warm-up before their first tick: for a
+// 10^4-tick stream that is 9 one-segment passes per latent, half of each a warm-up, where this kernel does 5).
+//   A. every wave: its segment into its tile, chunk responses z_j, Kogge-Stone scan from a ZERO state -> e0_j, the state after chunk j
+//      had the segment started from zero; lane 63's is the segment's zero-start end state, parked in LDS.           __syncthreads()
+//   B. the true state entering segment s is  c_s = e0_63(s-1) + M^64 c_(s-1),  M^64 = AKHA^2048 -- the power the update kernel has
+//      flagged as below 1e-20 (1e-10 in fp32) whenever nlev <= 5, the criterion the scan itself drops its upper levels by and the
+//      SPLIT kernel's warm-up rests on -- so  c_s = e0_63(s-1)  to rounding (c_0 = the caller's start state).  It enters the lanes'
+//      start states linearly:  start_j = e0_(j-1) + M^j c_s,  and  q_j = M^j c_s  is the same scan applied to (c_s, 0, 0, ..).
+//      Then the replay, the stores, and the latent's NLL from the waves' partial sums (LDS, second barrier).
+// A latent this cannot take -- a missing tick anywhere in its stream (chunk maps are no longer powers of one matrix), scan tables that
+// do not decay that fast or are unusable -- is handed, inside the same launch, to the one-wavefront sweep above (wave 0 runs
+// filter_x_body over the whole stream, the other waves leave): exact, slower, as the SPLIT kernel treats such latents.
+constexpr int kTeamWaves = 8;          // 512 threads: the one-wavefront fallback keeps its 256-register budget
+template <int D> constexpr int team_table_len() { return XC<D>::GN + 6 * XC<D>::LS; }             // response table + the six scan powers (contiguous in XC)
+template <typename T, int D> constexpr size_t team_part_offset(int nw) { return (((size_t)nw * (64 * (kChunkX + 16 / sizeof(T)) + 2 * D) + team_table_len<D>()) * sizeof(T) + 15) / 16 * 16; }
+template <typename T, int D> constexpr size_t team_smem_bytes(int nw) { return team_part_offset<T, D>(nw) + (size_t)nw * 2 * sizeof(double); }
+
+template <typename T, int DB, int J, bool WRITE, bool NLL>
+__global__ void __launch_bounds__(64 * kTeamWaves)
+filter_x_team_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, const T* __restrict__ cbT, const double* __restrict__ cb64,
+                     const T* xin0, T* x, T* __restrict__ yhat, double* __restrict__ nll, size_t ldo, int nw /* wavefronts = segments of the stream */) {
+    constexpr int D = DB * J;
+    using V = typename VecOf<T>::type;
+    using Lay = XC<D>;
+    constexpr int CK = kChunkX, EPV = 16 / sizeof(T), STRIDE = CK + EPV, SEG = 64 * CK;
+    constexpr int NSL = Lay::LS / 16, NSG = Lay::GN / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char team_smem[];
+    T* tiles = reinterpret_cast<T*>(team_smem);                                       // [nw][64 * STRIDE]
+    T* e0end = tiles + (size_t)nw * 64 * STRIDE;                                       // [nw][D]  zero-start end state of every segment
+    T* carries = e0end + (size_t)nw * D;                                               // [nw][D]  carry-out slots of the replays (and of the fallback sweep)
+    T* tab = carries + (size_t)nw * D;                                                 // [GN + 6 LS]  this latent's response table and scan powers
+    double* part = reinterpret_cast<double*>(team_smem + team_part_offset<T, D>(nw));  // [nw][2]  per-wave sum of v^2, observed ticks
+    __shared__ int dirty_any;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t l = blockIdx.x;
+    if (l >= L) return;
+    const T* __restrict__ c = cbT + l * Lay::SIZE;
+    static_assert(Lay::SP == Lay::G + Lay::GN, "the team kernel copies G and SP as one range");
+    const bool scan_ok = __builtin_amdgcn_readfirstlane((int)(c[Lay::SCANOK] != T(0))) != 0;
+    const int nlev = __builtin_amdgcn_readfirstlane((int)c[Lay::NLEV]);
+    const bool team_ok = scan_ok && nlev <= 5;                                         // uniform over the workgroup
+    T* tile = tiles + (size_t)wave * 64 * STRIDE;
+    T* tile_lane = tile + lane * STRIDE;
+    const T* row = Ty + l * ld;
+    const size_t t0 = (size_t)wave * SEG;
+    const int n = (int)(Tlen - t0 < (size_t)SEG ? Tlen - t0 : (size_t)SEG);            // (nw = ceil(Tlen / SEG): every wave owns >= 1 tick)
+    // A wave's life here is one dependent chain (little else runs on its SIMD to hide a wait), so every global load of the sweep is
+    // issued up front: the wave's segment, the latent's tables (ONE copy per workgroup, into LDS: all waves sweep the same latent, and an
+    // LDS read later costs ~100 cycles where a fetch from L2 / HBM costs 1-2 us), the replay's blocks of A (scalar loads)
+    V raw[CK / EPV];
+    ReplayConst<T, DB, J> rc;
+    if (team_ok) {
+#pragma unroll
+        for (int r = 0; r < CK / EPV; r++) {
+            const int e = (r * 64 + lane) * EPV;
+            raw[r] = V{};
+            if (e < n) raw[r] = nt_load(reinterpret_cast<const V*>(row + t0 + e));
+        }
+        for (int e = threadIdx.x; e < team_table_len<D>(); e += blockDim.x) tab[e] = c[Lay::G + e];
+        load_replay_const<T, DB, J>(launder(c), c, lane, rc);
+    }
+    if (threadIdx.x == 0) dirty_any = 0;
+    __syncthreads();
+    T z[D];
+    bool bad = false;
+    if (team_ok) {
+        // ---- A. stage in (chunk-major into the padded tile), chunk response, scan from a zero state ----
+#pragma unroll
+        for (int r = 0; r < CK / EPV; r++) {
+            const int e = (r * 64 + lane) * EPV;
+            T vals[EPV];
+            unpack<T>(raw[r], vals);
+#pragma unroll
+            for (int q = 0; q < EPV; q++) if (e + q >= n) vals[q] = T(0);           // beyond the stream: inert zeros
+            *reinterpret_cast<V*>(tile + (e / CK) * STRIDE + (e % CK)) = pack<T>(vals);
+        }
+        T g[NSG];
+        load_slabs<T, NSG>(tab, lane, g);
+        wave_lds_fence();
+#pragma unroll
+        for (int i = 0; i < D; i++) z[i] = T(0);
+        static_for<CK / EPV>([&](auto kvv) {
+            constexpr int kv = decltype(kvv)::value;
+            T yv[EPV];
+            unpack<T>(*reinterpret_cast<const V*>(tile_lane + kv * EPV), yv);
+            static_for<EPV>([&](auto qq) {
+                constexpr int k = kv * EPV + decltype(qq)::value;
+                bad = bad || (yv[decltype(qq)::value] != yv[decltype(qq)::value]);
+                if constexpr (kXSkip & 1) { z[k % D] += yv[decltype(qq)::value]; return; }
+                static_for<D>([&](auto ii) {
+                    constexpr int e = k * D + decltype(ii)::value;
+                    fmac_bc<e % 16>(z[decltype(ii)::value], g[e / 16], yv[decltype(qq)::value]);
+                });
+            });
+            if constexpr (kv % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+        });
+        if (__builtin_amdgcn_ballot_w64(bad) != 0) { if (lane == 0) dirty_any = 1; }
+        else {
+            T t[D];
+#pragma unroll
+            for (int lv = 0; lv < 6; lv++) {
+                if (lv >= nlev || (kXSkip & 2)) break;
+                T sp[NSL];
+                load_slabs<T, NSL>(tab + Lay::GN + lv * Lay::LS, lane, sp);
+                const int sh = 1 << lv, addr = ((lane - sh) & 63) * 4;
+#pragma unroll
+                for (int i = 0; i < D; i++) { const T m = bperm<T>(addr, z[i]); t[i] = lane >= sh ? m : T(0); }
+                matvec_bc<T, D, NSL>(sp, t, z);
+            }
+            if (lane == 63) {
+#pragma unroll
+                for (int i = 0; i < D; i++) e0end[wave * D + i] = z[i];
+            }
+        }
+    }
+    __syncthreads();
+    if (!team_ok || dirty_any) {
+        // ---- fallback: the whole stream by one wavefront (the SPLIT kernel's own treatment of such latents) ----
+        if (wave != 0) return;
+        filter_x_body<T, DB, J, WRITE, NLL, true, false>(Ty, Tlen, ld, cbT, cb64, xin0, x, yhat, nll, /*nslice=*/1, /*segs_per_slice=*/(int)((Tlen + SEG - 1) / SEG),
+                                                         /*nll_part=*/nll, ldo, nullptr, nullptr, l, /*slice=*/0, lane, tile, carries);
+        return;
+    }
+    // ---- B. the state entering this segment, its way into the lanes' start states, replay ----
+    T xs[D];
+    {
+        T q[D], t[D];
+#pragma unroll
+        for (int i = 0; i < D; i++) {
+            const T cin = wave == 0 ? xin0[l * D + i] : e0end[(wave - 1) * D + i];     // (uniform address: one broadcast read)
+            q[i] = lane == 0 ? cin : T(0);
+        }
+#pragma unroll
+        for (int lv = 0; lv < 6; lv++) {
+            if (lv >= nlev || (kXSkip & 2)) break;
+            T sp[NSL];
+            load_slabs<T, NSL>(tab + Lay::GN + lv * Lay::LS, lane, sp);
+            const int sh = 1 << lv, addr = ((lane - sh) & 63) * 4;
+#pragma unroll
+            for (int i = 0; i < D; i++) { const T m = bperm<T>(addr, q[i]); t[i] = lane >= sh ? m : T(0); }
+            matvec_bc<T, D, NSL>(sp, t, q);
+        }
+        const int addr1 = ((lane - 1) & 63) * 4;
+#pragma unroll
+        for (int i = 0; i < D; i++) { const T m = bperm<T>(addr1, z[i]); xs[i] = (lane >= 1 ? m : T(0)) + q[i]; }
+    }
+    T xc[D];
+    double acc = 0.0;
+    unsigned nobs = 0;
+    if constexpr (kXSkip & 4) {
+#pragma unroll
+        for (int i = 0; i < D; i++) xc[i] = read_lane(xs[i], 63);
+    } else
+    replay<T, DB, J, WRITE, NLL>(rc, tile_lane, carries + wave * D, lane, n, 0, xs, xc, acc, nobs);
+    // ---- stage out ----
+    if (WRITE) {
+        wave_lds_fence();
+        T* orow = yhat + l * ldo;
+#pragma unroll
+        for (int r = 0; r < CK / EPV; r++) {
+            const int e = (r * 64 + lane) * EPV;
+            if (e < n) nt_store(*reinterpret_cast<const V*>(tile + (e / CK) * STRIDE + (e % CK)), reinterpret_cast<V*>(orow + t0 + e));
+        }
+    }
+    if (wave == nw - 1 && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < D; i++) x[l * D + i] = xc[i];
+    }
+    if (NLL) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { acc += __shfl_xor(acc, o, 64); nobs += __shfl_xor(nobs, o, 64); }
+        if (lane == 0) { part[2 * wave] = acc; part[2 * wave + 1] = (double)nobs; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double a = 0.0, nn = 0.0;
+            for (int w = 0; w < nw; w++) { a += part[2 * w]; nn += part[2 * w + 1]; }      // in segment order (deterministic)
+            const double* c64 = cb64 + l * Lay::SIZE;
+            nll[l] = 0.5 * (a / c64[Lay::S] + nn * c64[Lay::LOGS]);
         }
     }
 }
@@ -680,9 +1047,32 @@ int launch_x(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, con
 }
 
 template <typename T, int DB, int J>
+int launch_x_team(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, const double* cb64, const void* xin, void* x, void* yhat, double* nll,
+                  hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, size_t ldo, double* total, int nw) {
+    const size_t smem = team_smem_bytes<T, DB * J>(nw);
+    dim3 block(64 * nw), grid((unsigned)L);
+#define MOIHGP_TEAM_LAUNCH(W_, N_)                                                                                                                   \
+    do {                                                                                                                                             \
+        auto kfn = filter_x_team_kernel<T, DB, J, W_, N_>;                                                                                           \
+        static size_t attr_set = 48 * 1024;  /* (more dynamic LDS than the default limit needs the attribute: raised on demand, per instantiation) */    \
+        if (smem > attr_set) { MOIHGP_HIP_FATAL(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); attr_set = smem; } \
+        hipExtLaunchKernelGGL(kfn, grid, block, smem, stream, ev0, ev1, 0, (const T*)Ty, Tlen, ld, L, cbT, cb64, (const T*)xin, (T*)x, (T*)yhat, nll, ldo, nw); \
+    } while (0)
+    if (yhat && nll) MOIHGP_TEAM_LAUNCH(true, true);
+    else if (yhat) MOIHGP_TEAM_LAUNCH(true, false);
+    else if (nll) MOIHGP_TEAM_LAUNCH(false, true);
+    else MOIHGP_TEAM_LAUNCH(false, false);
+#undef MOIHGP_TEAM_LAUNCH
+    if (nll && total) launch_nll_total(nll, L, total, stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_last_error("filter_x_team_kernel launch: %s", hipGetErrorString(e)); return 2; }
+    return 0;
+}
+
+template <typename T, int DB, int J>
 int launch_xd(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, const double* cb64, const void* xin, void* x, void* yhat, double* nll,
               hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, double* scratch, size_t scratch_len, int force_slices, size_t ldo,
-              int* link_flags, double* link_state, double* total, int env_links) {
+              int* link_flags, double* link_state, double* total, int env_links, int team_mode) {
     constexpr size_t SEG = 64 * (size_t)kChunkX;
     if (L >= 1024) {
         // chunks with a gap per segment up to which the broken-link stages of the second pass beat the tick-by-tick walk (measured,
@@ -691,9 +1081,18 @@ int launch_xd(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, co
         return launch_x<T, DB, J, 4, false>(Ty, Tlen, ld, L, cbT, cb64, xin, x, yhat, nll, stream, ev0, ev1, 1, max_links, nullptr, ldo,
                                             (max_links > 0 && link_state) ? link_flags : nullptr, link_state, total);
     }
-    // few latents: one wavefront per workgroup, and the stream cut into time slices (one wavefront each) while that adds
-    // wavefronts the chip can still use
     const size_t nseg = (Tlen + SEG - 1) / SEG;
+    // few latents, a stream of 2 .. kTeamWaves segments: one workgroup per latent, one wavefront per segment (filter_x_team_kernel), as long as
+    // all workgroups are resident at once (LDS: a wave's tile is 9 / 17 KB)
+    if (team_mode != 0 && force_slices == 0 && nseg >= 2 && nseg <= (size_t)kTeamWaves) {
+        const size_t smem = team_smem_bytes<T, DB * J>((int)nseg);
+        size_t per_cu = (160 * 1024) / smem;
+        if (per_cu > 2048 / (64 * nseg)) per_cu = 2048 / (64 * nseg);
+        if (smem <= 150 * 1024 && (team_mode == 1 || L <= 256 * per_cu))
+            return launch_x_team<T, DB, J>(Ty, Tlen, ld, L, cbT, cb64, xin, x, yhat, nll, stream, ev0, ev1, ldo, total, (int)nseg);
+    }
+    // otherwise: one wavefront per workgroup, and the stream cut into time slices (one wavefront each) while that adds
+    // wavefronts the chip can still use
     size_t want = force_slices > 0 ? (size_t)force_slices : (2048 + L - 1) / L;
     if (want > nseg) want = nseg;
     if (want * L > scratch_len) want = scratch_len / L;
@@ -714,14 +1113,14 @@ int launch_xd(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, co
 
 int launch_filter_stream_x(int kernel, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* cb64, const float* cb32,
                            const void* xin, void* x, void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1,
-                           double* scratch, size_t scratch_len, int force_slices, size_t ldo, int* link_flags, double* link_state, double* total, int max_links) {
+                           double* scratch, size_t scratch_len, int force_slices, size_t ldo, int* link_flags, double* link_state, double* total, int max_links, int team_mode) {
     if (L == 0) return 0;
     if (ldo == 0) ldo = ld;
     const int base = kernel_base(kernel), J = kernel_stack(kernel);
 #define MOIHGP_X_CASE(DBB, JJ)                                                                                        \
     if (base == (DBB == 2 ? 0 : 1) && J == JJ)                                                                        \
-        return dtype == 0 ? launch_xd<double, DBB, JJ>(Ty, T, ld, L, cb64, cb64, xin, x, yhat, nll, stream, ev0, ev1, scratch, scratch_len, force_slices, ldo, link_flags, link_state, total, max_links) \
-                          : launch_xd<float, DBB, JJ>(Ty, T, ld, L, cb32, cb64, xin, x, yhat, nll, stream, ev0, ev1, scratch, scratch_len, force_slices, ldo, link_flags, link_state, total, max_links)
+        return dtype == 0 ? launch_xd<double, DBB, JJ>(Ty, T, ld, L, cb64, cb64, xin, x, yhat, nll, stream, ev0, ev1, scratch, scratch_len, force_slices, ldo, link_flags, link_state, total, max_links, team_mode) \
+                          : launch_xd<float, DBB, JJ>(Ty, T, ld, L, cb32, cb64, xin, x, yhat, nll, stream, ev0, ev1, scratch, scratch_len, force_slices, ldo, link_flags, link_state, total, max_links, team_mode)
 #ifdef MOIHGP_X_ONLY_DBJ         // (development: -DMOIHGP_X_ONLY_DBJ=32 builds the DB = 3, J = 2 kernels alone: quick resource checks, A/B builds)
     MOIHGP_X_CASE(MOIHGP_X_ONLY_DBJ / 10, MOIHGP_X_ONLY_DBJ % 10);
 #else

@@ -226,6 +226,17 @@ __global__ void __launch_bounds__(64) stack_update_kernel(double dt, const doubl
         put(L::AB + e, e < J * DB * DB ? sA[(j * DB + a) * D + j * DB + b] : 0.0);
     }
     for (int e = kChunkX * D + lane; e < L::GN; e += 64) put(L::G + e, 0.0);
+    for (int e = lane; e < L::SIZE - L::PK; e += 64) {              // coefficient pairs of the packed fp32 replay (and the block's zero padding)
+        constexpr int PB = DB * DB + 2 * DB, NPAIR = (J + 1) / 2;
+        const int pr = e / 2, half = e % 2, p = pr / PB, i = pr % PB, j = 2 * p + half;      // block j supplies this half of pair i of block pair p
+        double v = 0.0;
+        if (p < NPAIR && j < J) {
+            if (i < DB * DB) v = sA[(j * DB + i / DB) * D + j * DB + i % DB];
+            else if (i < DB * DB + DB) v = sHA[j * DB + (i - DB * DB)];
+            else v = sK[j * DB + (i - DB * DB - DB)];
+        }
+        put(L::PK + e, v);
+    }
 
     // tables of the segment solve (recursion_x.hip): g_k = AKHA^(CK-1-k) K, and M^(2^lv) with M = AKHA^CK
     // ("tame" per precision: a mildly unstable latent -- the literal DARE of dare.h:23 does return such gains -- still scans as
