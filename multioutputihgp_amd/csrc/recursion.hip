@@ -40,6 +40,41 @@ struct FastConst {
     T pj[D * D];       // M^(lane%16 + 1)
 };
 
+// Step 3 of the segment solve: a lane replays its chunk from its true start state xs in innovation form (H = e0^T, so HA is row 0 of A):
+//     hx = A0.x ; v = y - hx ; yhat = hx + K0 v ; x_i <- A_i.x + K_i v
+// y[] holds the chunk on entry and the filtered means on exit, xs the state after the lane's last valid tick.  TAIL: ragged last segment
+// (zero padded), the replay masked per tick.
+template <typename T, int D, int CK, bool NLL, bool TAIL>
+__device__ inline void replay_chunk(T* y, T* xs, const FastConst<T, D, CK>& c, size_t t0, size_t Tlen, double& acc, unsigned& nobs) {
+    T part = 0;                              // sum of v^2 over this chunk (<= 16 terms) in stream precision
+#pragma unroll
+    for (int k = 0; k < CK; k++) {
+        const bool valid = !TAIL || (t0 + k) < Tlen;
+        T hx = 0;
+#pragma unroll
+        for (int j = 0; j < D; j++) hx = fma(c.a[j], xs[j], hx);
+        T v = y[k] - hx;
+        if (TAIL) v = valid ? v : T(0);
+        if (NLL) {
+            part = fma(v, v, part);
+            if (TAIL) nobs += valid ? 1u : 0u;
+        }
+        T xn[D];
+        xn[0] = fma(c.k[0], v, hx);
+#pragma unroll
+        for (int i = 1; i < D; i++) {
+            T s = c.k[i] * v;
+#pragma unroll
+            for (int j = 0; j < D; j++) s = fma(c.a[i * D + j], xs[j], s);
+            xn[i] = s;
+        }
+#pragma unroll
+        for (int i = 0; i < D; i++) xs[i] = (TAIL && !valid) ? xs[i] : xn[i];
+        y[k] = xs[0];
+    }
+    if (NLL) acc += (double)part;
+}
+
 // Fast path for one segment (64 lanes x CK ticks) of one latent without missing ticks.  y[] holds the
 // lane's chunk on entry and the filtered means on exit.  xin (wave-uniform) is the state before the
 // segment's first tick and is replaced by the state after its last valid tick.
@@ -87,33 +122,7 @@ __device__ inline bool fast_segment(T* y, T* xin, const FastConst<T, D, CK>& c, 
 #pragma unroll
     for (int i = 0; i < D; i++) xs[i] = wave_shr1(z[i], xin[i]);
     // ---- 3. replay ------------------------------------------------------------------------------
-    T part = 0;                              // sum of v^2 over this chunk (<= 16 terms) in stream precision
-#pragma unroll
-    for (int k = 0; k < CK; k++) {
-        const bool valid = !TAIL || (t0 + k) < Tlen;
-        T hx = 0;
-#pragma unroll
-        for (int j = 0; j < D; j++) hx = fma(c.a[j], xs[j], hx);
-        T v = y[k] - hx;
-        if (TAIL) v = valid ? v : T(0);
-        if (NLL) {
-            part = fma(v, v, part);
-            if (TAIL) nobs += valid ? 1u : 0u;
-        }
-        T xn[D];
-        xn[0] = fma(c.k[0], v, hx);
-#pragma unroll
-        for (int i = 1; i < D; i++) {
-            T s = c.k[i] * v;
-#pragma unroll
-            for (int j = 0; j < D; j++) s = fma(c.a[i * D + j], xs[j], s);
-            xn[i] = s;
-        }
-#pragma unroll
-        for (int i = 0; i < D; i++) xs[i] = (TAIL && !valid) ? xs[i] : xn[i];
-        y[k] = xs[0];
-    }
-    if (NLL) acc += (double)part;
+    replay_chunk<T, D, CK, NLL, TAIL>(y, xs, c, t0, Tlen, acc, nobs);
     // state after the last valid tick = final replay state of the lane that owns it
     int jl = 63;
     if (TAIL) {
@@ -397,6 +406,153 @@ __device__ inline void sweep(const T* __restrict__ row, T* __restrict__ orow, si
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// TEAM path of the time split (few latents; tried first, inside the SPLIT kernel below): a wavefront keeps its slice -- up to kTeamSeg
+// segments -- IN REGISTERS between the two halves of the solve, the stream is read once and nothing is computed twice:
+//   A. per own segment: load, chunk responses, scan from a ZERO state -> z_j (state after chunk j had the segment started from zero); the
+//      chunk y and z stay in registers; lane 63's z, the segment's zero-start end state e0, goes to LDS.            __syncthreads()
+//   B. the state entering the wave's first segment by the serial recurrence over ALL segments before it,  c <- M^64 c + e0  (3 x 3 products,
+//      fp64, every wave for itself: <= 32 steps); a start state enters a segment linearly, so the true state after chunk j is
+//      z_j + M^(j+1) c = z_j + pj (M^16)^(j / 16) c  with the per-lane power pj = M^(j % 16 + 1) of the scan's own table; then the replay
+//      from the true start states, the stores, and the next own segment starts from this one's end state.
+// Against the two-pass split (slice maps, then a second sweep that re-reads the slice from L2 and repeats response and scan) this saves
+// the second load / LDS transposition / response / scan of every segment: ~200 of ~700 instructions per segment.
+// A missing tick anywhere in the latent's stream (chunk maps are then no powers of one matrix) sends the whole workgroup to the two-pass
+// split, which is exact across gaps: returns false, workgroup-uniform, nothing written.
+constexpr int kTeamSeg = 4;
+constexpr int kTeamMaxSegs = 32;            // segments per stream: kMaxSplit waves x kTeamSeg
+
+template <typename T, int D, int CK, bool WRITE, bool NLL>
+__device__ inline bool team_slice(const T* __restrict__ row, T* __restrict__ orow, size_t Tlen /* this wave's slice */, size_t toff /* its first tick */,
+                                  const FastConst<T, D, CK>& c, typename VecOf<T>::type* lds, int lane, double (*e0all)[D], int* dirty,
+                                  const T* xstart /* the latent's start state */, T* xout /* state after the slice */,
+                                  double& acc, unsigned& nobs, size_t& nobs_uniform) {
+    using V = typename VecOf<T>::type;
+    constexpr int EPV = 16 / sizeof(T), VPL = CK / EPV, SEG = 64 * CK;
+    const int nsg = (int)((Tlen + SEG - 1) / SEG), nfull = (int)(Tlen / SEG);          // own segments (<= kTeamSeg), the full ones among them
+    const int g0 = (int)(toff / SEG);                                                  // index of the first own segment in the stream
+    T y[kTeamSeg][CK], z[kTeamSeg][D];
+    bool bad = false;
+    // ---- A ----
+#pragma unroll
+    for (int sg = 0; sg < kTeamSeg; sg++) {
+        if (sg < nsg) {                                                                // wave-uniform
+            V r[VPL];
+            if (sg < nfull) {
+                const T* p = row + (size_t)sg * SEG + (size_t)lane * EPV;
+#pragma unroll
+                for (int i = 0; i < VPL; i++) r[i] = *reinterpret_cast<const V*>(p + (size_t)i * 64 * EPV);
+            } else {
+#pragma unroll
+                for (int i = 0; i < VPL; i++) {
+                    const size_t tq = (size_t)sg * SEG + (size_t)(i * 64 + lane) * EPV;
+                    T e[EPV] = {};
+                    if (tq < Tlen) {                                                   // ld >= roundup(T, EPV): the vector is in bounds
+                        unpack<T>(*reinterpret_cast<const V*>(row + tq), e);
+#pragma unroll
+                        for (int k = 0; k < EPV; k++) if (tq + k >= Tlen) e[k] = T(0);
+                    }
+                    r[i] = pack<T>(e);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < VPL; i++) { const int q = i * 64 + lane; lds[q + q / VPL] = r[i]; }
+            wave_lds_fence();
+#pragma unroll
+            for (int k = 0; k < VPL; k++) unpack<T>(lds[lane * (VPL + 1) + k], &y[sg][k * EPV]);
+            wave_lds_fence();
+#pragma unroll
+            for (int i = 0; i < D; i++) z[sg][i] = T(0);
+#pragma unroll
+            for (int k = 0; k < CK; k++)
+#pragma unroll
+                for (int i = 0; i < D; i++) z[sg][i] = fma(c.g[k * D + i], y[sg][k], z[sg][i]);
+#pragma unroll
+            for (int i = 0; i < D; i++) bad |= (z[sg][i] != z[sg][i]);             // a NaN y poisons z
+            dpp_scan<T, D>(z[sg], c.sp, c.pj);
+            if (lane == 63) {
+#pragma unroll
+                for (int i = 0; i < D; i++) e0all[g0 + sg][i] = (double)z[sg][i];
+            }
+        }
+    }
+    if (__any(bad) && lane == 0) *dirty = 1;
+    __syncthreads();
+    if (*dirty) return false;
+    // ---- B ----
+    double cc[D];
+    {
+        double ms[D * D], t[D * D];                                                    // M^64 = ((M^8)^2)^2)^2, the transition of a whole segment
+#pragma unroll
+        for (int i = 0; i < D * D; i++) ms[i] = (double)c.sp[3 * D * D + i];
+        matmul<double, D>(ms, ms, t); matmul<double, D>(t, t, ms); matmul<double, D>(ms, ms, t);
+#pragma unroll
+        for (int i = 0; i < D; i++) cc[i] = (double)xstart[i];
+        for (int g = 0; g < g0; g++) {
+            double cn[D];
+#pragma unroll
+            for (int i = 0; i < D; i++) {
+                double a = e0all[g][i];
+#pragma unroll
+                for (int j = 0; j < D; j++) a = fma(t[i * D + j], cc[j], a);
+                cn[i] = a;
+            }
+#pragma unroll
+            for (int i = 0; i < D; i++) cc[i] = cn[i];
+        }
+    }
+    T m16[D * D];                                                                      // M^16: lane 15's entry of the per-lane table
+#pragma unroll
+    for (int i = 0; i < D * D; i++) m16[i] = read_lane(c.pj[i], 15);
+    const int rowi = lane >> 4;
+#pragma unroll
+    for (int sg = 0; sg < kTeamSeg; sg++) {
+        if (sg < nsg) {
+            T cin[D], u[D], t1[D];
+#pragma unroll
+            for (int i = 0; i < D; i++) { cin[i] = (T)cc[i]; u[i] = cin[i]; }
+#pragma unroll
+            for (int rr = 1; rr < 4; rr++) {                                           // u = (M^16)^row cin
+#pragma unroll
+                for (int i = 0; i < D; i++) t1[i] = T(0);
+                matvec_acc<T, D>(m16, u, t1);
+#pragma unroll
+                for (int i = 0; i < D; i++) u[i] = rowi >= rr ? t1[i] : u[i];
+            }
+            matvec_acc<T, D>(c.pj, u, z[sg]);                                          // true state after chunk j: z_j + M^(j+1) cin
+            T xs[D];
+#pragma unroll
+            for (int i = 0; i < D; i++) xs[i] = wave_shr1(z[sg][i], cin[i]);
+            const size_t t0 = (size_t)sg * SEG + (size_t)lane * CK;
+            int jl = 63;
+            if (sg < nfull) {
+                replay_chunk<T, D, CK, NLL, false>(y[sg], xs, c, t0, Tlen, acc, nobs);
+                nobs_uniform += SEG;
+            } else {
+                replay_chunk<T, D, CK, NLL, true>(y[sg], xs, c, t0, Tlen, acc, nobs);
+                jl = (int)((Tlen - 1 - (size_t)sg * SEG) / CK);
+            }
+#pragma unroll
+            for (int i = 0; i < D; i++) cc[i] = (double)read_lane(xs[i], jl);
+            if (WRITE) {
+#pragma unroll
+                for (int k = 0; k < VPL; k++) lds[lane * (VPL + 1) + k] = pack<T>(&y[sg][k * EPV]);
+                wave_lds_fence();
+                T* po = orow + (size_t)sg * SEG + (size_t)lane * EPV;
+#pragma unroll
+                for (int i = 0; i < VPL; i++) {
+                    const int q = i * 64 + lane;
+                    if (sg < nfull || (size_t)sg * SEG + (size_t)q * EPV < Tlen) nt_store(lds[q + q / VPL], reinterpret_cast<V*>(po + (size_t)i * 64 * EPV));
+                }
+                wave_lds_fence();
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < D; i++) xout[i] = (T)cc[i];
+    return true;
+}
+
 constexpr int kMaxSplit = 8;    // slices per latent = waves per workgroup in split mode (512 threads: 256-VGPR budget)
 
 // ---------------------------------------------------------------------------------------------
@@ -413,7 +569,7 @@ filter_scan_kernel(const T* __restrict__ Ty, size_t Ttot, size_t ld, size_t L, c
                    const double* __restrict__ cb64, const T* xin0 /* start state */, T* x /* end state; may be the same buffer */,
                    T* __restrict__ yhat, double* __restrict__ nll, int nsplit, size_t Tslice,
                    int nbig /* split: slices [0, nbig) hold Tslice ticks, the later ones one segment less (nbig == nsplit: all alike) */,
-                   size_t ldo /* row stride of yhat (the stream's own is ld) */) {
+                   size_t ldo /* row stride of yhat (the stream's own is ld) */, int team /* split: try the team path first (slices of <= kTeamSeg segments) */) {
     using V = typename VecOf<T>::type;
     using Lay = CB<D>;
     constexpr int EPV = 16 / sizeof(T);
@@ -467,7 +623,19 @@ filter_scan_kernel(const T* __restrict__ Ty, size_t Ttot, size_t ld, size_t L, c
     unsigned nobs = 0;         // per-lane count of observed ticks (tail / generic segments)
     size_t nobs_uniform = 0;   // observed ticks of full fast-path segments (every lane contributes CK)
 
+    bool team_done = false;
     if (SPLIT) {
+        if (team) {
+            // (behind the tiles, the carry records and the scan powers: the segments' zero-start end states and the "stream has a gap" flag)
+            unsigned char* tb = smem + (size_t)nsplit * NVP * sizeof(V) + (size_t)nsplit * CR * sizeof(double) + (((size_t)nsplit * 4 * D * D * sizeof(T) + 15) & ~(size_t)15);
+            double (*e0all)[D] = reinterpret_cast<double (*)[D]>(tb);
+            int* dirty = reinterpret_cast<int*>(tb + (size_t)kTeamMaxSegs * D * sizeof(double));
+            if (threadIdx.x == 0) *dirty = 0;
+            __syncthreads();
+            team_done = team_slice<T, D, CK, WRITE, NLL>(row, orow, Tlen, toff, c, lds, lane, e0all, dirty, xin0 + l * D, xin, acc, nobs, nobs_uniform);
+        }
+    }
+    if (SPLIT && !team_done) {
         // ---- pass 1: affine map of this slice, from a zero start.  Nobody consumes the map of the LAST
         // slice, so it skips this pass (it is also the only slice that can be ragged: Tslice is a whole
         // number of segments, hence pass 1 never meets a tail).
@@ -504,13 +672,13 @@ filter_scan_kernel(const T* __restrict__ Ty, size_t Ttot, size_t ld, size_t L, c
         for (int i = 0; i < D; i++) xin[i] = (T)xc[i];
         acc = 0.0; nobs = 0; nobs_uniform = 0;
         __syncthreads();       // everyone has read x[l] and the maps before anything is overwritten
-    } else {
+    } else if (!SPLIT) {
 #pragma unroll
         for (int i = 0; i < D; i++) xin[i] = xin0[l * D + i];
     }
 
     // ---- the real sweep (split + state only: just the last slice needs it) -------------------------
-    if (WRITE || NLL || !SPLIT || wave == nsplit - 1) {
+    if (!team_done && (WRITE || NLL || !SPLIT || wave == nsplit - 1)) {
         T unused[D * D];
         sweep<T, D, CK, WRITE, NLL, false, DBG>(row, orow, Tlen, xin, c, cb, lds, lane, acc, nobs, nobs_uniform, unused);
     }
@@ -615,25 +783,28 @@ filter_seq_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, co
 template <typename T, int D, int CK, int MINW, bool SPLIT>
 int launch_filter_t(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, const double* cb64, const void* xin, void* x,
                     void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, int nsplit, size_t Tslice, int n_unstable,
-                    double* total, int nbig, size_t ldo) {
+                    double* total, int nbig, size_t ldo, int team_ok = 1) {
     dim3 block(SPLIT ? 64 * nsplit : 64 * kWavesPerBlock);
     dim3 grid(SPLIT ? (unsigned)L : (unsigned)((L + kWavesPerBlock - 1) / kWavesPerBlock));
     constexpr size_t tile = 64 * (CK / (16 / sizeof(T)) + 1) * 16;                    // padded LDS tile per wave
     const size_t smem = (SPLIT ? (size_t)nsplit * (tile + (D * D + D + 2) * sizeof(double)) : (size_t)kWavesPerBlock * tile) +
-                        (size_t)(SPLIT ? nsplit : kWavesPerBlock) * 4 * D * D * sizeof(T);
+                        (size_t)(SPLIT ? nsplit : kWavesPerBlock) * 4 * D * D * sizeof(T) +
+                        (SPLIT ? (size_t)kTeamMaxSegs * D * sizeof(double) + 32 : 0);             // (team path: zero-start end states of the segments, flag)
+    // team path of the split: every slice fits kTeamSeg segments kept in registers
+    const int team = (SPLIT && team_ok && Tslice <= (size_t)kTeamSeg * 64 * CK && (Tlen + 64 * CK - 1) / (64 * CK) <= (size_t)kTeamMaxSegs) ? 1 : 0;
     const T* ty = static_cast<const T*>(Ty);
     const T* xi = static_cast<const T*>(xin);
     T* xs = static_cast<T*>(x);
     T* yh = static_cast<T*>(yhat);
     // hipExtLaunchKernelGGL attaches the (optional) events to the dispatch itself: kernel-exact timing
     if (yhat && nll)
-        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, true, true, MINW, SPLIT>), grid, block, smem, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nsplit, Tslice, nbig, ldo);
+        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, true, true, MINW, SPLIT>), grid, block, smem, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nsplit, Tslice, nbig, ldo, team);
     else if (yhat)
-        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, true, false, MINW, SPLIT>), grid, block, smem, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nsplit, Tslice, nbig, ldo);
+        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, true, false, MINW, SPLIT>), grid, block, smem, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nsplit, Tslice, nbig, ldo, team);
     else if (nll)
-        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, false, true, MINW, SPLIT>), grid, block, smem, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nsplit, Tslice, nbig, ldo);
+        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, false, true, MINW, SPLIT>), grid, block, smem, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nsplit, Tslice, nbig, ldo, team);
     else
-        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, false, false, MINW, SPLIT>), grid, block, smem, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nsplit, Tslice, nbig, ldo);
+        hipExtLaunchKernelGGL((filter_scan_kernel<T, D, CK, false, false, MINW, SPLIT>), grid, block, smem, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nsplit, Tslice, nbig, ldo, team);
     if (n_unstable > 0)
         hipLaunchKernelGGL((filter_seq_kernel<T, D>), dim3((unsigned)((L + 63) / 64)), dim3(64), 0, stream, ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, ldo);
     if (total && nll) hipLaunchKernelGGL(nll_total_kernel, dim3(1), dim3(1024), 0, stream, nll, L, total);
@@ -696,7 +867,7 @@ int launch_filter_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, 
         dim3 block(64 * kWavesPerBlock), grid((unsigned)((L + kWavesPerBlock - 1) / kWavesPerBlock));
         const size_t sm = (size_t)kWavesPerBlock * (64 * 5 * 16 + 36 * 4);
 #define MOIHGP_PROBE(MW, DBG_) hipExtLaunchKernelGGL((filter_scan_kernel<float, 3, kChunk32, true, true, MW, false, DBG_>), grid, block, sm, stream, ev0, ev1, 0, \
-                                                     (const float*)Ty, T, ld, L, cb32, cb64, (const float*)xin, (float*)x, (float*)yhat, nll, 1, T, 1, ldo)
+                                                     (const float*)Ty, T, ld, L, cb32, cb64, (const float*)xin, (float*)x, (float*)yhat, nll, 1, T, 1, ldo, 0)
         if (variant == 2) MOIHGP_PROBE(4, 2);
         else if (variant == 4) MOIHGP_PROBE(4, 4);
         else if (variant == 6) MOIHGP_PROBE(4, 6);

@@ -139,7 +139,11 @@ __device__ inline void replay_dpp(const T (&a)[J * DB * DB], const T& ha, const 
     wave_lds_fence();
 }
 
-template <typename T, int DB, int J, bool WRITE, bool NLL>
+// FULLFAST: a full segment without warm-up (n == 64 kChunkX, head == 0: a wave-uniform test) takes a copy of the loop without the per-tick
+// "is this the stream's last tick" test (five scalar instructions and a branch per tick: a lone wave issues one instruction of any kind
+// per four cycles, so they cost as much as vector ones); its carry-out is lane 63's final state.  The team kernel asks for it; the
+// many-latent kernel keeps the single loop (a second copy took part in its register allocation).
+template <typename T, int DB, int J, bool WRITE, bool NLL, bool FULLFAST = false>
 __device__ inline void replay(const ReplayConst<T, DB, J>& rc, T* tile_lane, T* carry, int lane, int n, int head,
                               T (&xs)[DB * J], T (&xc)[DB * J], double& acc, unsigned& nobs) {
     using RC = ReplayConst<T, DB, J>;
@@ -163,6 +167,8 @@ __device__ inline void replay(const ReplayConst<T, DB, J>& rc, T* tile_lane, T* 
     T partf = 0;                    // PK: sum of v^2 over the chunk in stream precision (32 terms), added to the fp64 total once
     double part = 0.0;
     V cur = *reinterpret_cast<const V*>(tile_lane);
+    auto walk = [&](auto check_tag) {
+    constexpr bool CHECK = decltype(check_tag)::value;
 #pragma unroll 2
     for (int g = 0; g < NG; g++) {
         const V nxt = *reinterpret_cast<const V*>(tile_lane + (g + 1 < NG ? g + 1 : g) * EPV);    // in flight during this group's ticks
@@ -194,7 +200,7 @@ __device__ inline void replay(const ReplayConst<T, DB, J>& rc, T* tile_lane, T* 
 #pragma unroll
                 for (int i = 0; i < RC::NPAIR * DB; i++) X[i] = XN[i];
                 o[e] = XN[0].x;                                        // ihgp.h:91 `yhat = xnew(0, 0)`, literally
-                if (k == klast) {                                      // wave-uniform
+                if (CHECK && k == klast) {                             // wave-uniform
                     if (lane == jl) {
                         if (NLL && counted) acc += (double)partf;
 #pragma unroll
@@ -206,7 +212,7 @@ __device__ inline void replay(const ReplayConst<T, DB, J>& rc, T* tile_lane, T* 
                             }
                     }
                 }
-            } else {
+            } else if constexpr (RC::SOP) {
                 T v;
                 {
                     T h0 = fma(rc.has[0], xs[0], -y[e]), h1 = rc.has[1] * xs[1];
@@ -233,7 +239,7 @@ __device__ inline void replay(const ReplayConst<T, DB, J>& rc, T* tile_lane, T* 
 #pragma unroll
                 for (int i = 0; i < D; i++) xs[i] = xn[i];
                 o[e] = xn[0];                                          // ihgp.h:91 `yhat = xnew(0, 0)`, literally
-                if (k == klast) {                                      // wave-uniform
+                if (CHECK && k == klast) {                             // wave-uniform
                     if (lane == jl) {
                         if (NLL && counted) acc += part;
 #pragma unroll
@@ -244,6 +250,28 @@ __device__ inline void replay(const ReplayConst<T, DB, J>& rc, T* tile_lane, T* 
         }
         if (WRITE) *reinterpret_cast<V*>(tile_lane + g * EPV) = pack<T>(o);
         cur = nxt;
+    }
+    };
+    if (FULLFAST && n == 64 * kChunkX && head == 0) {
+        walk(std::false_type{});
+        if (lane == 63) {                                              // the segment's last tick is lane 63's last
+            if constexpr (RC::PK) {
+#pragma unroll
+                for (int p = 0; p < RC::NPAIR; p++)
+#pragma unroll
+                    for (int q = 0; q < DB; q++) {
+                        carry[(2 * p) * DB + q] = X[p * DB + q].x;
+                        if (2 * p + 1 < J) carry[(2 * p + 1 < J ? 2 * p + 1 : 0) * DB + q] = X[p * DB + q].y;
+                    }
+                if (NLL) acc += (double)partf;
+            } else {
+#pragma unroll
+                for (int i = 0; i < D; i++) carry[i] = xs[i];
+                if (NLL) acc += part;
+            }
+        }
+    } else {
+        walk(std::true_type{});
     }
     if (NLL) {
         if constexpr (RC::PK) part = (double)partf;
@@ -895,16 +923,16 @@ filter_x_team_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L,
         });
         if (__builtin_amdgcn_ballot_w64(bad) != 0) { if (lane == 0) dirty_any = 1; }
         else {
-            T t[D];
+            T t[D], sp[2][NSL];
+            if (nlev > 0) load_slabs<T, NSL>(tab + Lay::GN, lane, sp[0]);
 #pragma unroll
             for (int lv = 0; lv < 6; lv++) {
                 if (lv >= nlev || (kXSkip & 2)) break;
-                T sp[NSL];
-                load_slabs<T, NSL>(tab + Lay::GN + lv * Lay::LS, lane, sp);
                 const int sh = 1 << lv, addr = ((lane - sh) & 63) * 4;
 #pragma unroll
                 for (int i = 0; i < D; i++) { const T m = bperm<T>(addr, z[i]); t[i] = lane >= sh ? m : T(0); }
-                matvec_bc<T, D, NSL>(sp, t, z);
+                if (lv + 1 < nlev) load_slabs<T, NSL>(tab + Lay::GN + (lv + 1) * Lay::LS, lane, sp[(lv + 1) & 1]);   // (next power: in flight during this level)
+                matvec_bc<T, D, NSL>(sp[lv & 1], t, z);
             }
             if (lane == 63) {
 #pragma unroll
@@ -921,27 +949,33 @@ filter_x_team_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L,
         return;
     }
     // ---- B. the state entering this segment, its way into the lanes' start states, replay ----
+    // q_j = M^j c_s: c_s is the same vector in every lane, so lane j applies the binary powers M^(2^k) of the set bits of j (they commute):
+    // per level one uniform matrix-vector product and a select, and no lane exchange (a scan of (c_s, 0, 0, ..) gives the same vectors
+    // through five ds_bpermute round trips, on a wave whose critical path this is)
     T xs[D];
     {
-        T q[D], t[D];
+        T q[D];
 #pragma unroll
-        for (int i = 0; i < D; i++) {
-            const T cin = wave == 0 ? xin0[l * D + i] : e0end[(wave - 1) * D + i];     // (uniform address: one broadcast read)
-            q[i] = lane == 0 ? cin : T(0);
-        }
+        for (int i = 0; i < D; i++) q[i] = wave == 0 ? xin0[l * D + i] : e0end[(wave - 1) * D + i];     // (uniform address: one broadcast read)
+        T sp[NSL];
+        if (nlev > 0) load_slabs<T, NSL>(tab + Lay::GN, lane, sp);
 #pragma unroll
         for (int lv = 0; lv < 6; lv++) {
             if (lv >= nlev || (kXSkip & 2)) break;
-            T sp[NSL];
-            load_slabs<T, NSL>(tab + Lay::GN + lv * Lay::LS, lane, sp);
-            const int sh = 1 << lv, addr = ((lane - sh) & 63) * 4;
+            T t[D];
 #pragma unroll
-            for (int i = 0; i < D; i++) { const T m = bperm<T>(addr, q[i]); t[i] = lane >= sh ? m : T(0); }
-            matvec_bc<T, D, NSL>(sp, t, q);
+            for (int i = 0; i < D; i++) t[i] = T(0);
+            matvec_bc<T, D, NSL>(sp, q, t);                            // M^(2^lv) q
+            if (lv + 1 < nlev) load_slabs<T, NSL>(tab + Lay::GN + (lv + 1) * Lay::LS, lane, sp);     // (the next power, in flight during the selects)
+            const bool bit = (lane >> lv) & 1;
+#pragma unroll
+            for (int i = 0; i < D; i++) q[i] = bit ? t[i] : q[i];
         }
+        // (a lane whose index has a bit at or above nlev set would need M^(2^nlev) or more: below 1e-20 / 1e-10 by the table's own criterion)
+        const bool far = (lane >> nlev) != 0;
         const int addr1 = ((lane - 1) & 63) * 4;
 #pragma unroll
-        for (int i = 0; i < D; i++) { const T m = bperm<T>(addr1, z[i]); xs[i] = (lane >= 1 ? m : T(0)) + q[i]; }
+        for (int i = 0; i < D; i++) { const T m = bperm<T>(addr1, z[i]); xs[i] = (lane >= 1 ? m : T(0)) + (far ? T(0) : q[i]); }
     }
     T xc[D];
     double acc = 0.0;
@@ -950,7 +984,7 @@ filter_x_team_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L,
 #pragma unroll
         for (int i = 0; i < D; i++) xc[i] = read_lane(xs[i], 63);
     } else
-    replay<T, DB, J, WRITE, NLL>(rc, tile_lane, carries + wave * D, lane, n, 0, xs, xc, acc, nobs);
+    replay<T, DB, J, WRITE, NLL, true>(rc, tile_lane, carries + wave * D, lane, n, 0, xs, xc, acc, nobs);
     // ---- stage out ----
     if (WRITE) {
         wave_lds_fence();

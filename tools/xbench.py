@@ -15,6 +15,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("shapes", nargs="*", default=DEFAULT)
 ap.add_argument("--n", type=int, default=20)
 ap.add_argument("--opt", action="append", default=[], help="name=value handle options (moihgp_set_option)")
+ap.add_argument("--warm", type=int, default=3)
+ap.add_argument("--total", action="store_true", help="also queue the pass's NLL total behind every sweep (as bench.py's passes do)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)
 for sh in a.shapes:
@@ -27,11 +29,12 @@ for sh in a.shapes:
     Ty = synth_stream(L, 0, T, dtype, dev, SEED + 1)
     yhat = torch.empty_like(Ty); nll = torch.empty((L,), dtype=torch.float64, device=dev)
     x = torch.zeros((L, bank.d), dtype=dtype, device=dev); xz = torch.zeros_like(x)
-    for _ in range(3):
-        bank.filter(Ty, T=T, x=x, x_start=xz, yhat=yhat, nll=nll)
+    tot = torch.zeros(1, dtype=torch.float64, device=dev) if a.total else None
+    for _ in range(a.warm):
+        bank.filter(Ty, T=T, x=x, x_start=xz, yhat=yhat, nll=nll, nll_total=tot)
     bank.profile_enable(a.n)
     for _ in range(a.n):
-        bank.filter(Ty, T=T, x=x, x_start=xz, yhat=yhat, nll=nll)
+        bank.filter(Ty, T=T, x=x, x_start=xz, yhat=yhat, nll=nll, nll_total=tot)
     t = np.array(bank.profile_read()) * 1e3
     es = 4 if dtype == torch.float32 else 8
     b = 2 * es * L * T
