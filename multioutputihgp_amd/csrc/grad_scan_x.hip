@@ -15,8 +15,12 @@
 // Per segment (all arithmetic fp64, whatever the stream's type):
 //   1. z_j = sum_k g_k y_k, 64-lane scan with the powers of M = AKHA^32  ->  start state x_j of every chunk       (as the filter)
 //   2. replay x over the chunk: v_k, sum v^2; v replaces y in the LDS tile (everything below needs v, not y)
-//   3. r_j = sum_k v_k (HA AKHA^k)^T: what a START sensitivity of the chunk contributes to sum_k v_k HA dx(k), per unit
-//   4. for every parameter p: replay (x, dz) from dz = 0 -- dz is the chunk-LOCAL sensitivity, forced by dA_p x + dK_p v and fed
+//   3. the ADJOINT of the chunk, one backward walk over the innovations, lam_(k-1) = A^T lam_k + HA^T (v_k - K . lam_k) from lam = 0: it gives
+//      r_j = lam_(-1) = sum_k v_k (HA AKHA^k)^T, what a START sensitivity of the chunk contributes to sum_k v_k HA dx(k), per unit, and
+//      w_j = sum_i v_i lam_i, which turns a forcing dK_p v into sum_k v_k HA dz_p(k) = w . dK_p
+//   4a. for every parameter p that does not move A (dA_p = 0: the magnitudes, the noise variance): no replay at all -- the chunk-end dz_p is
+//      the response of the innovations to the table gp_p[k] = AKHA^(CK-1-k) dK_p (gp_table_kernel), and s = -w . dK_p
+//   4b. for every other parameter p (a lengthscale): replay (x, dz) from dz = 0 -- dz is the chunk-LOCAL sensitivity, forced by dA_p x + dK_p v and fed
 //      back through K dv -- collecting s = sum_k v_k dv_k(local); the chunk-end dz are scanned with the SAME powers of M (the
 //      homogeneous part of the recursion is AKHA, whatever p) to the true start sensitivity dx_j of every chunk, and by
 //      linearity  sum_k v_k dv_k = s - r_j . dx_j.  No table of d(AKHA^n)/dp is needed anywhere.
@@ -34,6 +38,7 @@ namespace {
 
 constexpr int kFewGaps = 3;                                          // chunks with a gap per window up to which the window is cut at them (else walked whole)
 constexpr int kGxWaves = 2;                                           // wavefronts per workgroup (LDS: 18.3 KB each)
+constexpr int kGxTables = 9;                                          // slab tables per latent in the table buffer: gp_p, p < P <= 9
 
 template <int D> struct GxLds {
     static constexpr int CK = kChunkX, STRIDE = CK + 2;
@@ -43,29 +48,36 @@ template <int D> struct GxLds {
     double gacc[9];                  // sum over the stream of v dv_p
 };
 
-// hp_k = HA AKHA^k, k < CK, as a slab table [k][i] per latent (step 3 of the sweep): lane j < D holds column j of AKHA and entry j
-// of the running row.  Its own small kernel: the table is wave-uniform data of the sweep, fetched there like the response table.
-template <int D>
-__global__ void __launch_bounds__(64) hp_table_kernel(const double* __restrict__ cb64, double* __restrict__ hp, size_t L) {
+// gp_p[k] = AKHA^(CK-1-k) dK_p, k < CK, per latent and hyper-parameter, as slab tables [P][k][i]: for a parameter that
+// does not move A (dA_p = 0: the magnitudes and the noise variance, matern52ss.h:61-63) the chunk-local sensitivity obeys
+// dz' = AKHA dz + dK_p v, so its value at the chunk's end is the chunk response of the innovations to this table -- exactly as the
+// state's is the response of the observations to g_k = AKHA^(CK-1-k) K.  Lane j < D holds row j of AKHA and entry j of the running vector.
+template <int D, int P>
+__global__ void __launch_bounds__(64) gp_table_kernel(const double* __restrict__ cb64, const double* __restrict__ cbd64, double* __restrict__ hp, size_t L) {
     using Lc = XC<D>;
+    using Ld = XD<D, P>;
+    constexpr int HPN = GxLds<D>::HPN;
     const int lane = threadIdx.x;
     const size_t l = blockIdx.x;
     if (l >= L) return;
     const double* c = cb64 + l * Lc::SIZE;
-    double* out = hp + l * GxLds<D>::HPN;
-    double col[D];
-    const int jc = lane < D ? lane : 0;
+    const double* cd = cbd64 + l * Ld::SIZE;
+    double arow[D];
+    const int jr = lane < D ? lane : 0;
 #pragma unroll
-    for (int i = 0; i < D; i++) col[i] = c[Lc::AKHA + i * D + jc];
-    double h = c[Lc::HA + jc];
-    for (int e = kChunkX * D + lane; e < GxLds<D>::HPN; e += 64) out[e] = 0.0;
+    for (int i = 0; i < D; i++) arow[i] = c[Lc::AKHA + jr * D + i];
+    for (int p = 0; p < P; p++) {
+        double* out = hp + (l * (size_t)(kGxTables) + p) * HPN;
+        for (int e = kChunkX * D + lane; e < HPN; e += 64) out[e] = 0.0;
+        double u = cd[Ld::DK + p * D + jr];
 #pragma unroll 1
-    for (int k = 0; k < kChunkX; k++) {
-        if (lane < D) out[k * D + lane] = h;
-        double hn = 0.0;
+        for (int k = kChunkX - 1; k >= 0; k--) {
+            if (lane < D) out[k * D + lane] = u;
+            double un = 0.0;
 #pragma unroll
-        for (int i = 0; i < D; i++) hn = fma(read_lane(h, i), col[i], hn);
-        h = hn;
+            for (int i = 0; i < D; i++) un = fma(arow[i], read_lane(u, i), un);
+            u = un;
+        }
     }
 }
 
@@ -186,7 +198,7 @@ template <typename TS, int DB, int J, int WRITE>
 __global__ void __launch_bounds__(64 * kGxWaves)
 grad_scan_x_kernel(const TS* __restrict__ Ty, size_t Tpar /* whole chunks */, size_t ld, size_t L, const double* __restrict__ cb64,
                    const double* __restrict__ cbd64, TS* __restrict__ x, TS* __restrict__ dx, TS* __restrict__ yhat, double* __restrict__ nll,
-                   double* __restrict__ grad, int* __restrict__ flags, const double* __restrict__ hpg /* [L][HPN]: hp_table_kernel */) {
+                   double* __restrict__ grad, int* __restrict__ flags, const double* __restrict__ hpg /* [L][kGxTables][HPN]: gp_table_kernel */) {
     constexpr int D = DB * J, P = 2 * J + 1, CK = kChunkX, SEG = 64 * CK, STRIDE = GxLds<D>::STRIDE;
     constexpr int EPV = 16 / (int)sizeof(TS);
     using VS = typename VecOf<TS>::type;
@@ -215,7 +227,7 @@ grad_scan_x_kernel(const TS* __restrict__ Ty, size_t Tpar /* whole chunks */, si
     for (int e = lane; e < (P + 1) * D; e += 64) sm.carry[e] = e < D ? (double)x[l * D + e] : (double)dx[l * P * D + (e - D)];
     if (lane < P) sm.gacc[lane] = 0.0;
     wave_lds_fence();
-    const double* __restrict__ hpl = hpg + l * GxLds<D>::HPN;
+    const double* __restrict__ hpl = hpg + l * (size_t)kGxTables * GxLds<D>::HPN;        // [p]: gp_p
 
     double acc = 0.0;                                                // per lane: sum of v^2
     unsigned nmiss = 0;                                              // lane 0: missing ticks met (segments walked tick by tick)
@@ -230,23 +242,36 @@ grad_scan_x_kernel(const TS* __restrict__ Ty, size_t Tpar /* whole chunks */, si
         bool mine = lane < nc;
         const uptr<double> cu = launder(c);
         // ---- stage in: coalesced 16-byte loads, chunk-major into the padded tile, zeros past the end ----
+        // (eight 16-byte loads per batch, and the lane's addresses recomputed here: the sixteen loads of an fp64 stream hoisted to the top, or
+        //  their loop-invariant offsets and LDS addresses kept live across the segment loop, sat at the kernel's point of highest pressure,
+        //  and its allocation paid for them in AGPR copies inside the replays)
+#pragma unroll 1
+        for (int rb = 0; rb < CK / EPV; rb += 8) {
+            VS raw[8];
+            int lo = lane;
+            asm volatile("" : "+v"(lo));
 #pragma unroll
-        for (int r = 0; r < CK / EPV; r++) {
-            const int e = (r * 64 + lane) * EPV;
-            TS vals[EPV];
+            for (int r = 0; r < 8; r++) {
+                const int e = ((rb + r) * 64 + lo) * EPV;
+                raw[r] = VS{};
+                if (e < n) raw[r] = nt_load(reinterpret_cast<const VS*>(row + t0 + e));
+            }
 #pragma unroll
-            for (int q = 0; q < EPV; q++) vals[q] = TS(0);
-            if (e < n) unpack<TS>(nt_load(reinterpret_cast<const VS*>(row + t0 + e)), vals);
-            double* dst = sm.tile + (e / CK) * STRIDE + (e % CK);
+            for (int r = 0; r < 8; r++) {
+                const int e = ((rb + r) * 64 + lo) * EPV;
+                TS vals[EPV];
+                unpack<TS>(raw[r], vals);
+                double* dst = sm.tile + (e / CK) * STRIDE + (e % CK);
 #pragma unroll
-            for (int q = 0; q < EPV; q += 2) *reinterpret_cast<double2*>(dst + q) = make_double2((double)vals[q], (double)vals[q + 1]);
+                for (int q = 0; q < EPV; q += 2) *reinterpret_cast<double2*>(dst + q) = make_double2((double)vals[q], (double)vals[q + 1]);
+            }
         }
         double ablk[NAB];
 #pragma unroll
         for (int i = 0; i < NAB; i++) ablk[i] = cu[Lc::AB + i];
         wave_lds_fence();
 
-        double xs[D], rr[D];                                          // start state of the lane's chunk; r of step 3
+        double xs[D], rr[D], ww[D];                                   // start state of the lane's chunk; r and w of step 3
         bool walked = false;
         // it = 0: the state itself (steps 1-3); it = p + 1: parameter p (step 4).  One loop so that the scan is instantiated once.
 #pragma unroll 1
@@ -355,8 +380,22 @@ grad_scan_x_kernel(const TS* __restrict__ Ty, size_t Tpar /* whole chunks */, si
 #pragma unroll 1
                     for (int k = 0; k < CK; k += 4) { one_tick(k); one_tick(k + 1); one_tick(k + 2); one_tick(k + 3); }
                 };
-                if (mode < 0) replay_p(std::integral_constant<int, 0>{});
-                else if (mode >= J) replay_p(std::integral_constant<int, J + 1>{});
+                if (mode < 0) {
+                    // dA_p = 0, H dA_p = 0: dz' = AKHA dz + dK_p v.  The chunk-end dz is the response of the innovations (in the tile since step 2)
+                    // to gp_p[k] = AKHA^(CK-1-k) dK_p, and sum_k v_k dv_k(local) = -w . dK_p with the adjoint sum w of step 3: no replay.
+                    bool dummy = false;
+                    chunk_response<D>(launder(hpl + (size_t)p * GxLds<D>::HPN), tile_lane, lane, z, dummy);
+                    double s0 = 0.0, s1 = 0.0;
+                    static_for<D>([&](auto ii) { constexpr int i = decltype(ii)::value; fmac_bc<i>(i % 2 == 0 ? s0 : s1, dkp, ww[i]); });
+                    s = -(s0 + s1);
+                }
+                else if (mode >= J) {
+                    // dA_p with more than one block: not produced by the update kernel (a lengthscale moves one component).  An instantiation of
+                    // the replay for it set this kernel's register allocation without ever running; such a latent goes to the tick-by-tick
+                    // kernel whole instead (nothing of it has been written yet: the carried state lives in LDS until the end).
+                    if (lane == 0) flags[l] = 1;
+                    return;
+                }
                 else static_for<J>([&](auto jj) { if (mode == decltype(jj)::value) replay_p(std::integral_constant<int, decltype(jj)::value + 1>{}); });
             }
             // ---- carry-in on lane 0, then the 64-lane Kogge-Stone scan with the uniform powers of M (as the filter's) ----
@@ -427,11 +466,45 @@ grad_scan_x_kernel(const TS* __restrict__ Ty, size_t Tpar /* whole chunks */, si
 #pragma unroll 1
                 for (int k = 0; k < CK; k += 2) { x_tick(k); x_tick(k + 1); }
                 acc += part;
-                // ---- step 3: r = sum_k v_k hp_k ----
+                // ---- step 3: the adjoint of the chunk, walked BACKWARD over the innovations:
+                //     lam_(k-1) = AKHA^T lam_k + HA^T v_k = A^T lam_k + HA^T (v_k - K . lam_k),   lam_(CK-1) = 0,
+                // i.e. lam_i = sum_(k>i) v_k (HA AKHA^(k-1-i))^T: what a unit forcing at tick i does to sum_k v_k HA dz(k).  Two sums come out of it:
+                //     r = lam_(-1) = sum_k v_k (HA AKHA^k)^T   what a START sensitivity of the chunk contributes (was a response to the hp table), and
+                //     w = sum_i v_i lam_i                      so that a forcing dK_p v (every parameter with dA_p = 0) gives sum_k v_k HA dz(k) = w . dK_p.
+                // A^T is block diagonal like A: 36 + 3 x 12 multiply-adds per tick at d = 12, once for all such parameters.
+                {
+                    double lam[D];
 #pragma unroll
-                for (int i = 0; i < D; i++) rr[i] = 0.0;
-                bool dummy = false;
-                chunk_response<D>(launder(hpl), tile_lane, lane, rr, dummy);
+                    for (int i = 0; i < D; i++) { lam[i] = 0.0; ww[i] = 0.0; }
+                    auto back_tick = [&](const int k) {
+                        const double v = tile_lane[k];
+                        double k0 = 0.0, k1 = 0.0, k2 = 0.0;
+                        static_for<D>([&](auto ii) {
+                            constexpr int i = decltype(ii)::value;
+                            fmac_bc<i>(i % 3 == 0 ? k0 : (i % 3 == 1 ? k1 : k2), kk, lam[i]);
+                        });
+#pragma unroll
+                        for (int i = 0; i < D; i++) ww[i] = fma(v, lam[i], ww[i]);
+                        const double mu = v - ((k0 + k1) + k2);
+                        double ln[D];
+#pragma unroll
+                        for (int j = 0; j < J; j++)
+#pragma unroll
+                            for (int q = 0; q < DB; q++) {                             // (A^T lam)_q of block j = sum_r A[r][q] lam_r
+                                double sl = ablk[j * DB * DB + q] * lam[j * DB];
+#pragma unroll
+                                for (int r = 1; r < DB; r++) sl = fma(ablk[j * DB * DB + r * DB + q], lam[j * DB + r], sl);
+                                ln[j * DB + q] = sl;
+                            }
+                        static_for<D>([&](auto ii) { fmac_bc<decltype(ii)::value>(ln[decltype(ii)::value], ha, mu); });
+#pragma unroll
+                        for (int i = 0; i < D; i++) lam[i] = ln[i];
+                    };
+#pragma unroll 1
+                    for (int k = CK - 1; k >= 0; k -= 2) { back_tick(k); back_tick(k - 1); }
+#pragma unroll
+                    for (int i = 0; i < D; i++) rr[i] = lam[i];
+                }
             } else {
                 // sum_k v_k dv_k over the chunk = s - r . dx_start; all chunks of the segment into the stream's total
                 double tot = s;
@@ -482,15 +555,20 @@ grad_scan_x_kernel(const TS* __restrict__ Ty, size_t Tpar /* whole chunks */, si
             }
           }
             wave_lds_fence();
+#pragma unroll 1
+            for (int rb = 0; rb < CK / EPV; rb += 8) {
+                int lo = lane;
+                asm volatile("" : "+v"(lo));                         // (addresses recomputed here, as in the stage-in)
 #pragma unroll
-            for (int r = 0; r < CK / EPV; r++) {
-                const int e = (r * 64 + lane) * EPV;
-                if (e < n) {
-                    const double* src = sm.tile + (e / CK) * STRIDE + (e % CK);
-                    TS vals[EPV];
+                for (int r = 0; r < 8; r++) {
+                    const int e = ((rb + r) * 64 + lo) * EPV;
+                    if (e < n) {
+                        const double* src = sm.tile + (e / CK) * STRIDE + (e % CK);
+                        TS vals[EPV];
 #pragma unroll
-                    for (int q = 0; q < EPV; q++) vals[q] = (TS)src[q];
-                    nt_store(pack<TS>(vals), reinterpret_cast<VS*>(orow + t0 + e));
+                        for (int q = 0; q < EPV; q++) vals[q] = (TS)src[q];
+                        nt_store(pack<TS>(vals), reinterpret_cast<VS*>(orow + t0 + e));
+                    }
                 }
             }
         }
@@ -517,7 +595,7 @@ template <typename TS, int DB, int J>
 int launch_gsx(const void* Ty, size_t Tpar, size_t ld, size_t L, const double* cb64, const double* cbd64, void* x, void* dx, void* yhat,
                double* nll, double* grad, int* flags, double* hp, hipStream_t stream, int out_mode, int hp_build) {
     dim3 block(64 * kGxWaves), grid((unsigned)((L + kGxWaves - 1) / kGxWaves));
-    if (hp_build) hipLaunchKernelGGL((hp_table_kernel<DB * J>), dim3((unsigned)L), dim3(64), 0, stream, cb64, hp, L);
+    if (hp_build) hipLaunchKernelGGL((gp_table_kernel<DB * J, 2 * J + 1>), dim3((unsigned)L), dim3(64), 0, stream, cb64, cbd64, hp, L);
 #define MOIHGP_GSX_LAUNCH(W_) hipLaunchKernelGGL((grad_scan_x_kernel<TS, DB, J, W_>), grid, block, 0, stream, (const TS*)Ty, Tpar, ld, L, cb64, cbd64, \
                                                  (TS*)x, (TS*)dx, (TS*)yhat, nll, grad, flags, (const double*)hp)
     if (yhat && out_mode == 2) MOIHGP_GSX_LAUNCH(2);
@@ -541,8 +619,11 @@ int launch_grad_scan_x(int kernel, int dtype, const void* Ty, size_t Tpar, size_
     if (base == (DBB == 2 ? 0 : 1) && J == JJ)                                                                                          \
         return dtype == 0 ? launch_gsx<double, DBB, JJ>(Ty, Tpar, ld, L, cb64, cbd64, x, dx, yhat, nll, grad, flags, hp, stream, out_mode, hp_build)  \
                           : launch_gsx<float, DBB, JJ>(Ty, Tpar, ld, L, cb64, cbd64, x, dx, yhat, nll, grad, flags, hp, stream, out_mode, hp_build)
+#ifndef MOIHGP_GSX_ONLY_D12       // (development: the d = 12 kernels alone, for quick resource checks)
     MOIHGP_GSX_CASE(2, 2); MOIHGP_GSX_CASE(2, 3); MOIHGP_GSX_CASE(2, 4);
-    MOIHGP_GSX_CASE(3, 2); MOIHGP_GSX_CASE(3, 3); MOIHGP_GSX_CASE(3, 4);
+    MOIHGP_GSX_CASE(3, 2); MOIHGP_GSX_CASE(3, 3);
+#endif
+    MOIHGP_GSX_CASE(3, 4);
 #undef MOIHGP_GSX_CASE
     set_last_error("stacked kernel id %d is not built", kernel);
     return 1;
