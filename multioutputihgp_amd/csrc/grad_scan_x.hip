@@ -384,7 +384,7 @@ grad_scan_x_kernel(const TS* __restrict__ Ty, size_t Tpar /* whole chunks */, si
                     // dA_p = 0, H dA_p = 0: dz' = AKHA dz + dK_p v.  The chunk-end dz is the response of the innovations (in the tile since step 2)
                     // to gp_p[k] = AKHA^(CK-1-k) dK_p, and sum_k v_k dv_k(local) = -w . dK_p with the adjoint sum w of step 3: no replay.
                     bool dummy = false;
-                    chunk_response<D>(launder(hpl + (size_t)p * GxLds<D>::HPN), tile_lane, lane, z, dummy);
+                    chunk_response<D>(launder(hpl + (size_t)__builtin_amdgcn_readfirstlane(p) * GxLds<D>::HPN), tile_lane, lane, z, dummy);
                     double s0 = 0.0, s1 = 0.0;
                     static_for<D>([&](auto ii) { constexpr int i = decltype(ii)::value; fmac_bc<i>(i % 2 == 0 ? s0 : s1, dkp, ww[i]); });
                     s = -(s0 + s1);
