@@ -6,16 +6,16 @@ out=$1; tag=$2
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 mkdir -p "$out"
-for c in c3 c2 c3f64 c2d6 c5 c4 c1 c3learn c3grad c5grad; do
+for c in c3 c2 c3f64 c2d6 c3d6 c3d6f64 c5 c4 c1 c3learn c3grad c5grad; do
   python3 bench.py --config $c > "$out/${tag}_${c}_bench.json" 2> "$out/${tag}_${c}_bench.err"
   echo "bench $c done"
 done
-for c in c3 c5 c2 c2d6; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_$c/kt" -o out -- python3 bench.py --config $c --steps 50 --warmup 5 --no-cpu --no-cold > "$out/${tag}_${c}_bench_under_rocprof.json" 2> "$out/prof_$c.err"
-  python3 profiles/summarize.py "$out/prof_$c" "$out" "${tag}_$c" $([ $c = c5 -o $c = c2d6 ] && echo filter_x_kernel || echo filter_scan_kernel) > /dev/null
+for c in c3 c5 c2 c2d6 c3d6 c3d6f64; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_$c/kt" -o out -- python3 bench.py --config $c --steps 200 --warmup 150 --no-cpu --no-cold > "$out/${tag}_${c}_bench_under_rocprof.json" 2> "$out/prof_$c.err"
+  python3 profiles/summarize.py "$out/prof_$c" "$out" "${tag}_$c" $([ $c = c3 -o $c = c2 ] && echo filter_scan || echo filter_x) > /dev/null
   echo "rocprof $c done"
 done
-for c in c3 c5 c2 c2d6; do
+for c in c3 c5 c2 c2d6 c3d6 c3d6f64; do
   bash tools/pmc_traffic.sh $c "$out/pmc_$c" > "$out/${tag}_${c}_pmc.json"
   echo "pmc $c done"
 done

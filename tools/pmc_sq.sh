@@ -16,7 +16,7 @@ out = sys.argv[1]
 acc = collections.defaultdict(list)
 for f in glob.glob(f"{out}/g*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "filter_x_kernel" in r["Kernel_Name"] or "filter_scan_kernel" in r["Kernel_Name"]:
+        if "filter_x_" in r["Kernel_Name"] or "filter_scan_kernel" in r["Kernel_Name"]:
             acc[(r["Counter_Name"], r["Dispatch_Id"])].append(float(r["Counter_Value"]))
 per = collections.defaultdict(list)
 for (name, disp), v in acc.items():

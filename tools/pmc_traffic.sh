@@ -17,7 +17,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = sorted(glob.glob(f"{out}/pmc_{c}/**/*counter_collection.csv", recursive=True))[-1]
     groups = collections.defaultdict(list)          # one group per kernel instantiation: a sweep may be several launches (second passes)
     for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] == c and ("filter_x_kernel" in r["Kernel_Name"] or "filter_scan_kernel" in r["Kernel_Name"]):
+        if r["Counter_Name"] == c and ("filter_x_" in r["Kernel_Name"] or "filter_scan_kernel" in r["Kernel_Name"]):
             groups[r["Kernel_Name"]].append(r)
     name, rows = max(groups.items(), key=lambda kv: sum(float(r["Counter_Value"]) for r in kv[1]))     # the dominant one
     v = [float(r["Counter_Value"]) for r in rows]
