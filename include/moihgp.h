@@ -232,6 +232,16 @@ int moihgp_grad_stream(moihgp_gp* gp, int dtype, const void* Ty, size_t T, size_
  * observed ones, and L <= 15040 (the tick's U^T y lives in the workgroup's LDS); otherwise the NaN propagates into Ty[:, t], i.e. the
  * recursion treats the whole tick as missing (use the per-tick ABI for such ticks). */
 int moihgp_project_stream(moihgp_gp* gp, int dtype, const void* Y, size_t T, void* Ty, size_t ld, void* stream);
+/* The same least-squares projection when the latents are split over ranks (one object per rank holding ITS columns of the global orthonormal
+ * factor, moihgp_set_mixing): (U0^T U0)^-1 couples all latents, but by Woodbury only sums over the latent columns cross the shards.
+ *   1. project the stream with the NaNs replaced by zeros (moihgp_project_stream on the zero-filled Y): Ty = S^-1/2 U_r^T y0, column-local;
+ *   2. moihgp_ls_shard_gram:  per affected tick (ticks: DEVICE int32 [n], ascending) this rank's part of [U_miss r | U_miss U_miss^T] into
+ *      packed [n][kmax + kmax^2] doubles (zero padded; kmax = the largest number of missing outputs in one tick, <= 64);
+ *   3. the caller all-reduces (SUM) `packed` over the ranks -- the path's one extra exchange;
+ *   4. moihgp_ls_shard_apply: solves the k x k systems (identical on every rank) and corrects this rank's rows of Ty in place.
+ * Y is the ORIGINAL stream (with its NaNs: they name the missing outputs). */
+int moihgp_ls_shard_gram(moihgp_gp* gp, int dtype, const void* Y, const int* ticks, size_t n, int kmax, const void* Ty, size_t ld, double* packed, void* stream);
+int moihgp_ls_shard_apply(moihgp_gp* gp, int dtype, const void* Y, const int* ticks, size_t n, int kmax, const double* packed, void* Ty, size_t ld, void* stream);
 int moihgp_unproject_stream(moihgp_gp* gp, int dtype, const void* Tyhat, size_t T, size_t ld, void* Yhat, void* stream);
 
 /* ---- the learners' windowed objective as one call (HOST pointers, fp64) -----------------------------

@@ -23,6 +23,7 @@ ADDITIVE_SYMBOLS = [
     "moihgp_project_stream", "moihgp_unproject_stream", "moihgp_stream_sync",
     "moihgp_profile_enable", "moihgp_profile_stride", "moihgp_profile_read", "moihgp_window_set", "moihgp_window_eval", "moihgp_pin_host_buffer",
     "moihgp_update_dev", "moihgp_window_eval_dev", "moihgp_get_params_dev", "moihgp_set_option", "moihgp_release_stream",
+    "moihgp_ls_shard_gram", "moihgp_ls_shard_apply",
 ]
 
 
@@ -124,6 +125,10 @@ def load_library():
     lib.moihgp_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
     lib.moihgp_release_stream.restype = C.c_int
     lib.moihgp_release_stream.argtypes = [C.c_void_p, C.c_void_p]
+    lib.moihgp_ls_shard_gram.restype = C.c_int
+    lib.moihgp_ls_shard_gram.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    lib.moihgp_ls_shard_apply.restype = C.c_int
+    lib.moihgp_ls_shard_apply.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.moihgp_stream_sync.restype = C.c_int
     lib.moihgp_stream_sync.argtypes = [C.c_void_p]
     _LIB = lib

@@ -819,6 +819,22 @@ static int unproject_stream_impl(moihgp_gp* gp, int dtype, const void* Tyhat, si
                                    (hipStream_t)stream);
 }
 
+// Latent shards: the two halves of the least-squares projection of partially observed ticks around the caller's all-reduce (tick.hip)
+int moihgp_ls_shard_gram(moihgp_gp* gp, int dtype, const void* Y, const int* ticks, size_t n, int kmax, const void* Ty, size_t ld, double* packed, void* stream) {
+    return guard_rc([&] {
+        if (!gp || gp->latents_only || (n && (!Y || !ticks || !Ty || !packed))) { set_last_error("ls_shard_gram: needs a full (shard) object and non-null buffers"); return 1; }
+        note_user_stream(gp, (hipStream_t)stream);
+        return launch_ls_shard(0, dtype, Y, gp->M, gp->L, ticks, n, kmax, gp->dU, gp->dsqrtS, gp->dinvsqrtS, packed, const_cast<void*>(Ty), ld, (hipStream_t)stream);
+    });
+}
+int moihgp_ls_shard_apply(moihgp_gp* gp, int dtype, const void* Y, const int* ticks, size_t n, int kmax, const double* packed, void* Ty, size_t ld, void* stream) {
+    return guard_rc([&] {
+        if (!gp || gp->latents_only || (n && (!Y || !ticks || !Ty || !packed))) { set_last_error("ls_shard_apply: needs a full (shard) object and non-null buffers"); return 1; }
+        note_user_stream(gp, (hipStream_t)stream);
+        return launch_ls_shard(1, dtype, Y, gp->M, gp->L, ticks, n, kmax, gp->dU, gp->dsqrtS, gp->dinvsqrtS, const_cast<double*>(packed), Ty, ld, (hipStream_t)stream);
+    });
+}
+
 int moihgp_unproject_stream(moihgp_gp* gp, int dtype, const void* Tyhat, size_t T, size_t ld, void* Yhat, void* stream) {
     return guard_rc([&] { return unproject_stream_impl(gp, dtype, Tyhat, T, ld, Yhat, stream); });
 }

@@ -194,6 +194,10 @@ constexpr size_t ls_project_lds_bytes(size_t L) { return (L + (size_t)kLsMaxMiss
 constexpr bool ls_project_fits(size_t L) { return ls_project_lds_bytes(L) <= 150 * 1024; }
 int launch_project_stream_missing(int dtype, const void* Y, size_t T, size_t M, size_t L, const double* U, const double* invsqrtS, void* Ty, size_t ld,
                                    hipStream_t s);
+// the same with the latents split over ranks: phase 0 = this rank's part of [U_miss r | U_miss U_miss^T] per affected tick (packed [n][kmax + kmax^2]),
+// phase 1 = solve the (all-reduced) k x k systems and correct this rank's rows of Ty.  ticks: device int32 [n], the affected ticks.
+int launch_ls_shard(int phase, int dtype, const void* Y, size_t M, size_t Lr, const int* ticks, size_t n, int kmax, const double* U, const double* sqrtS,
+                    const double* invsqrtS, double* packed, void* Ty, size_t ld, hipStream_t s);
 void launch_ortho_defect(const double* G /* L x L */, size_t L, double* out /* device scalar: max |G - I| */, hipStream_t s);
 void launch_step_tick(const TickArgs& a, const double* x, const double* Ty /*NULL: predict only*/, const double* dx,
                       double* xnew, double* Tyhat, double* dxnew, hipStream_t s);

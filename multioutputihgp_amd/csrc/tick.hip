@@ -410,6 +410,97 @@ __global__ void __launch_bounds__(256) ls_project_kernel(const T* __restrict__ Y
         Ty[l * ld + t] = (T)(invsqrtS[l] * a);
     }
 }
+
+// ---- the same projection with the LATENTS SPLIT OVER RANKS (sharded.py): a pair of kernels around one all-reduce -------------------------
+// (U0^T U0)^-1 couples all latents, but with U^T U = I the Woodbury form needs, from the other shards, only sums over the latent
+// columns:  G = U_miss U_miss^T (k x k) and b = U_miss r (k), r = U^T (y, NaN -> 0).  Kernel 1 (one workgroup per affected tick) forms this
+// rank's part of [b | G] from ITS columns of U and its projected column Ty[:, t] (r_l = sqrt(S_l) Ty[l][t]) into a packed record of
+// kmax + kmax^2 doubles (zero padded); the caller all-reduces the records of all affected ticks at once; kernel 2 solves
+// (I - G) w = b (every rank the same small system) and corrects this rank's rows:  Ty[l][t] += S_l^-1/2 sum_i U[m_i][l] w_i.
+// The missing outputs of a tick are found from the tick's observation vector, in ascending order (the same order on every rank).
+template <typename T>
+__global__ void __launch_bounds__(256) ls_shard_gram_kernel(const T* __restrict__ Y, size_t M, size_t Lr, const int* __restrict__ ticks, int kmax,
+                                                            const double* __restrict__ U /* [M][Lr] this rank's columns */, const double* __restrict__ sqrtS,
+                                                            const T* __restrict__ Ty, size_t ld, double* __restrict__ packed /* [n][kmax + kmax^2] */) {
+    __shared__ int miss[kLsMaxMissing];
+    __shared__ int kcount;
+    const size_t t = (size_t)ticks[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const T* y = Y + t * M;
+    double* rec = packed + (size_t)blockIdx.x * (size_t)(kmax + kmax * kmax);
+    if (tid == 0) kcount = 0;
+    for (int e = tid; e < kmax + kmax * kmax; e += 256) rec[e] = 0.0;
+    __syncthreads();
+    for (size_t m = tid; m < M; m += 256) {
+        const T v = y[m];
+        if (v != v) { const int slot = atomicAdd(&kcount, 1); if (slot < kLsMaxMissing) miss[slot] = (int)m; }
+    }
+    __syncthreads();
+    const int k = kcount < kmax ? kcount : kmax;
+    if (tid == 0) { for (int i = 1; i < k; i++) { const int v = miss[i]; int j = i - 1; while (j >= 0 && miss[j] > v) { miss[j + 1] = miss[j]; j--; } miss[j + 1] = v; } }
+    __syncthreads();
+    // entry (i, j < k) = u_i . u_j, entry (i, k) -> b_i = u_i . r over this rank's columns: one wave per entry, butterfly sum
+    for (int e = wave; e < k * (k + 1); e += 4) {
+        const int i = e / (k + 1), j = e % (k + 1);
+        const double* ui = U + (size_t)miss[i] * Lr;
+        double sacc = 0.0;
+        if (j < k) { const double* uj = U + (size_t)miss[j] * Lr; for (size_t l = lane; l < Lr; l += 64) sacc = fma(ui[l], uj[l], sacc); }
+        else for (size_t l = lane; l < Lr; l += 64) sacc = fma(ui[l], sqrtS[l] * (double)Ty[l * ld + t], sacc);
+        for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o);
+        if (lane == 0) { if (j < k) rec[kmax + i * kmax + j] = sacc; else rec[i] = sacc; }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) ls_shard_apply_kernel(const T* __restrict__ Y, size_t M, size_t Lr, const int* __restrict__ ticks, int kmax,
+                                                             const double* __restrict__ U, const double* __restrict__ invsqrtS,
+                                                             const double* __restrict__ packed /* reduced over the ranks */, T* __restrict__ Ty, size_t ld) {
+    __shared__ int miss[kLsMaxMissing];
+    __shared__ int kcount;
+    __shared__ double Gs[kLsMaxMissing * (kLsMaxMissing + 1)];
+    const size_t t = (size_t)ticks[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const T* y = Y + t * M;
+    const double* rec = packed + (size_t)blockIdx.x * (size_t)(kmax + kmax * kmax);
+    if (tid == 0) kcount = 0;
+    __syncthreads();
+    for (size_t m = tid; m < M; m += 256) {
+        const T v = y[m];
+        if (v != v) { const int slot = atomicAdd(&kcount, 1); if (slot < kLsMaxMissing) miss[slot] = (int)m; }
+    }
+    __syncthreads();
+    const int k = kcount < kmax ? kcount : kmax, kk = k + 1;
+    if (k == 0) return;
+    if (tid == 0) { for (int i = 1; i < k; i++) { const int v = miss[i]; int j = i - 1; while (j >= 0 && miss[j] > v) { miss[j + 1] = miss[j]; j--; } miss[j + 1] = v; } }
+    for (int e = tid; e < k * kk; e += 256) {            // augmented system (I - G | b)
+        const int i = e / kk, j = e % kk;
+        Gs[e] = j < k ? ((i == j ? 1.0 : 0.0) - rec[kmax + i * kmax + j]) : rec[i];
+    }
+    __syncthreads();
+    if (wave == 0) {                                       // symmetric positive definite: elimination without pivoting, lane = row (as ls_project_kernel)
+        for (int p = 0; p < k; p++) {
+            const double piv = Gs[p * kk + p];
+            if (lane > p && lane < k) {
+                const double f = Gs[lane * kk + p] / piv;
+                for (int j = p; j < kk; j++) Gs[lane * kk + j] -= f * Gs[p * kk + j];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (lane == 0) {
+            for (int i = k - 1; i >= 0; i--) {
+                double sacc = Gs[i * kk + k];
+                for (int j = i + 1; j < k; j++) sacc -= Gs[i * kk + j] * Gs[j * kk + k];
+                Gs[i * kk + k] = sacc / Gs[i * kk + i];
+            }
+        }
+    }
+    __syncthreads();
+    for (size_t l = tid; l < Lr; l += 256) {
+        double a = 0.0;
+        for (int i = 0; i < k; i++) a = fma(U[(size_t)miss[i] * Lr + l], Gs[i * kk + k], a);
+        Ty[l * ld + t] = (T)((double)Ty[l * ld + t] + invsqrtS[l] * a);
+    }
+}
 }  // namespace
 
 static inline unsigned nblk(size_t n, unsigned b) { return (unsigned)((n + b - 1) / b); }
@@ -469,6 +560,21 @@ int launch_project_stream_missing(int dtype, const void* Y, size_t T, size_t M, 
     } else {
         if (smem > 48 * 1024) MOIHGP_HIP_FATAL(hipFuncSetAttribute(reinterpret_cast<const void*>(ls_project_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         hipLaunchKernelGGL(ls_project_kernel<float>, dim3((unsigned)T), dim3(256), smem, s, (const float*)Y, T, M, L, U, invsqrtS, (float*)Ty, ld);
+    }
+    MOIHGP_HIP_FATAL(hipGetLastError());
+    return 0;
+}
+
+int launch_ls_shard(int phase, int dtype, const void* Y, size_t M, size_t Lr, const int* ticks, size_t n, int kmax, const double* U, const double* sqrtS,
+                    const double* invsqrtS, double* packed, void* Ty, size_t ld, hipStream_t s) {
+    if (n == 0) return 0;
+    if (kmax < 1 || kmax > kLsMaxMissing) { set_last_error("ls_shard: kmax must be 1 .. %d", kLsMaxMissing); return 1; }
+    if (phase == 0) {
+        if (dtype == 0) hipLaunchKernelGGL(ls_shard_gram_kernel<double>, dim3((unsigned)n), dim3(256), 0, s, (const double*)Y, M, Lr, ticks, kmax, U, sqrtS, (const double*)Ty, ld, packed);
+        else hipLaunchKernelGGL(ls_shard_gram_kernel<float>, dim3((unsigned)n), dim3(256), 0, s, (const float*)Y, M, Lr, ticks, kmax, U, sqrtS, (const float*)Ty, ld, packed);
+    } else {
+        if (dtype == 0) hipLaunchKernelGGL(ls_shard_apply_kernel<double>, dim3((unsigned)n), dim3(256), 0, s, (const double*)Y, M, Lr, ticks, kmax, U, invsqrtS, packed, (double*)Ty, ld);
+        else hipLaunchKernelGGL(ls_shard_apply_kernel<float>, dim3((unsigned)n), dim3(256), 0, s, (const float*)Y, M, Lr, ticks, kmax, U, invsqrtS, packed, (float*)Ty, ld);
     }
     MOIHGP_HIP_FATAL(hipGetLastError());
     return 0;

@@ -132,7 +132,9 @@ def missing_output_correction(U_r, sqrtS_r, Ty_r, missing, allreduce, lmax=None,
         a = r + Um^T (I_k - Um Um^T)^-1 Um r,      r = U^T (y with NaN -> 0).
     r and the correction are column-local; the k x k Gram matrix G = Um Um^T and the k-vector b = Um r are sums over the column shards:
     ONE all-reduce of sum_t (k_t + k_t^2) doubles for all affected ticks of the stream, then every rank solves the same small systems
-    and corrects its own rows.  (The unsharded device path does the same per tick: csrc/tick.hip ls_project_kernel.)
+    and corrects its own rows.  (The unsharded device path does the same per tick: csrc/tick.hip ls_project_kernel; the sharded device
+    path is the kernel pair moihgp_ls_shard_gram / moihgp_ls_shard_apply, which ShardedMOIHGP uses -- this function is their restatement on
+    torch tensors, kept for CPU tensors: the gloo tests of the host logic.)
 
     U_r [M, L_r] fp64: this rank's columns;  sqrtS_r [L_r];  Ty_r [L_r, >= T]: S_r^-1/2 U_r^T y0_t in column t, corrected IN PLACE;
     missing [T, M] bool;  allreduce: tensor -> its sum over the ranks.
@@ -263,10 +265,27 @@ class ShardedMOIHGP:
         if kmax > 64 or self.M - kmax < self.L:
             raise NotImplementedError(f"ShardedMOIHGP.filter: a tick with {kmax} of {self.M} outputs missing (limit: 64, and at least "
                                       f"{self.L} observed) needs the per-tick path")
-        dev = Y.device
-        U = torch.from_numpy(self._full.params[:self.M * self.L].reshape(self.M, self.L)[:, self.lo:self.hi].copy()).to(dev)   # [M, L_r] fp64
-        sqrtS = torch.from_numpy(self.S[self.lo:self.hi] ** 0.5).to(dev)
-        missing_output_correction(U, sqrtS, Ty, missing, self._allreduce, lmax=(self.L + self.world - 1) // self.world)
+        # the correction as a HIP kernel pair around the all-reduce (csrc/tick.hip ls_shard_gram_kernel / ls_shard_apply_kernel; the torch
+        # function above is its CPU restatement, used by the gloo host-logic tests): per affected tick this rank's part of
+        # [U_miss r | U_miss U_miss^T], one all-reduce of all the records, then the k x k solves and the correction of this rank's rows
+        import ctypes as C
+        from ._lib import last_error, load_library
+        lib = load_library()
+        aff = missing.any(dim=1).nonzero().flatten().to(torch.int32)
+        dt = 0 if Y.dtype == torch.float64 else 1
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        rec = kmax + kmax * kmax
+        step = max(1, (1 << 26) // rec)                                   # <= 512 MiB of records at a time; n and kmax are the same on every rank
+        for a in range(0, aff.numel(), step):
+            ticks = aff[a:a + step].contiguous()
+            packed = torch.empty((ticks.numel(), rec), dtype=torch.float64, device=Y.device)
+            if lib.moihgp_ls_shard_gram(self._shard.handle, dt, C.c_void_p(Y.data_ptr()), C.c_void_p(ticks.data_ptr()), ticks.numel(), kmax,
+                                        C.c_void_p(Ty.data_ptr()), Ty.stride(0), C.c_void_p(packed.data_ptr()), stream):
+                raise RuntimeError(last_error(lib) or "moihgp_ls_shard_gram failed")
+            packed = self._allreduce(packed)                              # the path's extra exchange: n (kmax + kmax^2) doubles
+            if lib.moihgp_ls_shard_apply(self._shard.handle, dt, C.c_void_p(Y.data_ptr()), C.c_void_p(ticks.data_ptr()), ticks.numel(), kmax,
+                                         C.c_void_p(packed.data_ptr()), C.c_void_p(Ty.data_ptr()), Ty.stride(0), stream):
+                raise RuntimeError(last_error(lib) or "moihgp_ls_shard_apply failed")
         return Ty
 
     def filter(self, Y: torch.Tensor, scatter: bool = False):
