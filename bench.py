@@ -290,6 +290,39 @@ def learn_row(steps, warmup, cpu=True, windows=(16, 128)):
     return out
 
 
+def loop_row(ticks=3, W=16, threading=True):
+    """BASELINE.json configs[2] as a LOOP: ticks of the online learner at M = L = 4096 (moihgp_online.h:173-187: filter the new observation, then
+    re-fit on the window, <= 5 L-BFGS iterations of <= 20 line-search points each), with theta, its gradient and the optimiser's correction
+    pairs on the device: the Eigen-free C++ learner of include/moihgp_cxx/lbfgsb_dev.hpp (tools/cxx/learner_bench.cpp, built here with g++
+    against libmoihgp.so).  `threading` = the reference's constructor flag: with it off (the reference's default) the value the objective
+    returns lacks the per-latent losses its gradient belongs to (moihgp.h:590 vs :597-607) and the line search exhausts its 20 points."""
+    import subprocess
+    exe = os.path.join(ROOT, "build", "learner_bench")
+    libdir = os.path.join(ROOT, "multioutputihgp_amd", "lib")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    subprocess.run(["g++", "-std=c++14", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "cxx", "learner_bench.cpp"), "-o", exe,
+                    "-L", libdir, "-lmoihgp", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    M = L = 4096
+    r = subprocess.run([exe, str(M), str(L), str(W), str(ticks), "1", "1" if threading else "0"], capture_output=True, text=True, timeout=900)
+    if r.returncode != 0:
+        raise RuntimeError(f"learner_bench failed ({r.returncode}): {r.stderr[-500:]}")
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    sec = d["seconds_per_tick"]
+    ev = d["objective_evaluations_per_tick"]
+    return {
+        "metric": "Kalman steps/sec (M outputs x T ticks) + NLL rel-err vs CPU oracle",
+        "value": L * W * ev / sec, "unit": "Kalman steps/s", "n_gpus": 1, "steps": ticks, "warmup": 1, "ms_per_step": sec * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"C3-loop: ticks of the online learner at M=L=4096, Matern-5/2 (d=3), window W={W}, threading={'on' if threading else 'off'}: step + "
+                               "L-BFGS re-fit (<= 5 iterations x <= 20 line-search points), parameters / gradient / correction pairs device-resident",
+                   "latents_total": L, "outputs": M, "window": W, "gradient_entries": d["num_param"]},
+        "roofline": {"bound": "mfma", "achieved": None, "peak": 78.6, "unit": "TFLOP/s", "frac": None, "traffic": None,
+                     "kernel": "gemm_mfma (polar factor) + window pipeline + vecops", "kernel_ms": None,
+                     "note": "wall time of whole learner ticks; see c3learn for the roofline of one objective evaluation"},
+        "learner": d, "ms_per_objective_evaluation_incl_optimiser": sec * 1e3 / max(ev, 1e-9),
+    }
+
+
 def grad_row(config, steps, warmup, cpu=True):
     """Mode G of SURVEY 8(d) over whole streams: the sensitivity / gradient sweep (ihgp.h:37-57 + :212-222 per tick: step with
     sensitivities, NLL and its gradient w.r.t. the latent's hyper-parameters), resident streams, one GPU.  c3grad: C3's shape
@@ -520,14 +553,14 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=None, help="untimed passes before the timed ones (default: 5 for the headline c3; 150 for the other shapes, whose fp64 "
                     "stacked kernels settle over their first ~100 launches: tools/micro/launch_dist.py)")
-    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS) + ["c1", "c3learn", "c3grad", "c5grad"])
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS) + ["c1", "c3learn", "c3loop", "c3grad", "c5grad"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / parity leg")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold-stream leg (roofline.frac_cold): profiled runs, so that a kernel trace holds the timed launches only")
     ap.add_argument("--no-others", action="store_true", help="skip the other BASELINE configurations that the default line carries in other_configs")
     ap.add_argument("--sync-allreduce", action="store_true", help="N > 1: make every pass wait for its own NLL all-reduce (no overlap with the next sweep)")
     args = ap.parse_args()
     if args.warmup is None:
-        args.warmup = 5 if args.config in ("c3", "c1", "c4", "c3learn") else (150 if args.config in CONFIGS else 5)
+        args.warmup = 5 if args.config in ("c3", "c1", "c4", "c3learn", "c3loop") else (150 if args.config in CONFIGS else 5)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args)             # before anything touches the GPU
@@ -574,6 +607,11 @@ def main():
         return 0
     if args.config in ("c3grad", "c5grad"):
         print(json.dumps(grad_row(args.config, args.steps, args.warmup, cpu=not args.no_cpu)), flush=True)
+        return 0
+    if args.config == "c3loop":
+        out = loop_row(ticks=max(1, min(args.steps, 10)), threading=True)
+        out["threading_off"] = loop_row(ticks=max(1, min(args.steps, 3)), threading=False)["learner"]
+        print(json.dumps(out), flush=True)
         return 0
 
     Lg_per, T, dtype, kernel, desc = CONFIGS[args.config]
@@ -713,6 +751,14 @@ def main():
                                          "host_path_evaluation_ms": lr["roofline"]["host_path_evaluation_ms"], "note": lr["roofline"]["note"]}
                 except Exception as e:             # (a context line: never let it take the headline down)
                     others["c3learn"] = {"error": str(e)}
+                try:
+                    lo = loop_row(ticks=3, threading=True)
+                    others["c3loop"] = {"workload": lo["config"]["workload"], "dtype": "f64", "ms_per_step": lo["ms_per_step"], "value": lo["value"],
+                                        "objective_evaluations_per_tick": lo["learner"]["objective_evaluations_per_tick"],
+                                        "lbfgs_iterations_per_tick": lo["learner"]["lbfgs_iterations_per_tick"],
+                                        "ms_per_objective_evaluation_incl_optimiser": lo["ms_per_objective_evaluation_incl_optimiser"]}
+                except Exception as e:
+                    others["c3loop"] = {"error": str(e)}
                 out["other_configs"] = others
             if nslab > 1:
                 yhat = torch.cat(yhat_slabs, dim=1)

@@ -277,6 +277,36 @@ int moihgp_window_eval_dev(moihgp_gp* gp, const double* x_dev, const double* dx_
 /* getParams (moihgp.h:721-738) into a DEVICE array [num_param]. */
 int moihgp_get_params_dev(moihgp_gp* gp, double* params_dev);
 
+/* ---- device vectors: what a bound-constrained L-BFGS needs to keep theta, the gradient and its correction pairs on the device ---------
+ * (include/moihgp_cxx/lbfgsb_dev.hpp is such an optimiser; with moihgp_update_dev / moihgp_window_eval_dev one iteration of the learners'
+ * loop, moihgp_online.h:40-72 + LBFGSB.h:117-241, then moves no parameter-sized vector across PCIe).  fp64, DEVICE pointers; a context owns
+ * a stream, the scratch of the reductions and a page-locked result word.  Element-wise entries are asynchronous on the context's stream;
+ * the reductions (dot, proj_step, proj_grad_norm) are deterministic (fixed grid, fixed order) and return their scalar after
+ * synchronising it.  mask (unsigned char [n], may be NULL): entries whose byte is 0 are skipped (the free-variable set of the active-set
+ * method).  Return codes as for the other additive entries. */
+typedef struct moihgp_dvec_ctx moihgp_dvec_ctx;
+moihgp_dvec_ctx* moihgp_dvec_ctx_new(void);
+void    moihgp_dvec_ctx_del(moihgp_dvec_ctx* c);
+double* moihgp_dvec_alloc(size_t n);                                  /* n doubles of device memory (NULL on failure) */
+unsigned char* moihgp_dvec_alloc_mask(size_t n);
+void    moihgp_dvec_free(void* p);
+int moihgp_dvec_upload(moihgp_dvec_ctx* c, double* dst_dev, const double* src_host, size_t n);     /* synchronous */
+int moihgp_dvec_download(moihgp_dvec_ctx* c, double* dst_host, const double* src_dev, size_t n);   /* synchronous */
+int moihgp_dvec_copy(moihgp_dvec_ctx* c, double* dst_dev, const double* src_dev, size_t n);
+int moihgp_dvec_sync(moihgp_dvec_ctx* c);
+int moihgp_dvec_dot(moihgp_dvec_ctx* c, size_t n, const double* a, const double* b, const unsigned char* mask, double* result);
+int moihgp_dvec_axpy(moihgp_dvec_ctx* c, size_t n, double alpha, const double* x, double* y, const unsigned char* mask);     /* y += alpha x */
+int moihgp_dvec_scale(moihgp_dvec_ctx* c, size_t n, double alpha, const double* x, double* y, const unsigned char* mask);    /* y = alpha x (0 where masked out) */
+int moihgp_dvec_sub(moihgp_dvec_ctx* c, size_t n, const double* a, const double* b, double* out);                           /* out = a - b */
+int moihgp_dvec_clamp(moihgp_dvec_ctx* c, size_t n, double* x, const double* lb, const double* ub);
+/* free_var[i] = 0 where x sits at a bound with the gradient pointing out of the box, or lb == ub; 1 elsewhere */
+int moihgp_dvec_active_set(moihgp_dvec_ctx* c, size_t n, const double* x, const double* g, const double* lb, const double* ub, unsigned char* free_var);
+/* xt = clamp(xp + step drt, lb, ub);  *dec = sum gradp (xt - xp)   (projected search point and its Armijo decrease) */
+int moihgp_dvec_proj_step(moihgp_dvec_ctx* c, size_t n, const double* xp, const double* drt, double step, const double* lb, const double* ub, const double* gradp,
+                          double* xt, double* dec);
+/* max |clamp(x - g, lb, ub) - x|   (projected-gradient norm, LBFGSB.h:64-67) */
+int moihgp_dvec_proj_grad_norm(moihgp_dvec_ctx* c, size_t n, const double* x, const double* g, const double* lb, const double* ub, double* result);
+
 /* Kernel-exact timing of moihgp_filter_stream launches (bench / diagnosis).  After
  * moihgp_profile_enable(gp, n) the next n launches on this handle are bracketed by a HIP event pair
  * attached to the dispatch itself (hipExtLaunchKernel), not to the stream.  The pair brackets the sweep's FIRST (dominant) kernel --

@@ -157,6 +157,8 @@ public:
     }
 
     Vector getParams() { return _moihgp->getParams(); }
+    // (not in the reference: start from given parameters instead of the constructor's random draw -- tests, warm starts)
+    void setParams(const Vector& p) { _moihgp->update(p); _params = _moihgp->getParams(); _obj->oldparams = _params; }
     size_t getNumParam() { return _num_param; }
     size_t getNumOutput() { return _num_output; }
     size_t getNumLatent() { return _num_latent; }

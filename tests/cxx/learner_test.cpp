@@ -6,6 +6,9 @@
 //              -> MOIHGPOnlineLearning::step per tick: yhat, then after the last tick the parameters, f(old), f(new)
 //   regression M L kern dt nticks seed | params0[np] | Y[nticks][M]
 //              -> RegressionObjective at params0 (apply_params), then predict()
+//   online_dev M L kern dt gamma W nticks | params0[np] | Y[nticks][M]
+//              -> the host learner and the device-vector learner (lbfgsb_dev.hpp) side by side from the same parameters: per tick both yhat,
+//                 then both parameter vectors, iteration counts and final objective values
 //   eigenlike  M L kern dt | params0[np] | y[M] ma[M]
 //              -> the reference learner's call pattern with an Eigen-like vector library (tests/cxx/eigen_like.hpp)
 #include <cstdio>
@@ -13,6 +16,7 @@
 #include <vector>
 #include "moihgp_cxx/moihgp_online.hpp"
 #include "moihgp_cxx/moihgp_regression.hpp"
+#include "moihgp_cxx/lbfgsb_dev.hpp"
 #include "eigen_like.hpp"
 
 using Vec = std::vector<double>;
@@ -54,6 +58,24 @@ template <class SS> int online_mode(size_t M, size_t L, double dt) {
     Vec pold = learner.objective().oldparams;
     double fold = learner.objective()(pold, g), fnew = learner.objective()(pnew, g);
     printf("%.17g %.17g\n", fold, fnew);
+    return 0;
+}
+template <class SS> int online_dev_mode(size_t M, size_t L, double dt) {
+    double gamma; size_t W; int nt;
+    if (scanf("%lf %zu %d", &gamma, &W, &nt) != 3) return 2;
+    moihgp::MOIHGPOnlineLearning<SS> host(dt, M, L, gamma, W, false);
+    moihgp::MOIHGPOnlineLearningDev<SS> dev(dt, M, L, gamma, W, false);
+    Vec p0(host.getNumParam()), y(M);
+    if (!rd(p0)) return 2;
+    host.setParams(p0); dev.setParams(p0);
+    for (int t = 0; t < nt; t++) {
+        if (!rd(y)) return 2;
+        Vec a = host.step(y), b = dev.step(y);
+        pr(a); pr(b);
+    }
+    Vec ph = host.getParams(), pd = dev.getParams();
+    pr(ph); pr(pd);
+    printf("%d %.17g\n", dev.last_iterations, dev.last_fx);
     return 0;
 }
 template <class SS> int regression_mode(size_t M, size_t L, double dt) {
@@ -113,6 +135,7 @@ int main() {
 #define DISPATCH(fn) (kern == 0 ? fn<moihgp::Matern32StateSpace>(M, L, dt) : fn<moihgp::Matern52StateSpace>(M, L, dt))
         if (!strcmp(mode, "objective")) return DISPATCH(objective_mode);
         if (!strcmp(mode, "online")) return DISPATCH(online_mode);
+        if (!strcmp(mode, "online_dev")) return DISPATCH(online_dev_mode);
         if (!strcmp(mode, "regression")) return DISPATCH(regression_mode);
         if (!strcmp(mode, "eigenlike")) return DISPATCH(eigenlike_mode);
     } catch (const std::exception& e) { fprintf(stderr, "%s\n", e.what()); return 3; }

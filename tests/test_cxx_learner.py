@@ -215,3 +215,23 @@ def test_cxx_reference_call_pattern_with_eigen_like_vectors(hip_built):
     loss, g = ref.negLogLikelihood(x1, y - ma, dx0)
     assert abs(float(out[0]) - loss) < 1e-9 * abs(loss)
     assert rel_err(_arr(out[1]), yh + ma) < 1e-9 and rel_err(_arr(out[2]), g) < 1e-8 and rel_err(_arr(out[3]), ref.params) < 1e-10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kern,M,L,W,nt", [(0, 6, 3, 4, 8), (1, 9, 5, 3, 6)])
+def test_cxx_device_vector_learner_follows_the_host_learner(hip_built, kern, M, L, W, nt):
+    """include/moihgp_cxx/lbfgsb_dev.hpp: the same projected L-BFGS with theta, the gradient and the correction pairs on the device
+    (moihgp_dvec_* kernels; objective through moihgp_update_dev / moihgp_window_eval_dev).  Same algorithm as the host learner, so from the
+    same parameters the two must produce the same predictions and parameters up to the rounding order of the reductions."""
+    exe = _cxx("learner_test", hip_built)
+    rng = np.random.default_rng(17 + kern)
+    p0 = _params(M, L, rng)
+    t = np.arange(nt)[:, None]
+    Y = np.sin(0.3 * t + np.arange(M)[None, :]) + 0.05 * rng.standard_normal((nt, M))
+    out = _lines(exe, f"online_dev {M} {L} {kern} 0.1 0.9 {W} {nt}\n{_fmt(p0)}\n" + "\n".join(_fmt(y) for y in Y) + "\n")
+    for k in range(nt):
+        a, b = _arr(out[2 * k]), _arr(out[2 * k + 1])
+        assert np.all(np.isfinite(a)) and rel_err(b, a) < 1e-7, k
+    ph, pd = _arr(out[2 * nt]), _arr(out[2 * nt + 1])
+    assert rel_err(pd, ph) < 1e-6
+    assert np.abs(ph - p0).max() > 1e-4                                # the learner moved
