@@ -132,6 +132,21 @@ def load_library():
     lib.moihgp_ls_shard_gram.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     lib.moihgp_ls_shard_apply.restype = C.c_int
     lib.moihgp_ls_shard_apply.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.moihgp_dvec_ctx_new.restype = C.c_void_p
+    lib.moihgp_dvec_ctx_del.restype = None; lib.moihgp_dvec_ctx_del.argtypes = [C.c_void_p]
+    lib.moihgp_dvec_sync.restype = C.c_int; lib.moihgp_dvec_sync.argtypes = [C.c_void_p]
+    lib.moihgp_dvec_dot.restype = C.c_int
+    lib.moihgp_dvec_dot.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+    lib.moihgp_dvec_axpy.restype = C.c_int
+    lib.moihgp_dvec_axpy.argtypes = [C.c_void_p, C.c_size_t, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.moihgp_dvec_scale.restype = C.c_int
+    lib.moihgp_dvec_scale.argtypes = [C.c_void_p, C.c_size_t, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.moihgp_dvec_active_set.restype = C.c_int
+    lib.moihgp_dvec_active_set.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.moihgp_dvec_proj_step.restype = C.c_int
+    lib.moihgp_dvec_proj_step.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+    lib.moihgp_dvec_proj_grad_norm.restype = C.c_int
+    lib.moihgp_dvec_proj_grad_norm.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
     lib.moihgp_stream_sync.restype = C.c_int
     lib.moihgp_stream_sync.argtypes = [C.c_void_p]
     _LIB = lib

@@ -1499,3 +1499,87 @@ def test_project_stream_missing_outputs_beyond_the_least_squares_path(env):
     y7 = Y[7].copy(); obs = ~np.isnan(y7)
     a = np.linalg.solve(Q[obs].T @ Q[obs], Q[obs].T @ y7[obs])
     assert rel_err(Ty3[:, 7].cpu().numpy(), a) < 1e-10
+
+
+# ------------------------------------------------------------------------------------------ round 3: options, stream release, device vectors
+def test_options_and_stream_release(env):
+    """moihgp_set_option: per-handle hooks (nothing reads the environment per launch); the kernel tiling probes are not in the shipped library.
+    moihgp_release_stream: a caller may destroy a stream that carried batched work once it has handed it back."""
+    import ctypes as C
+    lib = env["lib"]
+    rng = np.random.default_rng(5)
+    L, T = 8, 3000
+    prm = synth_params(L, rng)
+    bank = env["streams"].LatentBank(0.1, prm, kernel="Matern52ss")
+    assert lib.moihgp_set_option(bank._h, b"filter_split", 3) == 0 and lib.moihgp_set_option(bank._h, b"filter_split", 0) == 0
+    assert lib.moihgp_set_option(bank._h, b"no_such_option", 1) == 1
+    assert lib.moihgp_set_option(bank._h, b"filter_variant", 0) == 0
+    assert lib.moihgp_set_option(bank._h, b"filter_variant", 9) == 1          # the staging-only probe (no arithmetic) exists in tuning builds only
+    assert lib.moihgp_set_option(bank._h, b"filter_split", 1000) == 1
+    Ty = synth(L, T, rng)
+    o = env["cref"].filter_stream(env["cref"].ihgp_array("Matern52", 0.1, prm), Ty)
+    side = torch.cuda.Stream()
+    Tyd = to_dev(Ty, torch.float64)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        yhat, xT, nll = bank.filter(Tyd, T=T, stream=side)
+    assert lib.moihgp_release_stream(bank._h, C.c_void_p(side.cuda_stream)) == 0
+    bank.update(prm * 1.1)                                                     # ordered behind the sweep on the released stream; must not touch it again
+    side.synchronize()
+    assert rel_err_rows(yhat[:, :T].cpu().numpy(), o["yhat"]) < FP64_TIGHT
+    del side
+    prm2 = prm * 1.1
+    o2 = env["cref"].filter_stream(env["cref"].ihgp_array("Matern52", 0.1, prm2), Ty)
+    y2, _, _ = bank.filter(Tyd, T=T)
+    torch.cuda.synchronize()
+    assert rel_err_rows(y2[:, :T].cpu().numpy(), o2["yhat"]) < FP64_TIGHT
+
+
+def test_device_vector_kernels_vs_numpy(env):
+    """csrc/vecops.hip (moihgp_dvec_*): the vector kernels of the device-resident optimiser against numpy, sizes that span one and many
+    reduction workgroups, with and without the free-variable mask."""
+    import ctypes as C
+    lib = env["lib"]
+    dp = C.POINTER(C.c_double)
+    lib.moihgp_dvec_ctx_new.restype = C.c_void_p
+    lib.moihgp_dvec_ctx_del.argtypes = [C.c_void_p]
+    ctx = lib.moihgp_dvec_ctx_new()
+    assert ctx
+    rng = np.random.default_rng(2)
+    for n in (1, 257, 70001, 1 << 20):
+        a, b, g = rng.standard_normal(n), rng.standard_normal(n), rng.standard_normal(n)
+        lb, ub = -0.5 * np.ones(n), 0.7 * np.ones(n)
+        lb[::7] = ub[::7] = 0.1                                                # fixed variables
+        x = np.clip(rng.standard_normal(n), lb, ub)
+        mask = (rng.random(n) < 0.6).astype(np.uint8)
+        ta, tb, tg, tx, tl, tu = (torch.from_numpy(v).cuda() for v in (a, b, g, x, lb, ub))
+        tm = torch.from_numpy(mask).cuda()
+        P = lambda t: C.c_void_p(t.data_ptr())
+        r = C.c_double()
+        assert lib.moihgp_dvec_dot(C.c_void_p(ctx), C.c_size_t(n), P(ta), P(tb), None, C.byref(r)) == 0
+        assert abs(r.value - a @ b) <= 1e-12 * max(1.0, np.abs(a * b).sum())
+        assert lib.moihgp_dvec_dot(C.c_void_p(ctx), C.c_size_t(n), P(ta), P(tb), P(tm), C.byref(r)) == 0
+        assert abs(r.value - (a * b)[mask > 0].sum()) <= 1e-12 * max(1.0, np.abs(a * b).sum())
+        r1 = C.c_double(); lib.moihgp_dvec_dot(C.c_void_p(ctx), C.c_size_t(n), P(ta), P(tb), P(tm), C.byref(r1))
+        assert r1.value == r.value                                              # deterministic
+        free = torch.empty(n, dtype=torch.uint8, device="cuda")
+        assert lib.moihgp_dvec_active_set(C.c_void_p(ctx), C.c_size_t(n), P(tx), P(tg), P(tl), P(tu), P(free)) == 0
+        lib.moihgp_dvec_sync(C.c_void_p(ctx))
+        want_free = ~(((x <= lb) & (g > 0)) | ((x >= ub) & (g < 0)) | (lb == ub))
+        assert np.array_equal(free.cpu().numpy().astype(bool), want_free)
+        xt = torch.empty(n, dtype=torch.float64, device="cuda")
+        dec = C.c_double()
+        assert lib.moihgp_dvec_proj_step(C.c_void_p(ctx), C.c_size_t(n), P(tx), P(ta), C.c_double(0.3), P(tl), P(tu), P(tg), P(xt), C.byref(dec)) == 0
+        want_xt = np.clip(x + 0.3 * a, lb, ub)
+        assert np.abs(xt.cpu().numpy() - want_xt).max() < 1e-14
+        assert abs(dec.value - g @ (want_xt - x)) <= 1e-12 * max(1.0, np.abs(g * (want_xt - x)).sum())
+        assert lib.moihgp_dvec_proj_grad_norm(C.c_void_p(ctx), C.c_size_t(n), P(tx), P(tg), P(tl), P(tu), C.byref(r)) == 0
+        assert abs(r.value - np.abs(np.clip(x - g, lb, ub) - x).max()) < 1e-15
+        y = tb.clone()
+        assert lib.moihgp_dvec_axpy(C.c_void_p(ctx), C.c_size_t(n), C.c_double(-1.5), P(ta), P(y), P(tm)) == 0
+        lib.moihgp_dvec_sync(C.c_void_p(ctx))
+        assert np.allclose(y.cpu().numpy(), np.where(mask > 0, b - 1.5 * a, b), rtol=0, atol=1e-14)      # (fused multiply-add on the device)
+        assert lib.moihgp_dvec_scale(C.c_void_p(ctx), C.c_size_t(n), C.c_double(2.0), P(ta), P(y), P(tm)) == 0
+        lib.moihgp_dvec_sync(C.c_void_p(ctx))
+        assert np.array_equal(y.cpu().numpy(), np.where(mask > 0, 2.0 * a, 0.0))
+    lib.moihgp_dvec_ctx_del(C.c_void_p(ctx))
