@@ -1017,6 +1017,15 @@ def test_stacked_time_split_matches_unsplit(env, kern, dtype, monkeypatch):
         d = ((y2[:, :T] - y1[:, :T])[ok]).abs().max().item() / y1[:, :T][ok].abs().max().item()
         assert d < tol, (ns, d)
         assert rel_err(x2.cpu().numpy(), x1.cpu().numpy()) < tol and rel_err(n2.cpu().numpy(), n1.cpu().numpy()) < tol
+        # the other output combinations (their own kernel instantiations): state only, NLL only, means only
+        _, x3, _ = bank.filter(Tyd, T=T, x=x0.clone(), want_yhat=False, want_nll=False)
+        _, x4, n4 = bank.filter(Tyd, T=T, x=x0.clone(), want_yhat=False)
+        y5, x5, _ = bank.filter(Tyd, T=T, x=x0.clone(), want_nll=False)
+        torch.cuda.synchronize()
+        for xx in (x3, x4, x5):
+            assert rel_err(xx.cpu().numpy(), x1.cpu().numpy()) < tol
+        assert rel_err(n4.cpu().numpy(), n1.cpu().numpy()) < tol
+        assert ((y5[:, :T] - y1[:, :T])[ok]).abs().max().item() / y1[:, :T][ok].abs().max().item() < tol
     o = env["cref"].filter_stream(env["cref"].ihgp_array(kern, 0.1, prm), Ty, x0=x0.double().cpu().numpy(), nthreads=4)
     tol = FP64_TIGHT if dtype == torch.float64 else FP32_TOL
     tame = np.nan_to_num(np.abs(o["yhat"]), nan=0.0).max(axis=1) < 1e6     # (the slow latent may be unstable under the literal DARE)
