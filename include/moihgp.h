@@ -269,7 +269,9 @@ int moihgp_window_eval(moihgp_gp* gp, const double* x, const double* dx, double*
  * moihgp.h:93); x, dx, xnew, dxnew, loss are DEVICE arrays / a DEVICE scalar.  moihgp_update_dev == gpXX_update (moihgp.h:431-457; the
  * small tail S | sigma | per-latent values is mirrored to the host for getParams, the mixing is not copied until somebody asks);
  * moihgp_window_eval_dev == moihgp_window_eval on the window moihgp_window_set installed.  Both run on the handle's own stream and
- * return when the results are complete (like their host forms), so the caller's streams need no extra ordering.
+ * return when the results are complete (like their host forms), so the caller's streams need no extra ordering AFTER the call.  The
+ * input arrays must be complete when the call is made: synchronise (or otherwise finish) the stream that produced them first -- the
+ * handle's stream does not wait for caller streams it has never seen.
  * Same values as the host forms, bit for bit (same kernels). */
 int moihgp_update_dev(moihgp_gp* gp, const double* params_dev);
 int moihgp_window_eval_dev(moihgp_gp* gp, const double* x_dev, const double* dx_dev, double* loss_dev, double* grad_dev,
