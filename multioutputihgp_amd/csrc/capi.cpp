@@ -84,6 +84,8 @@ struct moihgp_gp {
     int polar_its = 0;         // Newton-Schulz steps of the last device polar factor (0: single-workgroup kernel / none yet)
     double* dhp = nullptr;     // [L][gradx_hp_len(d)] HA AKHA^k rows of the stacked models' time-parallel gradient sweep (on first use)
     double* dxscratch = nullptr; // stacked kernels, few latents: per-slice NLL partials
+    double* dtp64 = nullptr;     // stacked kernels, fewer than 1024 latents: scan powers of the chunk-templated team kernel (launch_team_powers), per update
+    float* dtp32 = nullptr;
     double* cbd64 = nullptr;     // stacked kernels: sensitivity blocks (XD), fp64; filled once somebody asks for gradients
     bool sens_wanted = false, sens_valid = false;
     bool U_host_stale = false; // the device holds a newer U than the host mirror (fetched on getParams)
@@ -112,7 +114,7 @@ struct moihgp_gp {
 
 static void gp_free(moihgp_gp* g) {
     if (!g) return;
-    void* ptrs[] = {g->dU, g->dS, g->dsqrtS, g->dinvsqrtS, g->dsigma, g->dparams, g->cb64, g->cb32, g->dx, g->dpart, g->dTy, g->dUty, g->dTyhat, g->dloss, g->dgrad, g->dscratch, g->dwork, g->dpolar, g->dfallback, g->dwin, g->dunstable, g->dxscratch, g->cbd64, g->dU32, g->dhp, g->dlink, g->dwinmiss};
+    void* ptrs[] = {g->dU, g->dS, g->dsqrtS, g->dinvsqrtS, g->dsigma, g->dparams, g->cb64, g->cb32, g->dx, g->dpart, g->dTy, g->dUty, g->dTyhat, g->dloss, g->dgrad, g->dscratch, g->dwork, g->dpolar, g->dfallback, g->dwin, g->dunstable, g->dxscratch, g->cbd64, g->dU32, g->dhp, g->dlink, g->dwinmiss, g->dtp64, g->dtp32};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (void* p : g->pinned) (void)hipHostUnregister(p);
@@ -168,6 +170,10 @@ static void run_ihgp_update(moihgp_gp* g) {
         // the sensitivities cost nine more 100-iteration Lyapunov solves per latent at d = 12: only for handles that use them
         launch_stack_update(g->kernel, g->dt, g->dparams, g->L, g->cb64, g->cb32, g->sens_wanted ? g->cbd64 : nullptr, g->dunstable, g->stream);
         g->sens_valid = g->sens_wanted;
+        if (g->L < 1024) {
+            if (!g->dtp64) { g->dtp64 = dev_alloc<double>(g->L * team_powers_elems(g->d)); g->dtp32 = dev_alloc<float>(g->L * team_powers_elems(g->d)); }
+            launch_team_powers(g->kernel, g->cb64, g->L, g->dtp64, g->dtp32, g->stream);
+        }
     }
     else launch_ihgp_update(g->kernel, g->d, g->dt, g->dparams, g->L, g->cb64, g->cb32, g->dunstable, g->stream);
     MOIHGP_HIP_FATAL(hipMemcpyAsync(g->n_unstable, g->dunstable, 2 * sizeof(int), hipMemcpyDeviceToHost, g->stream));
@@ -686,7 +692,7 @@ static int filter_stream_io_impl(moihgp_gp* gp, int dtype, const void* Ty, size_
         if (gp->L >= 1024 && !gp->dlink) gp->dlink = dev_alloc<double>(gp->L * 144);     // hand-over records of the second (broken-link) pass
         int rc = launch_filter_stream_x(gp->kernel, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cb32, x_in, x, yhat, nll, (hipStream_t)stream, e0, e1,
                                         gp->dxscratch, slen, gp->opt_filter_split /* test hook: 1 = off, n = slices */, ld_out, gp->L >= 1024 ? gp->dfallback : nullptr, gp->dlink, nll ? nll_total : nullptr,
-                                        gp->opt_filter_maxlinks, gp->opt_filter_team);
+                                        gp->opt_filter_maxlinks, gp->opt_filter_team, gp->dtp64, gp->dtp32);
         return rc;
     }
     // time split across the wavefronts of a workgroup when there are too few latents to fill the chip
@@ -968,7 +974,7 @@ int moihgp_set_option(moihgp_gp* gp, const char* name, long value) {
     if (!gp || !name) { set_last_error("set_option: null argument"); return 1; }
     const std::string n(name);
     if (n == "filter_split") { if (value < 0 || value > 64) { set_last_error("filter_split: 0 (automatic), 1 (off) or a slice count"); return 1; } gp->opt_filter_split = (int)value; return 0; }
-    if (n == "filter_team") { if (value < -1 || value > 1) { set_last_error("filter_team: -1 (automatic), 0 (never), 1 (whenever the stream fits)"); return 1; } gp->opt_filter_team = (int)value; return 0; }
+    if (n == "filter_team") { if (value < -1 || value > 2) { set_last_error("filter_team: -1 (automatic), 0 (never), 1 (whenever the stream fits), 2 (the 32-tick-chunk form only)"); return 1; } gp->opt_filter_team = (int)value; return 0; }
     if (n == "filter_maxlinks") { if (value < -1 || value > 64) { set_last_error("filter_maxlinks: -1 (automatic) .. 64"); return 1; } gp->opt_filter_maxlinks = (int)value; return 0; }
     if (n == "filter_variant") {
 #ifdef MOIHGP_TUNING

@@ -126,12 +126,16 @@ void launch_ihgp_update(int kernel, int d, double dt, const double* params_dev, 
 // params_dev [n][2J+1] = (magnitude_j, lengthscale_j) x J, noise.
 void launch_stack_update(int kernel, double dt, const double* params_dev, size_t n, double* cb64, float* cb32,
                          double* cbd64 /* [n] sensitivity blocks XD, or NULL to skip them */, int* n_unstable, hipStream_t stream);
+// recursion_x.hip: scan powers of the chunk-templated team kernel (few latents), [L][5][team_powers_elems(d)] in both precisions; after every launch_stack_update
+constexpr size_t team_powers_elems(int d) { return 5 * (size_t)(7 * ((d * d + 15) / 16 * 16) + 16); }
+void launch_team_powers(int kernel, const double* cb64, size_t L, double* tp64, float* tp32, hipStream_t stream);
 int launch_filter_stream_x(int kernel, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* cb64, const float* cb32,
                            const void* xin, void* x, void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
                            double* scratch = nullptr /* [scratch_len] per-slice NLL partials of the time split */, size_t scratch_len = 0,
                            int force_slices = 0 /* tuning / test hook: 1 = no split, n > 1 = n slices */, size_t ld_out = 0 /* row stride of yhat; 0 = ld */,
                            int* link_flags = nullptr /* [L] */, double* link_state = nullptr /* [L][144] */, double* total = nullptr /* sum of nll[] */,
-                           int max_links = -1 /* -1: automatic */, int team_mode = -1 /* few latents: -1 automatic, 0 never, 1 always use the team kernel */
+                           int max_links = -1 /* -1: automatic */, int team_mode = -1 /* few latents: -1 automatic, 0 never, 1 always use a team kernel, 2 the 32-tick one */,
+                           const double* tp64 = nullptr, const float* tp32 = nullptr /* launch_team_powers' tables, or NULL: no chunk-templated team kernel */
                            /* scratch; with both (L >= 1024): segments with few gaps are handled as broken links by a second pass instead of
                               being walked tick by tick */);
 

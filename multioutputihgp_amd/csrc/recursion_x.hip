@@ -143,18 +143,19 @@ __device__ inline void replay_dpp(const T (&a)[J * DB * DB], const T& ha, const 
 // "is this the stream's last tick" test (five scalar instructions and a branch per tick: a lone wave issues one instruction of any kind
 // per four cycles, so they cost as much as vector ones); its carry-out is lane 63's final state.  The team kernel asks for it; the
 // many-latent kernel keeps the single loop (a second copy took part in its register allocation).
-template <typename T, int DB, int J, bool WRITE, bool NLL, bool FULLFAST = false>
+template <typename T, int DB, int J, bool WRITE, bool NLL, bool FULLFAST = false, int CKR = kChunkX /* ticks per lane */>
 __device__ inline void replay(const ReplayConst<T, DB, J>& rc, T* tile_lane, T* carry, int lane, int n, int head,
                               T (&xs)[DB * J], T (&xc)[DB * J], double& acc, unsigned& nobs) {
     using RC = ReplayConst<T, DB, J>;
     using V = typename VecOf<T>::type;
-    constexpr int D = DB * J, EPV = 16 / sizeof(T), NG = kChunkX / EPV;
+    constexpr int D = DB * J, EPV = 16 / sizeof(T), NG = CKR / EPV;
     if constexpr (!RC::PK && !RC::SOP) {
+        static_assert(RC::PK || RC::SOP || CKR == kChunkX, "the slab form is built for kChunkX ticks per lane");
         replay_dpp<T, DB, J, WRITE, NLL>(rc.a, rc.ha, rc.kk, tile_lane, carry, lane, n, head, xs, xc, acc, nobs);
         return;
     }
-    const int jl = (n - 1) / kChunkX, klast = (n - 1) % kChunkX;      // lane and tick of the last tick of the segment
-    const bool counted = lane * kChunkX >= head;
+    const int jl = (n - 1) / CKR, klast = (n - 1) % CKR;      // lane and tick of the last tick of the segment
+    const bool counted = lane * CKR >= head;
     // the state: scalars, or pairs across two components (PK)
     typedef typename RC::T2 T2;
     T2 X[RC::PK ? RC::NPAIR * DB : 1];
@@ -252,7 +253,7 @@ __device__ inline void replay(const ReplayConst<T, DB, J>& rc, T* tile_lane, T* 
         cur = nxt;
     }
     };
-    if (FULLFAST && n == 64 * kChunkX && head == 0) {
+    if (FULLFAST && n == 64 * CKR && head == 0) {
         walk(std::false_type{});
         if (lane == 63) {                                              // the segment's last tick is lane 63's last
             if constexpr (RC::PK) {
@@ -276,7 +277,7 @@ __device__ inline void replay(const ReplayConst<T, DB, J>& rc, T* tile_lane, T* 
     if (NLL) {
         if constexpr (RC::PK) part = (double)partf;
         acc += (counted && lane < jl) ? part : 0.0;
-        nobs += counted ? (lane < jl ? (unsigned)kChunkX : (lane == jl ? (unsigned)(klast + 1) : 0u)) : 0u;
+        nobs += counted ? (lane < jl ? (unsigned)CKR : (lane == jl ? (unsigned)(klast + 1) : 0u)) : 0u;
     }
     wave_lds_fence();
 #pragma unroll
@@ -291,7 +292,7 @@ __device__ inline void replay(const ReplayConst<T, DB, J>& rc, T* tile_lane, T* 
 // row_ror additions inside the wave's first 16-lane row -- and an observed tick adds K (y - HA x).  About a dozen dependent
 // instructions per tick (the first version gathered the whole state with v_readlane against full rows of A: 2 D + ... per tick,
 // 175 ns; this one 40-60 ns).  One entry per lane: this path must not set the kernel's registers.
-template <typename T, int DB, int J, bool WRITE, bool NLL>
+template <typename T, int DB, int J, bool WRITE, bool NLL, int CKS = kChunkX /* ticks per tile row */>
 __device__ inline void sequential(const T* __restrict__ c, T* tile, int stride, int n, int head, int lane, T (&xc)[DB * J], double& acc, unsigned& nobs) {
     constexpr int D = DB * J;
     using Lay = XC<D>;
@@ -307,10 +308,10 @@ __device__ inline void sequential(const T* __restrict__ c, T* tile, int stride, 
     T ynext = tile[0];
 #pragma unroll 1
     for (int t = 0; t < n; t++) {
-        T* slot = tile + (t / kChunkX) * stride + (t % kChunkX);
+        T* slot = tile + (t / CKS) * stride + (t % CKS);
         const T y = ynext;                                           // same address in every lane: one broadcast read, one tick ahead
         const int tn = t + 1 < n ? t + 1 : t;
-        ynext = tile[(tn / kChunkX) * stride + (tn % kChunkX)];
+        ynext = tile[(tn / CKS) * stride + (tn % CKS)];
         T s = arow[0] * dpp0<0x00, 0xF>(xv);
         s = fma(arow[1], dpp0<0x55, 0xF>(xv), s);
         if (DB > 2) s = fma(arow[DB - 1], dpp0<0xAA, 0xF>(xv), s);
@@ -1013,6 +1014,329 @@ filter_x_team_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// TEAM, CHUNK LENGTH AS A PARAMETER: kTeamCWaves = 8 wavefronts per latent -- two on every SIMD of the compute unit that holds the
+// latent -- and the chunk length chosen so that eight segments of 64 chunks cover the stream (10^4 ticks: CK = 20, 1280-tick segments).
+// Stage stamps of the first versions (tools/team_stamps.py, profiles/r03/team_stamps_*.log) showed the few-latents sweep bound by the
+// ISSUE SLOTS OF ONE COMPUTE UNIT, not by latency: five 2048-tick wavefronts sit 2-1-1-1 on the four SIMDs, ten 1024-tick ones 3-3-2-2,
+// and in both the youngest wavefront of the fullest SIMD finishes last, having waited for its elders at every stage.  Eight wavefronts
+// balance the SIMDs, and the longest chunk that still gives eight segments keeps the scans' share (two per segment, whatever its length) lowest.
+// The tables come from the latent's block as far as they do not depend on CK (the response table of a CK-tick chunk is the last CK rows of
+// G; the replay's coefficients); the scan powers M^(2^k), M = AKHA^CK, k = 0..6, and the facts derived from them come from
+// team_powers_kernel's table (below; filled at IHGP::update for banks of fewer than 1024 latents).
+// No whole-stream fallback lives in this kernel; what the 32-tick team kernel hands back is handled here, exactly and in place, through a
+// chain of LDS flags:
+//   * every wave publishes the TRUE state after its segment, eend[w], and then done[w]; wave w takes its carry-in from eend[w-1] once
+//     done[w-1] is set (wave 0 from the caller's start state: the chain always terminates; all waves of a workgroup are resident);
+//   * a clean segment of a latent that decays publishes its zero-start end state right after its scan -- nobody waits;  one that does
+//     not decay publishes e0 + M^64 c_w once its own carry-in is there (a serial chain of one matrix-vector product per segment);
+//   * a segment with a missing tick -- or every segment of a latent that is not tame -- is walked tick by tick from its true carry-in
+//     (sequential(), the many-latent kernel's own walk) and publishes the walk's end state: only such segments wait for each other.
+// For fp32 (packed replay) at every state dimension and fp64 (scalar-operand replay) up to d = 8; fp64 d = 9, 12 keep the 32-tick team kernel.
+#ifdef MOIHGP_TUNING
+// tuning builds only: shader-clock stamps of workgroup 0's wavefronts at the stage boundaries (tools/team_stamps.py)
+__device__ unsigned long long g_team_stamps[16][16];
+#define MOIHGP_STAMP(i_) do { if ((i_) == 9) __builtin_amdgcn_s_waitcnt(0); if (blockIdx.x == 0 && lane == 0) { g_team_stamps[wave][i_] = __builtin_readcyclecounter(); if ((i_) == 0 || (i_) == 9) g_team_stamps[wave][(i_) == 0 ? 14 : 15] = wall_clock64(); } } while (0)
+#else
+#define MOIHGP_STAMP(i_) do { } while (0)
+#endif
+constexpr int kTeamCWaves = 8;
+constexpr int kTeamNck = 5;                                  // chunk lengths the kernel is built for: 16, 20, .., 32 (index (CK - 16) / 4)
+template <int D> constexpr int team_powers_len() { return 7 * XC<D>::LS + 16; }       // M^(1,2,..,64) | levels that matter, decays, tame, 0..
+
+// The scan powers of the chunk-templated team kernel, per latent and chunk length: M^(2^k), M = AKHA^CK, k = 0..6 (fp64 products through
+// LDS, one or a few entries per lane), and what update() derives from such powers for 32-tick chunks (stationary_x.hip, same bounds): the
+// number of levels that matter in each precision, whether M^64 still does ("decays"), whether every power stays inside the format
+// ("tame": 1e150 / 1e18).  Run once per IHGP::update for banks small enough for the team kernel (a dozen dependent D x D products:
+// 3.5 us when the sweep kernel formed them itself, per launch -- more than the stream's load latency hides).
+template <int D>
+__global__ void __launch_bounds__(64) team_powers_kernel(const double* __restrict__ cb64, double* __restrict__ tp64, float* __restrict__ tp32) {
+    using Lay = XC<D>;
+    constexpr int NN = D * D, TPL = team_powers_len<D>();
+    __shared__ double pwr[4 * Lay::LS];
+    const int lane = threadIdx.x, cki = blockIdx.y, CK = 16 + 4 * cki;
+    const size_t l = blockIdx.x;
+    const double* __restrict__ c64 = cb64 + l * Lay::SIZE;
+    double* o64 = tp64 + (l * kTeamNck + cki) * TPL;
+    float* o32 = tp32 + (l * kTeamNck + cki) * TPL;
+    auto mm = [&](double* dst, const double* a, const double* b) {                      // dst = a b   (dst distinct from both)
+        for (int e = lane; e < NN; e += 64) {
+            const int i = e / D, j = e % D;
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; k++) acc = fma(a[i * D + k], b[k * D + j], acc);
+            dst[e] = acc;
+        }
+        wave_lds_fence();
+    };
+    double *sq = pwr, *sq2 = pwr + Lay::LS, *m = pwr + 2 * Lay::LS, *m2 = pwr + 3 * Lay::LS;
+    for (int e = lane; e < NN; e += 64) sq[e] = c64[Lay::AKHA + e];
+    wave_lds_fence();
+    bool have = false;
+    for (int k = 0; (CK >> k) != 0; k++) {                                              // AKHA^CK by squaring and multiplying
+        if ((CK >> k) & 1) {
+            if (!have) { for (int e = lane; e < NN; e += 64) m[e] = sq[e]; wave_lds_fence(); have = true; }
+            else { mm(m2, m, sq); double* t = m; m = m2; m2 = t; }
+        }
+        if ((CK >> (k + 1)) != 0) { mm(sq2, sq, sq); double* t = sq; sq = sq2; sq2 = t; }
+    }
+    bool tame64 = true, tame32 = true;
+    int nlv64 = 1, nlv32 = 1, dec64 = 1, dec32 = 1;
+    for (int lv = 0; lv < 7; lv++) {
+        double big = 0.0;
+        for (int e = lane; e < Lay::LS; e += 64) {
+            const double v = e < NN ? m[e] : 0.0;
+            o64[lv * Lay::LS + e] = v;
+            o32[lv * Lay::LS + e] = (float)v;
+            tame64 = tame64 && (fabs(v) < 1e150);                                       // (false for NaN too)
+            tame32 = tame32 && (fabs(v) < 1e18);
+            big = fmax(big, fabs(v));
+        }
+        for (int o = 32; o >= 1; o >>= 1) big = fmax(big, __shfl_xor(big, o, 64));
+        if (big * D >= 1e-20) { if (lv < 6) nlv64 = lv + 1; else dec64 = 0; }
+        if (big * D >= 1e-10) { if (lv < 6) nlv32 = lv + 1; else dec32 = 0; }
+        if (lv < 6) { mm(m2, m, m); double* t = m; m = m2; m2 = t; }
+    }
+    tame64 = __builtin_amdgcn_ballot_w64(!tame64) == 0;
+    tame32 = __builtin_amdgcn_ballot_w64(!tame32) == 0;
+    if (lane < 16) {
+        o64[7 * Lay::LS + lane] = lane == 0 ? (double)nlv64 : lane == 1 ? (double)dec64 : lane == 2 ? (tame64 ? 1.0 : 0.0) : 0.0;
+        o32[7 * Lay::LS + lane] = lane == 0 ? (float)nlv32 : lane == 1 ? (float)dec32 : lane == 2 ? (tame32 ? 1.0f : 0.0f) : 0.0f;
+    }
+}
+
+// tile row of one lane: CK ticks + padding such that the rows' 16-byte groups fall on distinct LDS banks (an odd number of groups per row)
+template <typename T, int CK> constexpr int teamc_stride() { return ((CK + 16 / (int)sizeof(T)) / (16 / (int)sizeof(T))) % 2 == 1 ? CK + 16 / (int)sizeof(T) : CK + 32 / (int)sizeof(T); }
+template <typename T, int D, int CK> constexpr int teamc_table_len() { return (CK * D + 15) / 16 * 16 + 7 * XC<D>::LS; }      // last CK rows of G | M^(1,2,..,64)
+template <typename T, int D, int CK> constexpr size_t teamc_aux_offset(int nw) {    // tiles | e0 [nw][D] | eend [nw][D] | carries [nw][D] | tables
+    return (((size_t)nw * (64 * teamc_stride<T, CK>() + 3 * D) + teamc_table_len<T, D, CK>()) * sizeof(T) + 15) / 16 * 16;
+}
+template <typename T, int D, int CK> constexpr size_t teamc_smem_bytes(int nw) {      // + sums [nw][2] | flags [nw]
+    return teamc_aux_offset<T, D, CK>(nw) + 2 * (size_t)nw * sizeof(double) + (size_t)nw * sizeof(int);
+}
+
+template <typename T, int DB, int J, bool WRITE, bool NLL, int CK>
+__global__ void __launch_bounds__(64 * kTeamCWaves)
+filter_x_teamc_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, const T* __restrict__ cbT, const double* __restrict__ cb64,
+                      const T* __restrict__ tpT /* team_powers_kernel's table in T */, const T* xin0, T* x, T* __restrict__ yhat, double* __restrict__ nll,
+                      size_t ldo, int nw /* wavefronts = segments of 64 CK ticks */) {
+    constexpr int D = DB * J, NN = D * D;
+    using V = typename VecOf<T>::type;
+    using Lay = XC<D>;
+    constexpr int EPV = 16 / sizeof(T), STRIDE = teamc_stride<T, CK>(), SEG = 64 * CK;
+    constexpr int NSL = Lay::LS / 16, GNC = (CK * D + 15) / 16 * 16, NSG = GNC / 16;
+    static_assert(CK % EPV == 0 && CK <= kChunkX, "whole 16-byte groups; the response table is a tail of the 32-tick one");
+    static_assert(ReplayConst<T, DB, J>::PK || ReplayConst<T, DB, J>::SOP || CK == kChunkX, "the DPP replay form is written for 32-tick chunks");
+    extern __shared__ __attribute__((aligned(16))) unsigned char team_smem[];
+    T* tiles = reinterpret_cast<T*>(team_smem);                                       // [nw][64 * STRIDE]
+    T* e0s = tiles + (size_t)nw * 64 * STRIDE;                                         // [nw][D]  zero-start end state of a clean segment
+    T* eend = e0s + (size_t)nw * D;                                                    // [nw][D]  TRUE state after the segment
+    T* carries = eend + (size_t)nw * D;                                                // [nw][D]  carry-out slots of the replays
+    T* tab = carries + (size_t)nw * D;                                                 // [GNC | 7 LS]
+    double* part = reinterpret_cast<double*>(team_smem + teamc_aux_offset<T, D, CK>(nw));  // [nw][2]  per-wave sum of v^2, observed ticks
+    int* done = reinterpret_cast<int*>(part + 2 * (size_t)nw);                         // [nw]     eend[w] is valid
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t l = blockIdx.x;
+    if (l >= L) return;
+    const T* __restrict__ c = cbT + l * Lay::SIZE;
+    const T* __restrict__ tp = tpT + (l * kTeamNck + (CK - 16) / 4) * team_powers_len<D>();
+    MOIHGP_STAMP(0);
+    T* tile = tiles + (size_t)wave * 64 * STRIDE;
+    T* tile_lane = tile + lane * STRIDE;
+    const T* row = Ty + l * ld;
+    const size_t t0 = (size_t)wave * SEG;
+    const int n = (int)(Tlen - t0 < (size_t)SEG ? Tlen - t0 : (size_t)SEG);            // (nw = ceil(Tlen / SEG): every wave owns >= 1 tick)
+    // every global load of the sweep up front: the wave's segment, the latent's tables (one copy per workgroup, into LDS), the replay's operands
+    V raw[CK / EPV];
+#pragma unroll
+    for (int r = 0; r < CK / EPV; r++) {
+        const int e = (r * 64 + lane) * EPV;
+        raw[r] = V{};
+        if (e < n) raw[r] = nt_load(reinterpret_cast<const V*>(row + t0 + e));
+    }
+    for (int e = threadIdx.x; e < teamc_table_len<T, D, CK>(); e += blockDim.x)
+        tab[e] = e < CK * D ? c[Lay::G + (kChunkX - CK) * D + e] : e < GNC ? T(0) : tp[e - GNC];     // g_k of a CK-tick chunk: the table's last CK rows; the powers
+    ReplayConst<T, DB, J> rc;
+    load_replay_const<T, DB, J>(launder(c), c, lane, rc);
+    T cin[D];                                                                          // (x may be xin0's own buffer: read before anyone can have written)
+#pragma unroll
+    for (int i = 0; i < D; i++) cin[i] = xin0[l * D + i];
+    if (lane == 0) done[wave] = 0;
+    __syncthreads();
+    MOIHGP_STAMP(1);
+    const bool scan_ok = __builtin_amdgcn_readfirstlane((int)(c[Lay::SCANOK] != T(0) && tp[7 * Lay::LS + 2] != T(0))) != 0;   // response table and powers tame
+    const int nlev = __builtin_amdgcn_readfirstlane((int)tp[7 * Lay::LS]);              // levels of the scan that matter
+    const bool decays = __builtin_amdgcn_readfirstlane((int)(tp[7 * Lay::LS + 1] != T(0))) != 0;    // M^64 negligible: segments chain through e0 alone
+    const T* pw = tab + GNC;                                                           // pw + lv * LS: M^(2^lv)
+    // ---- A. stage in, chunk response, (clean segments) scan from a zero state ----
+#pragma unroll
+    for (int r = 0; r < CK / EPV; r++) {
+        const int e = (r * 64 + lane) * EPV;
+        T vals[EPV];
+        unpack<T>(raw[r], vals);
+#pragma unroll
+        for (int q = 0; q < EPV; q++) if (e + q >= n) vals[q] = T(0);               // beyond the stream: inert zeros
+        *reinterpret_cast<V*>(tile + (e / CK) * STRIDE + (e % CK)) = pack<T>(vals);
+    }
+    MOIHGP_STAMP(2);
+    T g[NSG];
+    load_slabs<T, NSG>(tab, lane, g);
+    wave_lds_fence();
+    T z[D];
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < D; i++) z[i] = T(0);
+    static_for<CK / EPV>([&](auto kvv) {
+        constexpr int kv = decltype(kvv)::value;
+        T yv[EPV];
+        unpack<T>(*reinterpret_cast<const V*>(tile_lane + kv * EPV), yv);
+        static_for<EPV>([&](auto qq) {
+            constexpr int k = kv * EPV + decltype(qq)::value;
+            bad = bad || (yv[decltype(qq)::value] != yv[decltype(qq)::value]);
+            static_for<D>([&](auto ii) {
+                constexpr int e = k * D + decltype(ii)::value;
+                fmac_bc<e % 16>(z[decltype(ii)::value], g[e / 16], yv[decltype(qq)::value]);
+            });
+        });
+    });
+    MOIHGP_STAMP(3);
+    const bool walk = !scan_ok || __builtin_amdgcn_ballot_w64(bad) != 0;                // wave-uniform
+    if (!walk) {
+        T t[D], sp[2][NSL];
+        load_slabs<T, NSL>(pw, lane, sp[0]);
+#pragma unroll
+        for (int lv = 0; lv < 6; lv++) {
+            if (lv >= nlev) break;
+            const int sh = 1 << lv, addr = ((lane - sh) & 63) * 4;
+#pragma unroll
+            for (int i = 0; i < D; i++) { const T m = bperm<T>(addr, z[i]); t[i] = lane >= sh ? m : T(0); }
+            if (lv + 1 < nlev) load_slabs<T, NSL>(pw + (lv + 1) * Lay::LS, lane, sp[(lv + 1) & 1]);   // (next power: in flight during this level)
+            matvec_bc<T, D, NSL>(sp[lv & 1], t, z);
+        }
+        if (lane == 63) {
+#pragma unroll
+            for (int i = 0; i < D; i++) { e0s[wave * D + i] = z[i]; if (decays) eend[wave * D + i] = z[i]; }
+        }
+        if (decays) {                                                                  // true end state = e0 to rounding: publish, nobody has to wait for us
+            wave_lds_fence();
+            if (lane == 0) __hip_atomic_store(&done[wave], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    MOIHGP_STAMP(4);
+    // ---- B. the state entering this segment ----
+    if (wave != 0) {
+        while (__hip_atomic_load(&done[wave - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int i = 0; i < D; i++) cin[i] = eend[(wave - 1) * D + i];                  // (uniform address: one broadcast read)
+    }
+    MOIHGP_STAMP(5);
+    T xc[D];
+    double acc = 0.0;
+    unsigned nobs = 0;
+    if (walk) {
+        // tick by tick from the true carry-in; outputs into the tile, sum of v^2 and the count in lane 0
+#pragma unroll
+        for (int i = 0; i < D; i++) xc[i] = cin[i];
+        bool any_lost = false;
+#pragma unroll
+        for (int i = 0; i < D; i++) any_lost = any_lost || !((xc[i] - xc[i]) == T(0));
+        if (!scan_ok && any_lost) {                                                    // an unstable latent that has left the format: NaN from here on, as the
+            const T qnan = __builtin_nan("");                                          // many-latent kernel does (its walk would give the same, 10 x slower)
+            if (WRITE) {
+#pragma unroll 4
+                for (int k = 0; k < CK; k++) tile_lane[k] = qnan;
+            }
+#pragma unroll
+            for (int i = 0; i < D; i++) xc[i] = qnan;
+            if (NLL) acc = __builtin_nan("");
+        } else {
+            sequential<T, DB, J, WRITE, NLL, CK>(c, tile, STRIDE, n, 0, lane, xc, acc, nobs);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < D; i++) eend[wave * D + i] = xc[i];
+        }
+        wave_lds_fence();
+        if (lane == 0) __hip_atomic_store(&done[wave], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+        if (!decays) {                                                                 // true end state = e0 + M^64 cin: our successor is waiting for it
+            T t[D], sp[NSL];
+            load_slabs<T, NSL>(pw + 6 * Lay::LS, lane, sp);
+#pragma unroll
+            for (int i = 0; i < D; i++) t[i] = e0s[wave * D + i];
+            matvec_bc<T, D, NSL>(sp, cin, t);
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < D; i++) eend[wave * D + i] = t[i];
+            }
+            wave_lds_fence();
+            if (lane == 0) __hip_atomic_store(&done[wave], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        // q_j = M^j cin from the binary powers of the lane's own index (cin is uniform: no lane exchange), start states, replay
+        T xs[D];
+        {
+            T q[D], sp[NSL];
+#pragma unroll
+            for (int i = 0; i < D; i++) q[i] = cin[i];
+            load_slabs<T, NSL>(pw, lane, sp);
+#pragma unroll
+            for (int lv = 0; lv < 6; lv++) {
+                if (lv >= nlev) break;
+                T t[D];
+#pragma unroll
+                for (int i = 0; i < D; i++) t[i] = T(0);
+                matvec_bc<T, D, NSL>(sp, q, t);
+                if (lv + 1 < nlev) load_slabs<T, NSL>(pw + (lv + 1) * Lay::LS, lane, sp);
+                const bool bit = (lane >> lv) & 1;
+#pragma unroll
+                for (int i = 0; i < D; i++) q[i] = bit ? t[i] : q[i];
+            }
+            const bool far = (lane >> nlev) != 0;                                      // would need M^(2^nlev) or more: below the table's own criterion
+            const int addr1 = ((lane - 1) & 63) * 4;
+#pragma unroll
+            for (int i = 0; i < D; i++) { const T m = bperm<T>(addr1, z[i]); xs[i] = (lane >= 1 ? m : T(0)) + (far ? T(0) : q[i]); }
+        }
+        MOIHGP_STAMP(6);
+        replay<T, DB, J, WRITE, NLL, true, CK>(rc, tile_lane, carries + wave * D, lane, n, 0, xs, xc, acc, nobs);
+    }
+    MOIHGP_STAMP(7);
+    // ---- stage out ----
+    if (WRITE) {
+        wave_lds_fence();
+        T* orow = yhat + l * ldo;
+#pragma unroll
+        for (int r = 0; r < CK / EPV; r++) {
+            const int e = (r * 64 + lane) * EPV;
+            if (e < n) nt_store(*reinterpret_cast<const V*>(tile + (e / CK) * STRIDE + (e % CK)), reinterpret_cast<V*>(orow + t0 + e));
+        }
+    }
+    MOIHGP_STAMP(8);
+    if (wave == nw - 1 && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < D; i++) x[l * D + i] = xc[i];
+    }
+    if (NLL) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { acc += __shfl_xor(acc, o, 64); nobs += __shfl_xor(nobs, o, 64); }
+        if (lane == 0) { part[2 * wave] = acc; part[2 * wave + 1] = (double)nobs; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double a = 0.0, nn = 0.0;
+            for (int w = 0; w < nw; w++) { a += part[2 * w]; nn += part[2 * w + 1]; }      // in segment order (deterministic)
+            const double* c64 = cb64 + l * Lay::SIZE;
+            nll[l] = 0.5 * (a / c64[Lay::S] + nn * c64[Lay::LOGS]);
+        }
+    }
+    MOIHGP_STAMP(9);
+}
+
+#ifdef MOIHGP_TUNING
+extern "C" int moihgp_tuning_team_stamps(unsigned long long* out /* [16][16] */) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_team_stamps), sizeof(unsigned long long) * 256);
+}
+#endif
+
 // nll[l] = sum over the slices, in slice order (deterministic)
 __global__ void __launch_bounds__(256) sum_slices_kernel(const double* __restrict__ part, size_t L, int nslice, double* __restrict__ nll) {
     const size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1103,10 +1427,63 @@ int launch_x_team(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT
     return 0;
 }
 
+template <typename T, int DB, int J, int CK>
+int launch_x_teamc(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, const double* cb64, const T* tpT, const void* xin, void* x, void* yhat, double* nll,
+                   hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, size_t ldo, double* total, int nw) {
+    const size_t smem = teamc_smem_bytes<T, DB * J, CK>(nw);
+    dim3 block(64 * nw), grid((unsigned)L);
+#define MOIHGP_TEAMC_LAUNCH(W_, N_)                                                                                                                  \
+    do {                                                                                                                                             \
+        auto kfn = filter_x_teamc_kernel<T, DB, J, W_, N_, CK>;                                                                                      \
+        static size_t attr_set = 48 * 1024;                                                                                                          \
+        if (smem > attr_set) { MOIHGP_HIP_FATAL(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); attr_set = smem; } \
+        hipExtLaunchKernelGGL(kfn, grid, block, smem, stream, ev0, ev1, 0, (const T*)Ty, Tlen, ld, L, cbT, cb64, tpT, (const T*)xin, (T*)x, (T*)yhat, nll, ldo, nw); \
+    } while (0)
+    if (yhat && nll) MOIHGP_TEAMC_LAUNCH(true, true);
+    else if (yhat) MOIHGP_TEAMC_LAUNCH(true, false);
+    else if (nll) MOIHGP_TEAMC_LAUNCH(false, true);
+    else MOIHGP_TEAMC_LAUNCH(false, false);
+#undef MOIHGP_TEAMC_LAUNCH
+    if (nll && total) launch_nll_total(nll, L, total, stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_last_error("filter_x_teamc_kernel launch: %s", hipGetErrorString(e)); return 2; }
+    return 0;
+}
+
+// the chunk-templated team kernel for a stream of Tlen ticks, if one of its chunk lengths gives 2 .. kTeamCWaves segments that fit a compute unit
+// (returns -1 if none does: the caller goes on to the other forms)
+template <typename T, int DB, int J>
+int try_x_teamc(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, const double* cb64, const T* tpT, const void* xin, void* x, void* yhat, double* nll,
+                hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, size_t ldo, double* total, int team_mode) {
+    if (!tpT) return -1;
+    if constexpr (ReplayConst<T, DB, J>::PK || ReplayConst<T, DB, J>::SOP) {
+        int rc = -1;
+        auto attempt = [&](auto ckk) {
+            constexpr int CK = decltype(ckk)::value;
+            if (rc != -1 || Tlen > 64 * (size_t)CK * kTeamCWaves) return;               // (ascending CK: the shortest chunk that covers the stream in eight segments)
+            const size_t nw = (Tlen + 64 * (size_t)CK - 1) / (64 * (size_t)CK);
+            if (nw < 2) return;
+            const size_t smem = teamc_smem_bytes<T, DB * J, CK>((int)nw);
+            size_t per_cu = (160 * 1024) / smem;
+            if (per_cu > 2048 / (64 * nw)) per_cu = 2048 / (64 * nw);
+            if (smem > 150 * 1024 || !(team_mode == 1 || L <= 256 * per_cu)) { rc = -2; return; }      // (a longer chunk needs more LDS still)
+            rc = launch_x_teamc<T, DB, J, CK>(Ty, Tlen, ld, L, cbT, cb64, tpT, xin, x, yhat, nll, stream, ev0, ev1, ldo, total, (int)nw);
+        };
+        attempt(std::integral_constant<int, 16>{});
+        attempt(std::integral_constant<int, 20>{});
+        attempt(std::integral_constant<int, 24>{});
+        attempt(std::integral_constant<int, 28>{});
+        attempt(std::integral_constant<int, 32>{});
+        return rc == -2 ? -1 : rc;
+    } else {
+        return -1;
+    }
+}
+
 template <typename T, int DB, int J>
 int launch_xd(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, const double* cb64, const void* xin, void* x, void* yhat, double* nll,
               hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, double* scratch, size_t scratch_len, int force_slices, size_t ldo,
-              int* link_flags, double* link_state, double* total, int env_links, int team_mode) {
+              int* link_flags, double* link_state, double* total, int env_links, int team_mode, const T* tpT) {
     constexpr size_t SEG = 64 * (size_t)kChunkX;
     if (L >= 1024) {
         // chunks with a gap per segment up to which the broken-link stages of the second pass beat the tick-by-tick walk (measured,
@@ -1118,11 +1495,17 @@ int launch_xd(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, co
     const size_t nseg = (Tlen + SEG - 1) / SEG;
     // few latents, a stream of 2 .. kTeamWaves segments: one workgroup per latent, one wavefront per segment (filter_x_team_kernel), as long as
     // all workgroups are resident at once (LDS: a wave's tile is 9 / 17 KB)
+    // ... eight wavefronts and the chunk length to match, where the replay takes the chunk length (fp32; fp64 up to d = 8)
+    // (team_mode 2 = the 32-tick team kernel only)
+    if (team_mode != 0 && team_mode != 2 && force_slices == 0) {
+        const int rc = try_x_teamc<T, DB, J>(Ty, Tlen, ld, L, cbT, cb64, tpT, xin, x, yhat, nll, stream, ev0, ev1, ldo, total, team_mode);
+        if (rc != -1) return rc;
+    }
     if (team_mode != 0 && force_slices == 0 && nseg >= 2 && nseg <= (size_t)kTeamWaves) {
         const size_t smem = team_smem_bytes<T, DB * J>((int)nseg);
         size_t per_cu = (160 * 1024) / smem;
         if (per_cu > 2048 / (64 * nseg)) per_cu = 2048 / (64 * nseg);
-        if (smem <= 150 * 1024 && (team_mode == 1 || L <= 256 * per_cu))
+        if (smem <= 150 * 1024 && (team_mode == 1 || team_mode == 2 || L <= 256 * per_cu))
             return launch_x_team<T, DB, J>(Ty, Tlen, ld, L, cbT, cb64, xin, x, yhat, nll, stream, ev0, ev1, ldo, total, (int)nseg);
     }
     // otherwise: one wavefront per workgroup, and the stream cut into time slices (one wavefront each) while that adds
@@ -1145,16 +1528,32 @@ int launch_xd(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, co
 
 }  // namespace
 
+void launch_team_powers(int kernel, const double* cb64, size_t L, double* tp64, float* tp32, hipStream_t stream) {
+    if (L == 0) return;
+    const int d = (kernel_base(kernel) == 0 ? 2 : 3) * kernel_stack(kernel);
+    dim3 grid((unsigned)L, kTeamNck);
+    switch (d) {
+        case 4: hipLaunchKernelGGL(team_powers_kernel<4>, grid, dim3(64), 0, stream, cb64, tp64, tp32); break;
+        case 6: hipLaunchKernelGGL(team_powers_kernel<6>, grid, dim3(64), 0, stream, cb64, tp64, tp32); break;
+        case 8: hipLaunchKernelGGL(team_powers_kernel<8>, grid, dim3(64), 0, stream, cb64, tp64, tp32); break;
+        case 9: hipLaunchKernelGGL(team_powers_kernel<9>, grid, dim3(64), 0, stream, cb64, tp64, tp32); break;
+        case 12: hipLaunchKernelGGL(team_powers_kernel<12>, grid, dim3(64), 0, stream, cb64, tp64, tp32); break;
+        default: break;
+    }
+    MOIHGP_HIP_FATAL(hipGetLastError());
+}
+
 int launch_filter_stream_x(int kernel, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* cb64, const float* cb32,
                            const void* xin, void* x, void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1,
-                           double* scratch, size_t scratch_len, int force_slices, size_t ldo, int* link_flags, double* link_state, double* total, int max_links, int team_mode) {
+                           double* scratch, size_t scratch_len, int force_slices, size_t ldo, int* link_flags, double* link_state, double* total, int max_links, int team_mode,
+                           const double* tp64, const float* tp32) {
     if (L == 0) return 0;
     if (ldo == 0) ldo = ld;
     const int base = kernel_base(kernel), J = kernel_stack(kernel);
 #define MOIHGP_X_CASE(DBB, JJ)                                                                                        \
     if (base == (DBB == 2 ? 0 : 1) && J == JJ)                                                                        \
-        return dtype == 0 ? launch_xd<double, DBB, JJ>(Ty, T, ld, L, cb64, cb64, xin, x, yhat, nll, stream, ev0, ev1, scratch, scratch_len, force_slices, ldo, link_flags, link_state, total, max_links, team_mode) \
-                          : launch_xd<float, DBB, JJ>(Ty, T, ld, L, cb32, cb64, xin, x, yhat, nll, stream, ev0, ev1, scratch, scratch_len, force_slices, ldo, link_flags, link_state, total, max_links, team_mode)
+        return dtype == 0 ? launch_xd<double, DBB, JJ>(Ty, T, ld, L, cb64, cb64, xin, x, yhat, nll, stream, ev0, ev1, scratch, scratch_len, force_slices, ldo, link_flags, link_state, total, max_links, team_mode, tp64) \
+                          : launch_xd<float, DBB, JJ>(Ty, T, ld, L, cb32, cb64, xin, x, yhat, nll, stream, ev0, ev1, scratch, scratch_len, force_slices, ldo, link_flags, link_state, total, max_links, team_mode, tp32)
 #ifdef MOIHGP_X_ONLY_DBJ         // (development: -DMOIHGP_X_ONLY_DBJ=32 builds the DB = 3, J = 2 kernels alone: quick resource checks, A/B builds)
     MOIHGP_X_CASE(MOIHGP_X_ONLY_DBJ / 10, MOIHGP_X_ONLY_DBJ % 10);
 #else

@@ -989,6 +989,60 @@ def test_stacked_full_size_properties(env, kern, dtype, L, T):
     assert max(d1, d2) < tol, (d1, d2)
 
 
+@pytest.mark.parametrize("kern", STACKED)
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("T", [1025, 2049, 5000, 10000, 10240, 12000, 14000, 16384])
+def test_stacked_team_kernels_vs_oracle(env, kern, dtype, T):
+    """Few latents, streams of 2 .. 10 segments: one workgroup per latent, one wavefront per segment (recursion_x.hip, the team kernels:
+    16-tick chunks / 1024-tick segments where the replay allows it, 32-tick chunks / 2048-tick segments otherwise or on request).  Each form
+    against the oracle's tick loop and against the one-wavefront sweep, with what the segments hand to each other exercised: a latent that
+    decays too slowly for the zero-start chaining, gaps in one segment only, sparse gaps everywhere, a series never observed, a start state."""
+    J = int(kern[-1])
+    rng = np.random.default_rng(31 * J + T)
+    L = 7
+    prm = synth_params_stacked(L, J, rng)
+    prm[0, 1::2][:J] = 90.0; prm[0, -1] = 1e-3          # slow latent: lengthscales 90, noise 1e-3
+    prm[5, 1::2][:J] = 25.0; prm[5, -1] = 0.02          # in between
+    bank = env["streams"].LatentBank(0.1, prm, kernel=kern)
+    Ty = synth(L, T, rng)
+    Ty[1, 1030:1040] = np.nan                           # one segment of either form
+    Ty[2, rng.random(T) < 0.01] = np.nan
+    Ty[3, :] = np.nan
+    Ty[4, [0, 1023, 1024, T - 1]] = np.nan              # segment boundaries, first and last tick
+    Tyd = to_dev(Ty, dtype)
+    x0 = torch.from_numpy(0.3 * rng.standard_normal((L, bank.d))).to(dtype).cuda()
+    o = env["cref"].filter_stream(env["cref"].ihgp_array(kern, 0.1, prm), Ty, x0=x0.double().cpu().numpy(), nthreads=4)
+    tame = np.nan_to_num(np.abs(o["yhat"]), nan=0.0).max(axis=1) < 1e6     # (the slow latents may be unstable under the literal DARE)
+    assert tame.sum() >= 5
+    bank.set_option("filter_team", 0); bank.set_option("filter_split", 1)
+    y0, xT0, n0 = bank.filter(Tyd, T=T, x=x0.clone())
+    torch.cuda.synchronize()
+    tol = FP64_TIGHT if dtype == torch.float64 else FP32_TOL
+    for mode in (1, 2, -1):
+        bank.set_option("filter_team", mode); bank.set_option("filter_split", 0)
+        yh, xT, nll = bank.filter(Tyd, T=T, x=x0.clone())
+        _, xb, nb = bank.filter(Tyd, T=T, x=x0.clone(), want_yhat=False)
+        yc, xc, _ = bank.filter(Tyd, T=T, x=x0.clone(), want_nll=False)
+        torch.cuda.synchronize()
+        yg, yo = yh[:, :T].cpu().numpy().astype(np.float64)[tame], o["yhat"][tame]
+        okn = np.isfinite(yo)
+        assert np.array_equal(np.isfinite(yg), okn), mode
+        assert np.abs((yg - yo)[okn]).max() / np.abs(yo[okn]).max() < tol * 10, mode
+        assert rel_err(xT.cpu().numpy()[tame], o["x"][tame]) < tol * 10 and rel_err(nll.cpu().numpy()[tame], o["nll_per_latent"][tame]) < tol * 10, mode
+        assert nll[3].item() == 0.0
+        # against the one-wavefront sweep, every latent (the unstable ones too, while finite), and the other output combinations
+        rt = 1e-10 if dtype == torch.float64 else 2e-4
+        ok = torch.isfinite(y0[:, :T])
+        assert torch.equal(torch.isfinite(yh[:, :T]), ok), mode
+        scale = torch.where(ok, y0[:, :T], torch.zeros_like(y0[:, :T])).abs().amax(dim=1, keepdim=True) + 1e-30
+        assert (torch.where(ok, yh[:, :T] - y0[:, :T], torch.zeros_like(y0[:, :T])).abs() / scale).max().item() < rt, mode
+        fin = torch.isfinite(n0)
+        assert rel_err(nll[fin].cpu().numpy(), n0[fin].cpu().numpy()) < rt and rel_err(nb[fin].cpu().numpy(), n0[fin].cpu().numpy()) < rt, mode
+        for xx in (xT, xb, xc):
+            assert rel_err(torch.nan_to_num(xx).cpu().numpy(), torch.nan_to_num(xT0).cpu().numpy()) < rt, mode
+        assert (torch.where(ok, yc[:, :T] - yh[:, :T], torch.zeros_like(y0[:, :T])).abs() / scale).max().item() < rt, mode
+
+
 @pytest.mark.parametrize("kern,dtype", [("Matern52x2", torch.float64), ("Matern52x4", torch.float64), ("Matern32x3", torch.float32)])
 def test_stacked_time_split_matches_unsplit(env, kern, dtype, monkeypatch):
     """Few latents: the stream is cut into time slices that start from a zero state after a warm-up (recursion_x.hip).  Same
