@@ -70,5 +70,9 @@ __device__ inline void matvec_bc(const T (&m)[NS], const T (&v)[D], T (&out)[D])
     });
 }
 
+// scan powers of the chunk-templated team kernel (recursion_x.hip), built by stack_dispatch.hip's team_powers_kernel at every update
+constexpr int kTeamNck = 5;                                  // chunk lengths the kernel is built for: 16, 20, .., 32 (index (CK - 16) / 4)
+template <int D> constexpr int team_powers_len() { return 7 * XC<D>::LS + 16; }       // M^(1,2,..,64) | levels that matter, decays, tame, 0..
+
 }  // namespace
 }  // namespace moihgp

@@ -993,8 +993,8 @@ def test_stacked_full_size_properties(env, kern, dtype, L, T):
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 @pytest.mark.parametrize("T", [1025, 2049, 5000, 10000, 10240, 12000, 14000, 16384])
 def test_stacked_team_kernels_vs_oracle(env, kern, dtype, T):
-    """Few latents, streams of 2 .. 10 segments: one workgroup per latent, one wavefront per segment (recursion_x.hip, the team kernels:
-    16-tick chunks / 1024-tick segments where the replay allows it, 32-tick chunks / 2048-tick segments otherwise or on request).  Each form
+    """Few latents, streams of 2 .. 8 segments: one workgroup per latent, one wavefront per segment (recursion_x.hip, the team kernels:
+    eight wavefronts and chunks of 16 .. 32 ticks to match where the replay allows it, 32-tick chunks otherwise or on request).  Each form
     against the oracle's tick loop and against the one-wavefront sweep, with what the segments hand to each other exercised: a latent that
     decays too slowly for the zero-start chaining, gaps in one segment only, sparse gaps everywhere, a series never observed, a start state."""
     J = int(kern[-1])

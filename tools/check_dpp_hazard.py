@@ -6,7 +6,7 @@ the wait states for DPP instructions it generates itself, but it does not look i
 right in front of one of ours would go unnoticed.  This script disassembles the device code of an object file and reports
 every such pair.
 
-    python tools/check_dpp_hazard.py [build/obj/recursion_x.o]      exit status 1 if a hazard is found
+    python tools/check_dpp_hazard.py [build/obj/recursion_x_32.o]      exit status 1 if a hazard is found
 """
 import os
 import re
@@ -86,7 +86,7 @@ def scan(text):
 
 
 def main():
-    obj = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", "obj", "recursion_x.o")
+    obj = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", "obj", "recursion_x_32.o")
     hazards, ndpp = scan(disassemble(obj))
     print(f"{obj}: {ndpp} DPP instructions, {len(hazards)} hazards")
     for h in hazards[:20]:

@@ -10,7 +10,7 @@ from oracle import cref
 env = dict(MOIHGP=MOIHGP, streams=streams, cref=cref, lib=load_library())
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 12345)
 nfail = 0; n = 0
-Ts = [1, 2, 3, 15, 16, 17, 31, 32, 33, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 1535, 1536, 2047, 2048, 2049, 3071, 3072, 3073, 4095, 4096, 4097, 5000]
+Ts = [1, 2, 3, 15, 16, 17, 31, 32, 33, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 1535, 1536, 2047, 2048, 2049, 3071, 3072, 3073, 4095, 4096, 4097, 5000, 8192, 8193, 10000, 10240, 10241, 12288, 12289, 14336, 14337, 16384, 16385]
 kerns_f = ["Matern32", "Matern52", "Matern52x2", "Matern32x2", "Matern52x3", "Matern52x4", "Matern32x4"]
 for i in range(int(sys.argv[2]) if len(sys.argv) > 2 else 150):
     T = int(rng.choice(Ts + [int(rng.integers(1, 6000))]))

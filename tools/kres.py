@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Register / LDS / scratch use of the gfx950 kernels in an object file, one line per kernel (from the code object's metadata notes).
-    python tools/kres.py build/obj/recursion_x.o [substring ...]      only kernels whose demangled name holds every substring"""
+    python tools/kres.py build/obj/recursion_x_32.o [substring ...]      only kernels whose demangled name holds every substring"""
 import os, re, shutil, subprocess, sys, tempfile
 LLVM = "/opt/rocm/lib/llvm/bin"
 
