@@ -6,7 +6,7 @@ out=$1; tag=$2
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 mkdir -p "$out"
-for c in c3 c2 c3f64 c2d6 c3d6 c3d6f64 c5 c4 c1 c3learn c3grad c5grad; do
+for c in c3 c2 c3f64 c2d6 c3d6 c3d6f64 c5 c4 c1 c3learn c3grad c5grad c3loop; do
   python3 bench.py --config $c > "$out/${tag}_${c}_bench.json" 2> "$out/${tag}_${c}_bench.err"
   echo "bench $c done"
 done
