@@ -291,7 +291,8 @@ moihgp_dvec_ctx* moihgp_dvec_ctx_new(void);
 void    moihgp_dvec_ctx_del(moihgp_dvec_ctx* c);
 double* moihgp_dvec_alloc(size_t n);                                  /* n doubles of device memory (NULL on failure) */
 unsigned char* moihgp_dvec_alloc_mask(size_t n);
-void    moihgp_dvec_free(void* p);
+void    moihgp_dvec_free(void* p);                                    /* as hipFree for the caller; blocks of 1 MB and more are kept for the next alloc of that size */
+void    moihgp_dvec_trim(void);                                       /* hand the kept blocks (at most 32 GB) back to the driver */
 int moihgp_dvec_upload(moihgp_dvec_ctx* c, double* dst_dev, const double* src_host, size_t n);     /* synchronous */
 int moihgp_dvec_download(moihgp_dvec_ctx* c, double* dst_host, const double* src_dev, size_t n);   /* synchronous */
 int moihgp_dvec_copy(moihgp_dvec_ctx* c, double* dst_dev, const double* src_dev, size_t n);

@@ -17,6 +17,8 @@
 #include <limits>
 #include <list>
 #include <memory>
+#include <chrono>
+#include <map>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -29,6 +31,27 @@ extern "C" {
 
 namespace moihgp {
 namespace opt {
+
+// Opt-in wall-clock accounting of the learner's phases (tools/cxx/learner_bench.cpp prints it): off unless phases().enabled is set.
+struct Phases {
+    bool enabled = false;
+    std::map<std::string, double> seconds;
+    std::map<std::string, long> calls;
+};
+inline Phases& phases() { static Phases p; return p; }
+class PhaseTimer {
+public:
+    explicit PhaseTimer(const char* name) : m_name(name), m_on(phases().enabled) { if (m_on) m_t0 = std::chrono::steady_clock::now(); }
+    ~PhaseTimer() {
+        if (!m_on) return;
+        phases().seconds[m_name] += std::chrono::duration<double>(std::chrono::steady_clock::now() - m_t0).count();
+        phases().calls[m_name]++;
+    }
+private:
+    const char* m_name;
+    bool m_on;
+    std::chrono::steady_clock::time_point m_t0;
+};
 
 inline void dv_check(int rc, const char* what) {
     if (rc != 0) throw std::runtime_error(std::string(what) + ": " + moihgp_last_error());
@@ -170,8 +193,11 @@ public:
         if (lb.size() != n || ub.size() != n) throw std::invalid_argument("'lb' and 'ub' must have the same size as 'x'");
         moihgp_dvec_ctx* c = m_ops->ctx();
         dv_check(moihgp_dvec_clamp(c, n, x.data(), lb.data(), ub.data()), "dvec_clamp");
-        m_bfgs.reset(m_ops, n, m_param.m);
-        for (DVec* v : {&m_grad, &m_xp, &m_gradp, &m_drt, &m_xt, &m_s, &m_y}) v->resize(n);
+        {
+            PhaseTimer pt("solver: storage");
+            m_bfgs.reset(m_ops, n, m_param.m);
+            for (DVec* v : {&m_grad, &m_xp, &m_gradp, &m_drt, &m_xt, &m_s, &m_y}) v->resize(n);
+        }
         if (m_nfree != n) { moihgp_dvec_free(m_free); m_free = moihgp_dvec_alloc_mask(n); if (!m_free) throw std::runtime_error("moihgp_dvec_alloc_mask failed"); m_nfree = n; }
         std::vector<double> fpast(m_param.past > 0 ? m_param.past : 0);
         m_ops->sync();
@@ -183,11 +209,15 @@ public:
         const double eps = std::numeric_limits<double>::epsilon();
         int k = 1;
         for (;;) {
-            m_ops->copy(x, m_xp); m_ops->copy(m_grad, m_gradp);
-            dv_check(moihgp_dvec_active_set(c, n, x.data(), m_grad.data(), lb.data(), ub.data(), m_free), "active_set");
-            m_bfgs.apply_Hv_free(m_grad, m_free, m_drt);
-            m_ops->scale(-1.0, m_drt, m_drt);
-            double slope = m_ops->dot(m_grad, m_drt);
+            double slope;
+            {
+                PhaseTimer pt("solver: direction (two-loop on the face)");
+                m_ops->copy(x, m_xp); m_ops->copy(m_grad, m_gradp);
+                dv_check(moihgp_dvec_active_set(c, n, x.data(), m_grad.data(), lb.data(), ub.data(), m_free), "active_set");
+                m_bfgs.apply_Hv_free(m_grad, m_free, m_drt);
+                m_ops->scale(-1.0, m_drt, m_drt);
+                slope = m_ops->dot(m_grad, m_drt);
+            }
             if (!(slope < 0.0)) {                                      // not a descent direction: steepest descent on the face
                 m_ops->scale(-1.0, m_grad, m_drt, m_free);
                 slope = m_ops->dot(m_grad, m_drt);
@@ -216,8 +246,11 @@ public:
                 fpast[k % m_param.past] = fx;
             }
             if (m_param.max_iterations != 0 && k >= m_param.max_iterations) return k;
-            m_ops->sub(x, m_xp, m_s); m_ops->sub(m_grad, m_gradp, m_y);
-            if (m_ops->dot(m_s, m_y) > eps * m_ops->dot(m_y, m_y)) m_bfgs.add_correction(m_s, m_y);
+            {
+                PhaseTimer pt("solver: correction pair");
+                m_ops->sub(x, m_xp, m_s); m_ops->sub(m_grad, m_gradp, m_y);
+                if (m_ops->dot(m_s, m_y) > eps * m_ops->dot(m_y, m_y)) m_bfgs.add_correction(m_s, m_y);
+            }
             k++;
         }
     }
@@ -255,12 +288,18 @@ public:
         evaluations++;
         _ops->sub(params, oldparams, _dparams);
         _ops->sync();                                                            // (the handle works on its own stream)
-        opt::dv_check(moihgp_update_dev(_gp->handle(), params.data()), "update_dev");           // :43
-        if (bfgs_mat.get_m() > 0) bfgs_mat.apply_Hv(_dparams, _gamma, grad);     // :45-48: grad = Bp
-        else { grad.resize(_num_param); _ops->scale(1.0, _dparams, grad); }      // :51
-        double loss = 0.5 * _ops->dot(_dparams, grad);                           // :53
+        { opt::PhaseTimer pt("objective: update_dev"); opt::dv_check(moihgp_update_dev(_gp->handle(), params.data()), "update_dev"); }           // :43
+        if (opt::phases().enabled) { opt::phases().seconds["objective: Newton-Schulz steps of the polar factor (count, not ms)"] += 1e-3 * moihgp_polar_iterations(_gp->handle()); opt::phases().calls["objective: Newton-Schulz steps of the polar factor (count, not ms)"]++; }
+        double loss;
+        {
+            opt::PhaseTimer pt("objective: proximal term (B dp)");
+            if (bfgs_mat.get_m() > 0) bfgs_mat.apply_Hv(_dparams, _gamma, grad);     // :45-48: grad = Bp
+            else { grad.resize(_num_param); _ops->scale(1.0, _dparams, grad); }      // :51
+            loss = 0.5 * _ops->dot(_dparams, grad);                                  // :53
+        }
         if (!Y.empty()) {
             if (_window_dirty) {
+                opt::PhaseTimer pt("objective: window_set");
                 _Yflat.resize(Y.size() * _num_output);
                 size_t t = 0;
                 for (std::list<Vector>::iterator it = Y.begin(); it != Y.end(); ++it, ++t)
@@ -270,11 +309,13 @@ public:
                 _ops->upload(_x, _xd); _ops->upload(_dx, _dxd);
                 _window_dirty = false;
             }
+            opt::PhaseTimer pt("objective: window_eval_dev");
             opt::dv_check(moihgp_window_eval_dev(_gp->handle(), _xd.data(), _dxd.data(), _loss.data(), _g.data(), nullptr, nullptr), "window_eval_dev");   // :61-70
             std::vector<double> l1;
             _ops->download(_loss, l1);
             loss += l1[0];
             _ops->axpy(1.0, _g, grad);
+            _ops->sync();
         }
         _ops->sync();
         return loss;
@@ -342,10 +383,13 @@ public:
     // moihgp_online.h:173-187
     Vector step(const Vector& y) {
         Vector yhat(_num_output), yc(_num_output), xnew(x.size());
-        _obj->push_back(y);
-        for (size_t m = 0; m < _num_output; m++) yc[m] = y[m] - _obj->ma[m];
-        gp32_step3(_moihgp->handle(), x.data(), yc.data(), xnew.data(), yhat.data());               // :178
-        for (size_t m = 0; m < _num_output; m++) yhat[m] += _obj->ma[m];                            // :179
+        { opt::PhaseTimer pt("step: push_back (window, carried state)"); _obj->push_back(y); }
+        {
+            opt::PhaseTimer pt("step: filter the new observation");
+            for (size_t m = 0; m < _num_output; m++) yc[m] = y[m] - _obj->ma[m];
+            gp32_step3(_moihgp->handle(), x.data(), yc.data(), xnew.data(), yhat.data());               // :178
+            for (size_t m = 0; m < _num_output; m++) yhat[m] += _obj->ma[m];                            // :179
+        }
         x = xnew;
         dx.assign(dx.size(), 0.0);                                                                  // :181
         _obj->bfgs_mat = _solver->getBFGSMat();                                                     // :182 (shares the pairs: no copy)

@@ -9,7 +9,11 @@
 #include "common.h"
 #include "../../include/moihgp.h"
 
+#include <map>
+#include <mutex>
 #include <new>
+#include <unordered_map>
+#include <vector>
 
 namespace moihgp {
 namespace {
@@ -134,6 +138,14 @@ static double dv_finish(moihgp_dvec_ctx* c, int is_max) {
     return *c->result;
 }
 
+// cache of freed device vectors (see moihgp_dvec_alloc below)
+static std::mutex g_pool_mutex;
+static std::map<size_t, std::vector<void*>> g_pool;            // bytes -> free blocks of exactly that size
+static std::unordered_map<void*, size_t> g_live;               // every block this file handed out and has not returned to the driver
+static size_t g_pool_bytes = 0;
+constexpr size_t kPoolMinBytes = 1 << 20;                      // smaller blocks go straight back to the driver
+constexpr size_t kPoolMaxBytes = (size_t)32 << 30;             // cached at most (MI355X: 288 GB)
+
 extern "C" {
 
 moihgp_dvec_ctx* moihgp_dvec_ctx_new(void) {
@@ -155,17 +167,65 @@ void moihgp_dvec_ctx_del(moihgp_dvec_ctx* c) {
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
-double* moihgp_dvec_alloc(size_t n) {
+// Device vectors come from a small cache of freed blocks keyed by size: an optimiser over 10^7 parameters frees and allocates its 2 m
+// correction pairs at every solve (the learner hands last solve's matrix to the next objective, moihgp_online.h:182), and hipMalloc /
+// hipFree of 134 MB blocks cost 1-2 ms each -- 80 ms of a 220 ms learner tick at M = L = 4096.  A cached free keeps hipFree's meaning for
+// the caller (everything queued on the device has finished when it returns); moihgp_dvec_trim() hands the cache back to the driver.
+static void* dv_alloc_bytes(size_t bytes, const char* what) {
+    if (bytes == 0) bytes = 1;
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        auto it = g_pool.find(bytes);
+        if (it != g_pool.end() && !it->second.empty()) {
+            void* p = it->second.back();
+            it->second.pop_back();
+            g_pool_bytes -= bytes;
+            return p;
+        }
+    }
     void* p = nullptr;
-    if (hipMalloc(&p, (n ? n : 1) * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); set_last_error("dvec_alloc: out of device memory (%zu doubles)", n); return nullptr; }
-    return static_cast<double*>(p);
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        moihgp_dvec_trim();                                          // the cache may hold what is missing
+        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); set_last_error("%s: out of device memory (%zu bytes)", what, bytes); return nullptr; }
+    }
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        g_live[p] = bytes;
+    }
+    return p;
 }
-unsigned char* moihgp_dvec_alloc_mask(size_t n) {
-    void* p = nullptr;
-    if (hipMalloc(&p, n ? n : 1) != hipSuccess) { (void)hipGetLastError(); set_last_error("dvec_alloc_mask: out of device memory"); return nullptr; }
-    return static_cast<unsigned char*>(p);
+double* moihgp_dvec_alloc(size_t n) { return static_cast<double*>(dv_alloc_bytes(n * sizeof(double), "dvec_alloc")); }
+unsigned char* moihgp_dvec_alloc_mask(size_t n) { return static_cast<unsigned char*>(dv_alloc_bytes(n, "dvec_alloc_mask")); }
+void moihgp_dvec_free(void* p) {
+    if (!p) return;
+    size_t bytes = 0;
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        auto it = g_live.find(p);
+        if (it != g_live.end()) bytes = it->second;
+    }
+    if (bytes != 0 && bytes >= kPoolMinBytes) {
+        (void)hipDeviceSynchronize();                                // (what hipFree would have waited for)
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        if (g_pool_bytes + bytes <= kPoolMaxBytes) { g_pool[bytes].push_back(p); g_pool_bytes += bytes; return; }
+    }
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        g_live.erase(p);
+    }
+    (void)hipFree(p);
 }
-void moihgp_dvec_free(void* p) { if (p) (void)hipFree(p); }
+void moihgp_dvec_trim(void) {
+    std::vector<void*> blocks;
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        for (auto& kv : g_pool) for (void* p : kv.second) { blocks.push_back(p); g_live.erase(p); }
+        g_pool.clear();
+        g_pool_bytes = 0;
+    }
+    for (void* p : blocks) (void)hipFree(p);
+}
 int moihgp_dvec_upload(moihgp_dvec_ctx* c, double* dst_dev, const double* src_host, size_t n) {
     return dv_guard([&] { MOIHGP_HIP_FATAL(hipMemcpyAsync(dst_dev, src_host, n * sizeof(double), hipMemcpyHostToDevice, c->stream)); MOIHGP_HIP_FATAL(hipStreamSynchronize(c->stream)); return 0; });
 }

@@ -1598,6 +1598,39 @@ def test_options_and_stream_release(env):
     assert rel_err_rows(y2[:, :T].cpu().numpy(), o2["yhat"]) < FP64_TIGHT
 
 
+def test_device_vector_blocks_are_kept_for_reuse(env):
+    """moihgp_dvec_alloc / _free (csrc/vecops.hip): a freed block of 1 MB or more is handed out again for the next allocation of its size
+    (the optimiser frees and allocates its correction pairs at every solve), smaller ones go back to the driver, moihgp_dvec_trim empties
+    the cache; a reused block is ordinary device memory."""
+    import ctypes as C
+    lib = env["lib"]
+    lib.moihgp_dvec_alloc.restype = C.c_void_p; lib.moihgp_dvec_alloc.argtypes = [C.c_size_t]
+    lib.moihgp_dvec_free.restype = None; lib.moihgp_dvec_free.argtypes = [C.c_void_p]
+    lib.moihgp_dvec_trim()
+    n = 1 << 18                                           # 2 MB
+    p1 = lib.moihgp_dvec_alloc(n); p2 = lib.moihgp_dvec_alloc(n)
+    assert p1 and p2 and p1 != p2
+    lib.moihgp_dvec_free(p1)
+    p3 = lib.moihgp_dvec_alloc(n)
+    assert p3 == p1                                       # the kept block
+    p4 = lib.moihgp_dvec_alloc(n)
+    assert p4 and p4 not in (p1, p2)
+    t = torch.arange(n, dtype=torch.float64, device="cuda")
+    ctx = lib.moihgp_dvec_ctx_new()
+    back = torch.empty_like(t)
+    assert lib.moihgp_dvec_copy(C.c_void_p(ctx), C.c_void_p(p3), C.c_void_p(t.data_ptr()), C.c_size_t(n)) == 0
+    assert lib.moihgp_dvec_copy(C.c_void_p(ctx), C.c_void_p(back.data_ptr()), C.c_void_p(p3), C.c_size_t(n)) == 0
+    assert lib.moihgp_dvec_sync(ctx) == 0 and torch.equal(back, t)
+    lib.moihgp_dvec_ctx_del(ctx)
+    for p in (p2, p3, p4): lib.moihgp_dvec_free(p)
+    lib.moihgp_dvec_trim()
+    q = lib.moihgp_dvec_alloc(n)                          # after the trim: a fresh block from the driver (may or may not be the same address)
+    assert q
+    lib.moihgp_dvec_free(q)
+    s1 = lib.moihgp_dvec_alloc(16); lib.moihgp_dvec_free(s1)      # small: not kept, nothing to check but that it works
+    lib.moihgp_dvec_trim()
+
+
 def test_device_vector_kernels_vs_numpy(env):
     """csrc/vecops.hip (moihgp_dvec_*): the vector kernels of the device-resident optimiser against numpy, sizes that span one and many
     reduction workgroups, with and without the free-variable mask."""

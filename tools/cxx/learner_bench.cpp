@@ -20,12 +20,18 @@ template <class SS> int run(size_t M, size_t L, size_t W, int nt, bool threading
     size_t evals0 = 0;
     for (int t = 0; t < nt + 1; t++) {
         for (size_t m = 0; m < M; m++) y[m] = std::sin(0.05 * t * (1 + m % 7)) + 0.2 * rnd();
+        if (t == 1 && getenv("LEARNER_BENCH_PHASES")) moihgp::opt::phases().enabled = true;            // (phase table on stderr; tick 0 excluded)
         const auto t0 = clk::now();
         std::vector<double> yhat = learner.step(y);
         const double sec = std::chrono::duration<double>(clk::now() - t0).count();
         if (t > 0) { total += sec; worst = sec > worst ? sec : worst; evals_like += learner.last_iterations; }       // (tick 0 warms up: allocations, first polar factor)
         else evals0 = learner.objective().evaluations;
         if (!std::isfinite(yhat[0])) { fprintf(stderr, "non-finite prediction at tick %d\n", t); return 3; }
+    }
+    if (moihgp::opt::phases().enabled) {
+        fprintf(stderr, "phases over %d ticks (%.1f ms per tick in all):\n", nt, total / nt * 1e3);
+        for (const auto& kv : moihgp::opt::phases().seconds)
+            fprintf(stderr, "  %-48s %8.2f ms per tick  (%ld calls)\n", kv.first.c_str(), kv.second / nt * 1e3, moihgp::opt::phases().calls[kv.first]);
     }
     printf("{\"outputs\": %zu, \"latents\": %zu, \"window\": %zu, \"ticks\": %d, \"seconds_per_tick\": %.6f, \"worst_tick_seconds\": %.6f, "
            "\"lbfgs_iterations_per_tick\": %.2f, \"objective_evaluations_per_tick\": %.2f, \"threading\": %s, \"num_param\": %zu, \"final_objective\": %.10g}\n",
