@@ -1021,6 +1021,131 @@ filter_x_team_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L,
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// A segment WITH GAPS as a scan of the chunks' own affine maps (state dims up to kPairMaxDim; the second pass of the many-latent
+// kernel does the same inline): a missing tick is x <- A x, so a chunk that holds one moves the state by a matrix of its own.  Every lane
+// walks its chunk once with D + 1 vectors, gap-aware -- the response from a zero state, zr, and the D unit start states, mcol[c] = M e_c --
+// and the pairs (M_j, z_j) are scanned over the lanes (Kogge-Stone, lane shifts by ds_bpermute, identity where a lane has no source).
+// On return lane j holds the PREFIX map: the state after chunk j is  mcol x + zr  for a state x entering the segment -- which the
+// caller may not know yet (the team kernel scans while its carry-in is still on its way).
+template <typename T, int DB, int J, int CKC>
+__device__ inline void chunk_maps_scan(uptr<T> cu, const T* __restrict__ c, const T* tile_lane, int lane, T (&mcol)[DB * J][DB * J], T (&zr)[DB * J]) {
+    constexpr int D = DB * J;
+    using Lay = XC<D>;
+    const T ha = c[Lay::HA16 + (lane & 15)], kk = c[Lay::K16 + (lane & 15)];
+    T ablk[J * DB * DB];
+#pragma unroll
+    for (int i = 0; i < J * DB * DB; i++) ablk[i] = cu[Lay::AB + i];
+#pragma unroll
+    for (int cidx = 0; cidx < D; cidx++)
+#pragma unroll
+        for (int i = 0; i < D; i++) mcol[cidx][i] = (i == cidx) ? T(1) : T(0);
+#pragma unroll
+    for (int i = 0; i < D; i++) zr[i] = T(0);
+    auto tick_vec = [&](T (&xv)[D], T yin, bool miss) {
+        T h0 = 0, h1 = 0;
+        static_for<D>([&](auto ii) { constexpr int i = decltype(ii)::value; fmac_bc<i>(i % 2 == 0 ? h0 : h1, ha, xv[i]); });
+        const T v = miss ? T(0) : yin - (h0 + h1);
+        T xn[D];
+#pragma unroll
+        for (int j = 0; j < J; j++)
+#pragma unroll
+            for (int r = 0; r < DB; r++) {
+                T sum = ablk[j * DB * DB + r * DB] * xv[j * DB];
+#pragma unroll
+                for (int q = 1; q < DB; q++) sum = fma(ablk[j * DB * DB + r * DB + q], xv[j * DB + q], sum);
+                xn[j * DB + r] = sum;
+            }
+        static_for<D>([&](auto ii) { fmac_bc<decltype(ii)::value>(xn[decltype(ii)::value], kk, v); });
+#pragma unroll
+        for (int i = 0; i < D; i++) xv[i] = xn[i];
+    };
+#pragma unroll 1
+    for (int k = 0; k < CKC; k++) {
+        const T y = tile_lane[k];
+        const bool miss = (y != y);
+        tick_vec(zr, miss ? T(0) : y, miss);
+#pragma unroll
+        for (int cidx = 0; cidx < D; cidx++) tick_vec(mcol[cidx], T(0), miss);
+    }
+#pragma unroll 1
+    for (int lv = 0; lv < 6; lv++) {
+        const int sh = 1 << lv, addr = ((lane - sh) & 63) * 4;
+        const bool has = lane >= sh;
+        T zp[D], ncol[D][D];
+#pragma unroll
+        for (int i = 0; i < D; i++) { const T m = bperm<T>(addr, zr[i]); zp[i] = has ? m : T(0); }
+#pragma unroll
+        for (int cidx = 0; cidx < D; cidx++) {      // new column c = M (partner's column c)
+            T pc[D];
+#pragma unroll
+            for (int i = 0; i < D; i++) { const T m = bperm<T>(addr, mcol[cidx][i]); pc[i] = has ? m : ((i == cidx) ? T(1) : T(0)); }
+#pragma unroll
+            for (int i = 0; i < D; i++) {
+                T sacc = 0;
+#pragma unroll
+                for (int q = 0; q < D; q++) sacc = fma(mcol[q][i], pc[q], sacc);
+                ncol[cidx][i] = sacc;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < D; q++)
+#pragma unroll
+            for (int i = 0; i < D; i++) zr[i] = fma(mcol[q][i], zp[q], zr[i]);     // z = M z_p + z (old M)
+#pragma unroll
+        for (int cidx = 0; cidx < D; cidx++)
+#pragma unroll
+            for (int i = 0; i < D; i++) mcol[cidx][i] = ncol[cidx][i];
+    }
+}
+
+// The lane's chunk replayed from its true start state xs, gap-aware (ihgp.h:83-87: a missing tick is x <- A x, nothing counted); ticks
+// from n on (beyond the stream) are neither written nor counted.  The filtered means go to the tile, the innovations to acc / nobs.
+template <typename T, int DB, int J, int CKC, bool WRITE, bool NLL>
+__device__ inline void replay_gaps(uptr<T> cu, const T* __restrict__ c, T* tile_lane, int lane, int n, T (&xs)[DB * J], double& acc, unsigned& nobs) {
+    constexpr int D = DB * J;
+    using Lay = XC<D>;
+    const T ha = c[Lay::HA16 + (lane & 15)], kk = c[Lay::K16 + (lane & 15)];
+    T ablk[J * DB * DB];
+#pragma unroll
+    for (int i = 0; i < J * DB * DB; i++) ablk[i] = cu[Lay::AB + i];
+    double part = 0.0;
+    unsigned cnt = 0;
+#pragma unroll 1
+    for (int k = 0; k < CKC; k++) {
+        const bool live = lane * CKC + k < n;
+        const T y = tile_lane[k];
+        const bool miss = (y != y);
+        T h0 = 0, h1 = 0, h2 = 0;
+        static_for<D>([&](auto ii) {
+            constexpr int i = decltype(ii)::value;
+            fmac_bc<i>(i % 3 == 0 ? h0 : (i % 3 == 1 ? h1 : h2), ha, xs[i]);
+        });
+        const T v = miss ? T(0) : y - ((h0 + h1) + h2);
+        if (NLL) {
+            const bool counted = live && !miss;
+            const double vd = counted ? (double)v : 0.0;
+            part = fma(vd, vd, part);
+            cnt += counted ? 1u : 0u;
+        }
+        T xn[D];
+#pragma unroll
+        for (int j = 0; j < J; j++)
+#pragma unroll
+            for (int r = 0; r < DB; r++) {
+                T sum = ablk[j * DB * DB + r * DB] * xs[j * DB];
+#pragma unroll
+                for (int q = 1; q < DB; q++) sum = fma(ablk[j * DB * DB + r * DB + q], xs[j * DB + q], sum);
+                xn[j * DB + r] = sum;
+            }
+        static_for<D>([&](auto ii) { fmac_bc<decltype(ii)::value>(xn[decltype(ii)::value], kk, v); });
+#pragma unroll
+        for (int i = 0; i < D; i++) xs[i] = live ? xn[i] : xs[i];                  // (beyond the stream the state stays: lane jl ends on the stream's last state)
+        if (WRITE && live) tile_lane[k] = xn[0];
+    }
+    if (NLL) { acc += part; nobs += cnt; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // TEAM, CHUNK LENGTH AS A PARAMETER: kTeamCWaves = 8 wavefronts per latent -- two on every SIMD of the compute unit that holds the
 // latent -- and the chunk length chosen so that eight segments of 64 chunks cover the stream (10^4 ticks: CK = 20, 1280-tick segments).
 // Stage stamps of the first versions (tools/team_stamps.py, profiles/r03/team_stamps_*.log) showed the few-latents sweep bound by the
@@ -1143,7 +1268,49 @@ filter_x_teamc_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L
         });
     });
     MOIHGP_STAMP(3);
-    const bool walk = !scan_ok || __builtin_amdgcn_ballot_w64(bad) != 0;                // wave-uniform
+    const bool gaps = __builtin_amdgcn_ballot_w64(bad) != 0;                             // wave-uniform
+    constexpr bool PAIRS = D <= kPairMaxDim;                                           // a segment with gaps as a scan of its chunks' own maps
+    const bool walk = !scan_ok || (gaps && !PAIRS);
+    T xc[D];
+    double acc = 0.0;
+    unsigned nobs = 0;
+    bool done_by_pairs = false;
+    if constexpr (PAIRS) {
+        if (scan_ok && gaps) {
+            // the chunk maps and their prefix products need no carry-in: scanned while it is still on its way; then the state after
+            // every chunk is one D x D product away, this segment's end state is published at once, and one gap-aware replay finishes it
+            T mcol[D][D], zr[D];
+            chunk_maps_scan<T, DB, J, CK>(launder(c), c, tile_lane, lane, mcol, zr);
+            if (wave != 0) {
+                while (__hip_atomic_load(&done[wave - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                for (int i = 0; i < D; i++) cin[i] = eend[(wave - 1) * D + i];
+            }
+            T yj[D];                                                                   // state after this lane's chunk
+#pragma unroll
+            for (int i = 0; i < D; i++) yj[i] = zr[i];
+#pragma unroll
+            for (int q = 0; q < D; q++)
+#pragma unroll
+                for (int i = 0; i < D; i++) yj[i] = fma(mcol[q][i], cin[q], yj[i]);
+            if (lane == 63) {
+#pragma unroll
+                for (int i = 0; i < D; i++) eend[wave * D + i] = yj[i];
+            }
+            wave_lds_fence();
+            if (lane == 0) __hip_atomic_store(&done[wave], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            T xs[D];
+            const int addr1 = ((lane - 1) & 63) * 4;
+#pragma unroll
+            for (int i = 0; i < D; i++) { const T m = bperm<T>(addr1, yj[i]); xs[i] = lane >= 1 ? m : cin[i]; }
+            replay_gaps<T, DB, J, CK, WRITE, NLL>(launder(c), c, tile_lane, lane, n, xs, acc, nobs);
+            const int jl = __builtin_amdgcn_readfirstlane((n - 1) / CK);               // the lane whose chunk holds the stream's / segment's last tick
+#pragma unroll
+            for (int i = 0; i < D; i++) xc[i] = read_lane(xs[i], jl);
+            done_by_pairs = true;
+        }
+    }
+    if (!done_by_pairs) {
     if (!walk) {
         T t[D], sp[2][NSL];
         load_slabs<T, NSL>(pw, lane, sp[0]);
@@ -1173,9 +1340,6 @@ filter_x_teamc_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L
         for (int i = 0; i < D; i++) cin[i] = eend[(wave - 1) * D + i];                  // (uniform address: one broadcast read)
     }
     MOIHGP_STAMP(5);
-    T xc[D];
-    double acc = 0.0;
-    unsigned nobs = 0;
     if (walk) {
         // tick by tick from the true carry-in; outputs into the tile, sum of v^2 and the count in lane 0
 #pragma unroll
@@ -1241,6 +1405,7 @@ filter_x_teamc_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L
         }
         MOIHGP_STAMP(6);
         replay<T, DB, J, WRITE, NLL, true, CK>(rc, tile_lane, carries + wave * D, lane, n, 0, xs, xc, acc, nobs);
+    }
     }
     MOIHGP_STAMP(7);
     // ---- stage out ----
@@ -1392,6 +1557,22 @@ int launch_x_teamc(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cb
     return 0;
 }
 
+// workgroups of the chunk-templated team kernel a compute unit holds at once (registers -- the gap path keeps a D x D map per lane --, LDS, waves),
+// as the runtime computes it; asked once per instantiation and wavefront count
+template <typename T, int DB, int J, int CK>
+int teamc_blocks_per_cu(int nw, size_t smem, bool w, bool n) {
+    static int cache[4][kTeamCWaves + 1] = {};
+    int& slot = cache[(w ? 2 : 0) + (n ? 1 : 0)][nw];
+    if (slot == 0) {
+        const void* fn = w ? (n ? reinterpret_cast<const void*>(filter_x_teamc_kernel<T, DB, J, true, true, CK>) : reinterpret_cast<const void*>(filter_x_teamc_kernel<T, DB, J, true, false, CK>))
+                           : (n ? reinterpret_cast<const void*>(filter_x_teamc_kernel<T, DB, J, false, true, CK>) : reinterpret_cast<const void*>(filter_x_teamc_kernel<T, DB, J, false, false, CK>));
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * nw, smem) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 1; }
+        slot = nb;
+    }
+    return slot;
+}
+
 // the chunk-templated team kernel for a stream of Tlen ticks, if one of its chunk lengths gives 2 .. kTeamCWaves segments that fit a compute unit
 // (returns -1 if none does: the caller goes on to the other forms)
 template <typename T, int DB, int J>
@@ -1406,9 +1587,9 @@ int try_x_teamc(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, 
             const size_t nw = (Tlen + 64 * (size_t)CK - 1) / (64 * (size_t)CK);
             if (nw < 2) return;
             const size_t smem = teamc_smem_bytes<T, DB * J, CK>((int)nw);
-            size_t per_cu = (160 * 1024) / smem;
-            if (per_cu > 2048 / (64 * nw)) per_cu = 2048 / (64 * nw);
-            if (smem > 150 * 1024 || !(team_mode == 1 || L <= 256 * per_cu)) { rc = -2; return; }      // (a longer chunk needs more LDS still)
+            if (smem > 150 * 1024) { rc = -2; return; }                                  // (a longer chunk needs more LDS still)
+            const size_t per_cu = (size_t)teamc_blocks_per_cu<T, DB, J, CK>((int)nw, smem, yhat != nullptr, nll != nullptr);
+            if (!(team_mode == 1 || L <= 256 * per_cu)) { rc = -2; return; }
             rc = launch_x_teamc<T, DB, J, CK>(Ty, Tlen, ld, L, cbT, cb64, tpT, xin, x, yhat, nll, stream, ev0, ev1, ldo, total, (int)nw);
         };
         attempt(std::integral_constant<int, 16>{});
@@ -1437,6 +1618,11 @@ int launch_xd(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, co
     const size_t nseg = (Tlen + SEG - 1) / SEG;
     // few latents, a stream of 2 .. kTeamWaves segments: one workgroup per latent, one wavefront per segment (filter_x_team_kernel), as long as
     // all workgroups are resident at once (LDS: a wave's tile is 9 / 17 KB)
+    // Left to itself (team_mode -1) fp32 at d >= 8 keeps the time split below: measured at 256 latents x 10^4 ticks (tools/smallnan.py,
+    // profiles/r03/smallnan_*.log) it is as fast on streams without gaps (d = 12: 18.4 against 17.8-18.4 us, d = 9: 16.9 against 17.1) and
+    // four times faster on streams with gaps (350 us against 1300-1700: the split's slices work on a gappy latent side by side, a team
+    // kernel walks its segments one after the other, and the chunk-map scan that fixes this up to d = 6 needs a D x D map per lane).
+    if (team_mode == -1 && DB * J > kPairMaxDim && sizeof(T) == 4) team_mode = 0;
     // ... eight wavefronts and the chunk length to match, where the replay takes the chunk length (fp32; fp64 up to d = 8)
     // (team_mode 2 = the 32-tick team kernel only)
     if (team_mode != 0 && team_mode != 2 && force_slices == 0) {
