@@ -84,8 +84,10 @@ struct moihgp_gp {
     int polar_its = 0;         // Newton-Schulz steps of the last device polar factor (0: single-workgroup kernel / none yet)
     double* dhp = nullptr;     // [L][gradx_hp_len(d)] HA AKHA^k rows of the stacked models' time-parallel gradient sweep (on first use)
     double* dxscratch = nullptr; // stacked kernels, few latents: per-slice NLL partials
-    double* dtp64 = nullptr;     // stacked kernels, fewer than 1024 latents: scan powers of the chunk-templated team kernel (launch_team_powers), per update
+    double* dtp64 = nullptr;     // fewer than 1024 latents: scan powers of the chunk-templated team kernel (launch_team_powers), per update
     float* dtp32 = nullptr;
+    double* dxc64 = nullptr;     // the reference's own models, fewer than 1024 latents: their tables in the stacked layout (launch_xc_from_cb), per update
+    float* dxc32 = nullptr;
     double* cbd64 = nullptr;     // stacked kernels: sensitivity blocks (XD), fp64; filled once somebody asks for gradients
     bool sens_wanted = false, sens_valid = false;
     bool U_host_stale = false; // the device holds a newer U than the host mirror (fetched on getParams)
@@ -114,7 +116,7 @@ struct moihgp_gp {
 
 static void gp_free(moihgp_gp* g) {
     if (!g) return;
-    void* ptrs[] = {g->dU, g->dS, g->dsqrtS, g->dinvsqrtS, g->dsigma, g->dparams, g->cb64, g->cb32, g->dx, g->dpart, g->dTy, g->dUty, g->dTyhat, g->dloss, g->dgrad, g->dscratch, g->dwork, g->dpolar, g->dfallback, g->dwin, g->dunstable, g->dxscratch, g->cbd64, g->dU32, g->dhp, g->dlink, g->dwinmiss, g->dtp64, g->dtp32};
+    void* ptrs[] = {g->dU, g->dS, g->dsqrtS, g->dinvsqrtS, g->dsigma, g->dparams, g->cb64, g->cb32, g->dx, g->dpart, g->dTy, g->dUty, g->dTyhat, g->dloss, g->dgrad, g->dscratch, g->dwork, g->dpolar, g->dfallback, g->dwin, g->dunstable, g->dxscratch, g->cbd64, g->dU32, g->dhp, g->dlink, g->dwinmiss, g->dtp64, g->dtp32, g->dxc64, g->dxc32};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (void* p : g->pinned) (void)hipHostUnregister(p);
@@ -175,7 +177,18 @@ static void run_ihgp_update(moihgp_gp* g) {
             launch_team_powers(g->kernel, g->cb64, g->L, g->dtp64, g->dtp32, g->stream);
         }
     }
-    else launch_ihgp_update(g->kernel, g->d, g->dt, g->dparams, g->L, g->cb64, g->cb32, g->dunstable, g->stream);
+    else {
+        launch_ihgp_update(g->kernel, g->d, g->dt, g->dparams, g->L, g->cb64, g->cb32, g->dunstable, g->stream);
+        if (g->L < 1024) {
+            // the few-latents team kernel of the stacked filter serves these models too (one component): its tables, from the CB blocks just written
+            if (!g->dxc64) {
+                g->dxc64 = dev_alloc<double>(g->L * (size_t)xc_size(g->d)); g->dxc32 = dev_alloc<float>(g->L * (size_t)xc_size(g->d));
+                g->dtp64 = dev_alloc<double>(g->L * team_powers_elems(g->d)); g->dtp32 = dev_alloc<float>(g->L * team_powers_elems(g->d));
+            }
+            launch_xc_from_cb(g->d, g->cb64, g->L, g->dxc64, g->dxc32, g->stream);
+            launch_team_powers(g->kernel | (1 << 4), g->dxc64, g->L, g->dtp64, g->dtp32, g->stream);
+        }
+    }
     MOIHGP_HIP_FATAL(hipMemcpyAsync(g->n_unstable, g->dunstable, 2 * sizeof(int), hipMemcpyDeviceToHost, g->stream));
     MOIHGP_HIP_FATAL(hipStreamSynchronize(g->stream));
 }
@@ -694,6 +707,12 @@ static int filter_stream_io_impl(moihgp_gp* gp, int dtype, const void* Ty, size_
                                         gp->dxscratch, slen, gp->opt_filter_split /* test hook: 1 = off, n = slices */, ld_out, gp->L >= 1024 ? gp->dfallback : nullptr, gp->dlink, nll ? nll_total : nullptr,
                                         gp->opt_filter_maxlinks, gp->opt_filter_team, gp->dtp64, gp->dtp32);
         return rc;
+    }
+    // few latents, streams of 2 .. 8 segments: one workgroup per latent, eight wavefronts (the stacked filter's team kernel, recursion_x.hip)
+    if (gp->dxc64 && gp->opt_filter_team != 0 && gp->opt_filter_split == 0 && variant == 0) {
+        const int rc = launch_filter_teamc_plain(gp->d, dtype, Ty, T, ld, gp->L, gp->dxc64, gp->dxc32, gp->dtp64, gp->dtp32, x_in, x, yhat, nll, (hipStream_t)stream, e0, e1,
+                                                 ld_out, nll ? nll_total : nullptr, gp->opt_filter_team);
+        if (rc != -1) return rc;
     }
     // time split across the wavefronts of a workgroup when there are too few latents to fill the chip
     int nsplit = 1, nbig = 1; size_t Tslice = T;

@@ -91,7 +91,7 @@ struct XD {
 };
 constexpr int xd_size(int d, int P) { return (P * (2 * d * d + 2 * d) + 2 * P + 3) / 4 * 4; }
 constexpr int xc_size(int d) {
-    return d == 4 ? XC<4>::SIZE : d == 6 ? XC<6>::SIZE : d == 8 ? XC<8>::SIZE : d == 9 ? XC<9>::SIZE : d == 12 ? XC<12>::SIZE : 0;
+    return d == 2 ? XC<2>::SIZE : d == 3 ? XC<3>::SIZE : d == 4 ? XC<4>::SIZE : d == 6 ? XC<6>::SIZE : d == 8 ? XC<8>::SIZE : d == 9 ? XC<9>::SIZE : d == 12 ? XC<12>::SIZE : 0;
 }
 // kernel id = base | (J << 4) (include/moihgp.h); J == 0 for the reference's two models
 inline int kernel_base(int kernel) { return kernel & 15; }
@@ -126,6 +126,11 @@ void launch_ihgp_update(int kernel, int d, double dt, const double* params_dev, 
 // params_dev [n][2J+1] = (magnitude_j, lengthscale_j) x J, noise.
 void launch_stack_update(int kernel, double dt, const double* params_dev, size_t n, double* cb64, float* cb32,
                          double* cbd64 /* [n] sensitivity blocks XD, or NULL to skip them */, int* n_unstable, hipStream_t stream);
+// stationary_x.hip: the reference's own models (d = 2, 3) in the stacked layout, for the few-latents team kernel: [n][xc_size(d)] from the CB blocks
+void launch_xc_from_cb(int d, const double* cb64, size_t n, double* xc64, float* xc32, hipStream_t stream);
+// stack_dispatch.hip: the team kernel for those models, if the stream and the bank suit it (returns -1 if not: the caller carries on)
+int launch_filter_teamc_plain(int d, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* xc64, const float* xc32, const double* tp64, const float* tp32,
+                              const void* xin, void* x, void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, size_t ldo, double* total, int team_mode);
 // recursion_x.hip: scan powers of the chunk-templated team kernel (few latents), [L][5][team_powers_elems(d)] in both precisions; after every launch_stack_update
 constexpr size_t team_powers_elems(int d) { return 5 * (size_t)(7 * ((d * d + 15) / 16 * 16) + 16); }
 void launch_team_powers(int kernel, const double* cb64, size_t L, double* tp64, float* tp32, hipStream_t stream);

@@ -19,10 +19,11 @@
 // Roofline: VALU-bound for D >= 9 in fp64 (per tick about D*DB + 3D FMA replay + 7 D^2 / 32 scan + D response
 // against 16 B of traffic), near the HBM / VALU balance point for D = 6.  DESIGN.md 3.7.
 //
-// One translation unit per stacked model: the Makefile compiles this file six times, -DMOIHGP_X_TU=22, 23, 24, 32, 33, 34 (= DB J), in
+// One translation unit per model: the Makefile compiles this file eight times, -DMOIHGP_X_TU=22, 23, 24, 32, 33, 34 (= DB J; 21, 31: the
+// reference's own models, team kernel only), in
 // parallel (one unit with all six took eight minutes); stack_dispatch.hip holds the dispatcher over the units' entries.
 #ifndef MOIHGP_X_TU
-#error "compile with -DMOIHGP_X_TU=<DB J> (22, 23, 24, 32, 33, 34): csrc/Makefile"
+#error "compile with -DMOIHGP_X_TU=<DB J> (21, 31, 22, 23, 24, 32, 33, 34): csrc/Makefile"
 #endif
 #include "x_common.h"
 #include <hip/hip_ext.h>
@@ -1664,6 +1665,12 @@ int MOIHGP_X_CAT(launch_filter_x_, MOIHGP_X_TU)(int dtype, const void* Ty, size_
                            double* scratch, size_t scratch_len, int force_slices, size_t ldo, int* link_flags, double* link_state, double* total, int max_links, int team_mode,
                            const double* tp64, const float* tp32) {
     constexpr int DBB = MOIHGP_X_TU / 10, JJ = MOIHGP_X_TU % 10;
+    if constexpr (JJ == 1) {
+        // the reference's own models (one component): only the few-latents team kernel is built for them here -- everything else is recursion.hip's
+        if (L == 0 || team_mode == 0 || force_slices != 0) return -1;
+        return dtype == 0 ? try_x_teamc<double, DBB, 1>(Ty, T, ld, L, cb64, cb64, tp64, xin, x, yhat, nll, stream, ev0, ev1, ldo ? ldo : ld, total, team_mode)
+                          : try_x_teamc<float, DBB, 1>(Ty, T, ld, L, cb32, cb64, tp32, xin, x, yhat, nll, stream, ev0, ev1, ldo ? ldo : ld, total, team_mode);
+    } else
     return dtype == 0 ? launch_xd<double, DBB, JJ>(Ty, T, ld, L, cb64, cb64, xin, x, yhat, nll, stream, ev0, ev1, scratch, scratch_len, force_slices, ldo, link_flags, link_state, total, max_links, team_mode, tp64)
                       : launch_xd<float, DBB, JJ>(Ty, T, ld, L, cb32, cb64, xin, x, yhat, nll, stream, ev0, ev1, scratch, scratch_len, force_slices, ldo, link_flags, link_state, total, max_links, team_mode, tp32);
 }

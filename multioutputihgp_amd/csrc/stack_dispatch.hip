@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(64) team_powers_kernel(const double* __restric
                               void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, double* scratch, size_t scratch_len,     \
                               int force_slices, size_t ldo, int* link_flags, double* link_state, double* total, int max_links, int team_mode,       \
                               const double* tp64, const float* tp32)
-MOIHGP_X_DECL(22); MOIHGP_X_DECL(23); MOIHGP_X_DECL(24); MOIHGP_X_DECL(32); MOIHGP_X_DECL(33); MOIHGP_X_DECL(34);
+MOIHGP_X_DECL(21); MOIHGP_X_DECL(31); MOIHGP_X_DECL(22); MOIHGP_X_DECL(23); MOIHGP_X_DECL(24); MOIHGP_X_DECL(32); MOIHGP_X_DECL(33); MOIHGP_X_DECL(34);
 #undef MOIHGP_X_DECL
 
 void launch_team_powers(int kernel, const double* cb64, size_t L, double* tp64, float* tp32, hipStream_t stream) {
@@ -82,6 +82,8 @@ void launch_team_powers(int kernel, const double* cb64, size_t L, double* tp64, 
     const int d = (kernel_base(kernel) == 0 ? 2 : 3) * kernel_stack(kernel);
     dim3 grid((unsigned)L, kTeamNck);
     switch (d) {
+        case 2: hipLaunchKernelGGL(team_powers_kernel<2>, grid, dim3(64), 0, stream, cb64, tp64, tp32); break;
+        case 3: hipLaunchKernelGGL(team_powers_kernel<3>, grid, dim3(64), 0, stream, cb64, tp64, tp32); break;
         case 4: hipLaunchKernelGGL(team_powers_kernel<4>, grid, dim3(64), 0, stream, cb64, tp64, tp32); break;
         case 6: hipLaunchKernelGGL(team_powers_kernel<6>, grid, dim3(64), 0, stream, cb64, tp64, tp32); break;
         case 8: hipLaunchKernelGGL(team_powers_kernel<8>, grid, dim3(64), 0, stream, cb64, tp64, tp32); break;
@@ -90,6 +92,13 @@ void launch_team_powers(int kernel, const double* cb64, size_t L, double* tp64, 
         default: break;
     }
     MOIHGP_HIP_FATAL(hipGetLastError());
+}
+
+int launch_filter_teamc_plain(int d, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* xc64, const float* xc32, const double* tp64, const float* tp32,
+                              const void* xin, void* x, void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, size_t ldo, double* total, int team_mode) {
+    if (!xc64 || !tp64) return -1;
+    return d == 2 ? launch_filter_x_21(dtype, Ty, T, ld, L, xc64, xc32, xin, x, yhat, nll, stream, ev0, ev1, nullptr, 0, 0, ldo, nullptr, nullptr, total, -1, team_mode, tp64, tp32)
+                  : launch_filter_x_31(dtype, Ty, T, ld, L, xc64, xc32, xin, x, yhat, nll, stream, ev0, ev1, nullptr, 0, 0, ldo, nullptr, nullptr, total, -1, team_mode, tp64, tp32);
 }
 
 int launch_filter_stream_x(int kernel, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* cb64, const float* cb32,

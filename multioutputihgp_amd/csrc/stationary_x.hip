@@ -369,12 +369,70 @@ __global__ void __launch_bounds__(64) stack_update_kernel(double dt, const doubl
     }
 }
 
+// The few-latents team kernel of recursion_x.hip for the reference's OWN models (Matern-3/2, d = 2; Matern-5/2, d = 3: one component, J = 1):
+// its tables in the stacked layout, from the matrices IHGP::update has already put into the latent's CB block (stationary.hip) -- the same
+// AKHA, K, A, HA, S, log S to the last bit, so the two paths filter with one model; added here: the 32-row response table, the diagonal
+// block, the padded slabs and the coefficient pairs of the packed fp32 replay.  SP / NLEV stay zero: only the team kernel reads these
+// blocks, and it takes its scan powers from team_powers_kernel's table.
+template <int D>
+__global__ void __launch_bounds__(64) xc_from_cb_kernel(const double* __restrict__ cb, size_t n, double* __restrict__ xc64, float* __restrict__ xc32) {
+    constexpr int NN = D * D, DB = D, J = 1;
+    using C = CB<D>;
+    using L = XC<D>;
+    __shared__ double sAKHA[NN], sA[NN], sK[D], sHA[D], sV1[D], sG[kChunkX * D];
+    const size_t l = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (l >= n) return;
+    const double* __restrict__ c = cb + l * C::SIZE;
+    for (int e = lane; e < NN; e += 64) { sAKHA[e] = c[C::AKHA + e]; sA[e] = c[C::A + e]; }
+    if (lane < D) { sK[lane] = c[C::K + lane]; sHA[lane] = c[C::HA + lane]; sV1[lane] = c[C::K + lane]; }
+    lds_sync();
+    bool ok = true, ok32 = true;
+    for (int k = kChunkX - 1; k >= 0; k--) {                           // g_k = AKHA^(31-k) K, as stack_update_kernel forms it
+        if (lane < D) { sG[k * D + lane] = sV1[lane]; ok = ok && (fabs(sV1[lane]) < 1e150); ok32 = ok32 && (fabs(sV1[lane]) < 1e18); }
+        wmv<D>(sAKHA, sV1, sV1, lane);
+    }
+    ok = __builtin_amdgcn_ballot_w64(!ok) == 0;
+    ok32 = __builtin_amdgcn_ballot_w64(!ok32) == 0;
+    double* o64 = xc64 + l * L::SIZE;
+    float* o32 = xc32 + l * L::SIZE;
+    for (int e = lane; e < L::SIZE; e += 64) {                         // every entry of the block exactly once
+        double v = 0.0, v32 = 0.0;
+        bool split = false;
+        if (e < L::K) v = sAKHA[e - L::AKHA];
+        else if (e < L::A) v = sK[e - L::K];
+        else if (e < L::HA) v = sA[e - L::A];
+        else if (e < L::S) v = sHA[e - L::HA];
+        else if (e == L::S) v = c[C::S];
+        else if (e == L::LOGS) v = c[C::LOGS];
+        else if (e == L::SCANOK) { v = ok ? 1.0 : 0.0; v32 = ok32 ? 1.0 : 0.0; split = true; }
+        else if (e >= L::AB && e < L::HA16) { const int i = e - L::AB; v = i < DB * DB ? sA[i] : 0.0; }
+        else if (e >= L::HA16 && e < L::K16) { const int i = e - L::HA16; v = i < D ? sHA[i] : 0.0; }
+        else if (e >= L::K16 && e < L::G) { const int i = e - L::K16; v = i < D ? sK[i] : 0.0; }
+        else if (e >= L::G && e < L::SP) { const int i = e - L::G; v = i < kChunkX * D ? sG[i] : 0.0; }
+        else if (e >= L::PK) {                                         // coefficient pairs [A_rq | HA_q | K_r] of the one block, paired with zeros
+            constexpr int PB = DB * DB + 2 * DB;
+            const int ee = e - L::PK, pr = ee / 2, half = ee % 2;
+            if (half == 0 && pr < PB) v = pr < DB * DB ? sA[pr] : (pr < DB * DB + DB ? sHA[pr - DB * DB] : sK[pr - DB * DB - DB]);
+        }
+        o64[e] = v;
+        o32[e] = (float)(split ? v32 : v);
+    }
+}
+
 template <int DB, int J>
 void launch_t(double dt, const double* params, size_t n, double* cb64, float* cb32, double* cbd64, int* n_unstable, hipStream_t s) {
     hipLaunchKernelGGL((stack_update_kernel<DB, J>), dim3((unsigned)n), dim3(64), 0, s, dt, params, n, cb64, cb32, cbd64, n_unstable);
 }
 
 }  // namespace
+
+void launch_xc_from_cb(int d, const double* cb64, size_t n, double* xc64, float* xc32, hipStream_t stream) {
+    if (n == 0) return;
+    if (d == 2) hipLaunchKernelGGL(xc_from_cb_kernel<2>, dim3((unsigned)n), dim3(64), 0, stream, cb64, n, xc64, xc32);
+    else hipLaunchKernelGGL(xc_from_cb_kernel<3>, dim3((unsigned)n), dim3(64), 0, stream, cb64, n, xc64, xc32);
+    MOIHGP_HIP_FATAL(hipGetLastError());
+}
 
 void launch_stack_update(int kernel, double dt, const double* params_dev, size_t n, double* cb64, float* cb32, double* cbd64,
                          int* n_unstable, hipStream_t stream) {

@@ -89,6 +89,6 @@ def test_no_dpp_hazard_in_device_code(hip_built):
     import importlib.util
     spec = importlib.util.spec_from_file_location("check_dpp_hazard", os.path.join(ROOT, "tools", "check_dpp_hazard.py"))
     mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
-    for obj in ("recursion_x_22.o", "recursion_x_23.o", "recursion_x_24.o", "recursion_x_32.o", "recursion_x_33.o", "recursion_x_34.o", "grad_scan_x.o"):
+    for obj in ("recursion_x_21.o", "recursion_x_31.o", "recursion_x_22.o", "recursion_x_23.o", "recursion_x_24.o", "recursion_x_32.o", "recursion_x_33.o", "recursion_x_34.o", "grad_scan_x.o"):
         hazards, ndpp = mod.scan(mod.disassemble(os.path.join(ROOT, "build", "obj", obj)))
         assert ndpp > 1000 and hazards == [], (obj, hazards[:5])
