@@ -74,6 +74,18 @@ def synth_params(L, lo, rng, kernel="Matern52ss"):
     return np.column_stack(cols + [rng.uniform(0.05, 0.2, L)])
 
 
+def filter_kernel_name(bank, L, T, dtype):
+    """Name of the kernel the library's own selection takes for this sweep (csrc/recursion_x.hip launch_xd, csrc/capi.cpp): a label for the
+    JSON line, checked against the rocprofv3 summaries under profiles/."""
+    few = L <= 256 and 1024 < T <= 16384
+    fp32 = dtype == torch.float32
+    if bank.stacked:
+        if few and not (fp32 and bank.d > 6):
+            return "filter_x_teamc_kernel" if (fp32 or bank.d <= 8) else "filter_x_team_kernel"
+        return "filter_x_kernel"
+    return "filter_x_teamc_kernel" if (few and bank.d == 3) else "filter_scan_kernel"
+
+
 def synth_stream(L, lo, T, dtype, device, seed):
     """Ty[l][t] = sin(0.05 t (1 + l mod 7)) + 0.1 N(0,1), generated on the device."""
     from multioutputihgp_amd.streams import alloc_stream
@@ -467,7 +479,7 @@ def filter_row(name, device, passes=20, warm=150):
     row = {"workload": desc2, "state_dim": b2.d, "dtype": "f32" if dt2 == torch.float32 else "f64", "warmup": warm, "steps": passes,
            "pass": "sweep only (BASELINE.json: filter only)" if sweep_only else "sweep + the pass's NLL total (one-workgroup kernel behind it), as the headline",
            "ms_per_step": wall2 * 1e3, "value": L2 * T2 / wall2,
-           "kernel": "filter_x_team_kernel" if (b2.stacked and L2 <= 256) else ("filter_x_kernel" if b2.stacked else "filter_scan_kernel"), "kernel_ms": ms2,
+           "kernel": filter_kernel_name(b2, L2, T2, dt2), "kernel_ms": ms2,
            "steps_per_s_kernel_only": L2 * T2 / (ms2 * 1e-3), "bound": "hbm",
            "achieved_GBps": alg / (ms2 * 1e-3) / 1e9, "frac": alg / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
            ("kernel_ms_with_total_between_sweeps" if sweep_only else "kernel_ms_sweeps_back_to_back"): ms_o,
@@ -711,7 +723,7 @@ def main():
                        "layout": "series-major [L][ld], HBM-resident", "sharding": f"latents x{world}, NLL scalar all-reduce per pass" + ("" if world == 1 else (" (stream-ordered)" if args.sync_allreduce else " (overlapped with the next pass)"))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": ("filter_x_team_kernel" if L <= 256 and 2048 < T <= 16384 else "filter_x_kernel") if bank.stacked else "filter_scan_kernel", "kernel_ms": kern_ms,
+                         "kernel": filter_kernel_name(bank, L, T, dtype), "kernel_ms": kern_ms,
                          "kernel_ms_from": f"HIP event pairs on {len(kern_samples)} of the {args.steps * nslab} launches of the timed region",
                          "algorithmic_bytes_per_launch": alg_bytes, "frac_of_measured_copy_peak": achieved / HBM_COPY_GBPS,
                          # the other wall (mode F is 2 d^2 + 2 d flop per step; the d = 12 fp64 configuration sits on this one)

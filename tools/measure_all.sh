@@ -12,7 +12,7 @@ for c in c3 c2 c3f64 c2d6 c3d6 c3d6f64 c5 c4 c1 c3learn c3grad c5grad c3loop; do
 done
 for c in c3 c5 c2 c2d6 c3d6 c3d6f64; do
   rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_$c/kt" -o out -- python3 bench.py --config $c --steps 200 --warmup 150 --no-cpu --no-cold > "$out/${tag}_${c}_bench_under_rocprof.json" 2> "$out/prof_$c.err"
-  python3 profiles/summarize.py "$out/prof_$c" "$out" "${tag}_$c" $([ $c = c3 -o $c = c2 ] && echo filter_scan || echo filter_x) > /dev/null
+  python3 profiles/summarize.py "$out/prof_$c" "$out" "${tag}_$c" $([ $c = c3 ] && echo filter_scan || echo filter_x) > /dev/null
   echo "rocprof $c done"
 done
 for c in c3 c5 c2 c2d6 c3d6 c3d6f64; do
