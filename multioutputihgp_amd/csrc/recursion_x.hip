@@ -1590,7 +1590,10 @@ int try_x_teamc(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, 
             const size_t smem = teamc_smem_bytes<T, DB * J, CK>((int)nw);
             if (smem > 150 * 1024) { rc = -2; return; }                                  // (a longer chunk needs more LDS still)
             const size_t per_cu = (size_t)teamc_blocks_per_cu<T, DB, J, CK>((int)nw, smem, yhat != nullptr, nll != nullptr);
-            if (!(team_mode == 1 || L <= 256 * per_cu)) { rc = -2; return; }
+            // up to TWO rounds of workgroups over the 256 compute units (measured at 10^4 ticks, profiles/r03/midL_team_vs_split.log: d = 3 fp64 at 320 /
+            // 384 / 512 latents 17.7 / 18.4 / 20.4 us against 22.7 / 24.0 / 27.0 with the time split, d = 6 fp32 at 512 19.0 against 22.5; three rounds are
+            // level, four lose)
+            if (!(team_mode == 1 || L <= 2 * 256 * per_cu)) { rc = -2; return; }
             rc = launch_x_teamc<T, DB, J, CK>(Ty, Tlen, ld, L, cbT, cb64, tpT, xin, x, yhat, nll, stream, ev0, ev1, ldo, total, (int)nw);
         };
         attempt(std::integral_constant<int, 16>{});
