@@ -171,8 +171,9 @@ int moihgp_release_stream(moihgp_gp* gp, void* stream);
 /* Options of a handle (tuning / test hooks; defaults come from the environment variables of the same meaning, read ONCE when the
  * handle is created -- nothing below consults the environment per launch):
  *   "filter_split"    0 = automatic time split for few latents, 1 = off, n > 1 = n slices      (env MOIHGP_FILTER_SPLIT)
- *   "filter_team"     stacked models, few latents: -1 = automatic, 0 = never, 1 = always take a one-workgroup-per-latent kernel when the
- *                     stream fits one (2 .. 10 segments of 1024 ticks, or 2 .. 8 of 2048), 2 = the 2048-tick form only   (env MOIHGP_FILTER_TEAM)
+ *   "filter_team"     few latents: -1 = automatic, 0 = never, 1 = always take a one-workgroup-per-latent kernel when the stream fits one
+ *                     (2 .. 8 segments of 1024 .. 2048 ticks), 2 = the 2048-tick form only (stacked models)        (env MOIHGP_FILTER_TEAM)
+ *   "filter_plain_x"  Matern-3/2 and -5/2 through the stacked filter's kernels (one component): -1 = automatic, 0 = never, 1 = always
  *   "filter_maxlinks" -1 = automatic; chunks with a gap per segment that the stacked filter's second pass takes as broken links
  *                                                                                               (env MOIHGP_FILTER_MAXLINKS)
  *   "filter_variant"  kernel tiling probes; accepted only by a library built with -DMOIHGP_TUNING (make TUNING=1), rc 1 otherwise:

@@ -77,7 +77,7 @@ struct moihgp_gp {
     double* dlink = nullptr;   // [L][144] stacked filter: where the second (broken-link) pass resumes a latent (on first use)
     bool hp_valid = false;     // dhp matches the current tables (cleared by every IHGP::update)
     // options (moihgp_set_option; defaults from the environment, read once in gp_create)
-    int opt_filter_split = 0, opt_filter_variant = 0, opt_filter_maxlinks = -1, opt_filter_team = -1;
+    int opt_filter_split = 0, opt_filter_variant = 0, opt_filter_maxlinks = -1, opt_filter_team = -1, opt_filter_plain_x = -1;
     int* dwinmiss = nullptr;   // [W] window objective: 1 where the tick's observation vector holds NaN (on first use)
     size_t winmiss_cap = 0;
     bool win_has_nan = false;
@@ -179,13 +179,11 @@ static void run_ihgp_update(moihgp_gp* g) {
     }
     else {
         launch_ihgp_update(g->kernel, g->d, g->dt, g->dparams, g->L, g->cb64, g->cb32, g->dunstable, g->stream);
+        // the stacked filter's kernels serve these models too (one component): their tables in its layout, from the CB blocks just written
+        if (!g->dxc64) { g->dxc64 = dev_alloc<double>(g->L * (size_t)xc_size(g->d)); g->dxc32 = dev_alloc<float>(g->L * (size_t)xc_size(g->d)); }
+        launch_xc_from_cb(g->d, g->cb64, g->L, g->dxc64, g->dxc32, g->stream);
         if (g->L < 1024) {
-            // the few-latents team kernel of the stacked filter serves these models too (one component): its tables, from the CB blocks just written
-            if (!g->dxc64) {
-                g->dxc64 = dev_alloc<double>(g->L * (size_t)xc_size(g->d)); g->dxc32 = dev_alloc<float>(g->L * (size_t)xc_size(g->d));
-                g->dtp64 = dev_alloc<double>(g->L * team_powers_elems(g->d)); g->dtp32 = dev_alloc<float>(g->L * team_powers_elems(g->d));
-            }
-            launch_xc_from_cb(g->d, g->cb64, g->L, g->dxc64, g->dxc32, g->stream);
+            if (!g->dtp64) { g->dtp64 = dev_alloc<double>(g->L * team_powers_elems(g->d)); g->dtp32 = dev_alloc<float>(g->L * team_powers_elems(g->d)); }
             launch_team_powers(g->kernel | (1 << 4), g->dxc64, g->L, g->dtp64, g->dtp32, g->stream);
         }
     }
@@ -676,6 +674,12 @@ int moihgp_filter_stream(moihgp_gp* gp, int dtype, const void* Ty, size_t T, siz
     return moihgp_filter_stream_io(gp, dtype, Ty, T, ld, x, x, yhat, nll, nullptr, stream);
 }
 
+// Which sweeps of the reference's own models go through the stacked filter's kernels when nobody says (option filter_plain_x = -1).
+static bool plain_x_by_default(int d, int dtype, size_t L, size_t T) {
+    (void)d; (void)dtype; (void)L; (void)T;
+    return false;
+}
+
 static int filter_stream_io_impl(moihgp_gp* gp, int dtype, const void* Ty, size_t T, size_t ld, const void* x_in, void* x, void* yhat, double* nll,
                             double* nll_total, void* stream, size_t ld_out = 0) {
     if (int rc = check_stream_args(gp, dtype, Ty, T, ld, x)) return rc;
@@ -699,11 +703,17 @@ static int filter_stream_io_impl(moihgp_gp* gp, int dtype, const void* Ty, size_
         e1 = gp->prof_ev[2 * gp->prof_n + 1];
         gp->prof_n++;
     }
-    if (kernel_stack(gp->kernel)) {
+    // the reference's own models through the stacked filter's kernels (one component; tables from launch_xc_from_cb)
+    const bool plain_x = !kernel_stack(gp->kernel) && gp->dxc64 && variant == 0 && gp->opt_filter_split == 0 &&
+                         (gp->opt_filter_plain_x == 1 || (gp->opt_filter_plain_x == -1 && plain_x_by_default(gp->d, dtype, gp->L, T)));
+    if (kernel_stack(gp->kernel) || plain_x) {
+        const int kid = plain_x ? (gp->kernel | (1 << 4)) : gp->kernel;
+        const double* xb64 = plain_x ? gp->dxc64 : gp->cb64;
+        const float* xb32 = plain_x ? gp->dxc32 : gp->cb32;
         const size_t slen = gp->L < 1024 ? gp->L * 16 : 0;              // per-slice NLL partials of the time split (few latents only)
         if (slen && !gp->dxscratch) gp->dxscratch = dev_alloc<double>(slen);
         if (gp->L >= 1024 && !gp->dlink) gp->dlink = dev_alloc<double>(gp->L * 144);     // hand-over records of the second (broken-link) pass
-        int rc = launch_filter_stream_x(gp->kernel, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cb32, x_in, x, yhat, nll, (hipStream_t)stream, e0, e1,
+        int rc = launch_filter_stream_x(kid, dtype, Ty, T, ld, gp->L, xb64, xb32, x_in, x, yhat, nll, (hipStream_t)stream, e0, e1,
                                         gp->dxscratch, slen, gp->opt_filter_split /* test hook: 1 = off, n = slices */, ld_out, gp->L >= 1024 ? gp->dfallback : nullptr, gp->dlink, nll ? nll_total : nullptr,
                                         gp->opt_filter_maxlinks, gp->opt_filter_team, gp->dtp64, gp->dtp32);
         return rc;
@@ -995,6 +1005,7 @@ int moihgp_set_option(moihgp_gp* gp, const char* name, long value) {
     if (!gp || !name) { set_last_error("set_option: null argument"); return 1; }
     const std::string n(name);
     if (n == "filter_split") { if (value < 0 || value > 64) { set_last_error("filter_split: 0 (automatic), 1 (off) or a slice count"); return 1; } gp->opt_filter_split = (int)value; return 0; }
+    if (n == "filter_plain_x") { if (value < -1 || value > 1) { set_last_error("filter_plain_x: -1 (automatic), 0 (never), 1 (always: the stacked filter's kernels for Matern-3/2 and -5/2)"); return 1; } gp->opt_filter_plain_x = (int)value; return 0; }
     if (n == "filter_team") { if (value < -1 || value > 2) { set_last_error("filter_team: -1 (automatic), 0 (never), 1 (whenever the stream fits), 2 (the 32-tick-chunk form only)"); return 1; } gp->opt_filter_team = (int)value; return 0; }
     if (n == "filter_maxlinks") { if (value < -1 || value > 64) { set_last_error("filter_maxlinks: -1 (automatic) .. 64"); return 1; } gp->opt_filter_maxlinks = (int)value; return 0; }
     if (n == "filter_variant") {

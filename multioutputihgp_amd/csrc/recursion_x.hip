@@ -1669,11 +1669,13 @@ int MOIHGP_X_CAT(launch_filter_x_, MOIHGP_X_TU)(int dtype, const void* Ty, size_
                            const double* tp64, const float* tp32) {
     constexpr int DBB = MOIHGP_X_TU / 10, JJ = MOIHGP_X_TU % 10;
     if constexpr (JJ == 1) {
-        // the reference's own models (one component): only the few-latents team kernel is built for them here -- everything else is recursion.hip's
-        if (L == 0 || team_mode == 0 || force_slices != 0) return -1;
-        return dtype == 0 ? try_x_teamc<double, DBB, 1>(Ty, T, ld, L, cb64, cb64, tp64, xin, x, yhat, nll, stream, ev0, ev1, ldo ? ldo : ld, total, team_mode)
-                          : try_x_teamc<float, DBB, 1>(Ty, T, ld, L, cb32, cb64, tp32, xin, x, yhat, nll, stream, ev0, ev1, ldo ? ldo : ld, total, team_mode);
-    } else
+        // the reference's own models (one component); force_slices -1 = the few-latents team kernel or nothing (the caller carries on with recursion.hip)
+        if (force_slices == -1) {
+            if (L == 0 || team_mode == 0) return -1;
+            return dtype == 0 ? try_x_teamc<double, DBB, 1>(Ty, T, ld, L, cb64, cb64, tp64, xin, x, yhat, nll, stream, ev0, ev1, ldo ? ldo : ld, total, team_mode)
+                              : try_x_teamc<float, DBB, 1>(Ty, T, ld, L, cb32, cb64, tp32, xin, x, yhat, nll, stream, ev0, ev1, ldo ? ldo : ld, total, team_mode);
+        }
+    }
     return dtype == 0 ? launch_xd<double, DBB, JJ>(Ty, T, ld, L, cb64, cb64, xin, x, yhat, nll, stream, ev0, ev1, scratch, scratch_len, force_slices, ldo, link_flags, link_state, total, max_links, team_mode, tp64)
                       : launch_xd<float, DBB, JJ>(Ty, T, ld, L, cb32, cb64, xin, x, yhat, nll, stream, ev0, ev1, scratch, scratch_len, force_slices, ldo, link_flags, link_state, total, max_links, team_mode, tp32);
 }

@@ -97,8 +97,8 @@ void launch_team_powers(int kernel, const double* cb64, size_t L, double* tp64, 
 int launch_filter_teamc_plain(int d, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* xc64, const float* xc32, const double* tp64, const float* tp32,
                               const void* xin, void* x, void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, size_t ldo, double* total, int team_mode) {
     if (!xc64 || !tp64) return -1;
-    return d == 2 ? launch_filter_x_21(dtype, Ty, T, ld, L, xc64, xc32, xin, x, yhat, nll, stream, ev0, ev1, nullptr, 0, 0, ldo, nullptr, nullptr, total, -1, team_mode, tp64, tp32)
-                  : launch_filter_x_31(dtype, Ty, T, ld, L, xc64, xc32, xin, x, yhat, nll, stream, ev0, ev1, nullptr, 0, 0, ldo, nullptr, nullptr, total, -1, team_mode, tp64, tp32);
+    return d == 2 ? launch_filter_x_21(dtype, Ty, T, ld, L, xc64, xc32, xin, x, yhat, nll, stream, ev0, ev1, nullptr, 0, -1, ldo, nullptr, nullptr, total, -1, team_mode, tp64, tp32)
+                  : launch_filter_x_31(dtype, Ty, T, ld, L, xc64, xc32, xin, x, yhat, nll, stream, ev0, ev1, nullptr, 0, -1, ldo, nullptr, nullptr, total, -1, team_mode, tp64, tp32);
 }
 
 int launch_filter_stream_x(int kernel, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* cb64, const float* cb32,
@@ -111,6 +111,7 @@ int launch_filter_stream_x(int kernel, int dtype, const void* Ty, size_t T, size
 #define MOIHGP_X_CASE(DBB, JJ)                                                                                        \
     if (base == (DBB == 2 ? 0 : 1) && J == JJ)                                                                        \
         return launch_filter_x_##DBB##JJ(dtype, Ty, T, ld, L, cb64, cb32, xin, x, yhat, nll, stream, ev0, ev1, scratch, scratch_len, force_slices, ldo, link_flags, link_state, total, max_links, team_mode, tp64, tp32)
+    MOIHGP_X_CASE(2, 1); MOIHGP_X_CASE(3, 1);            // (the reference's own models in the stacked layout: launch_xc_from_cb)
     MOIHGP_X_CASE(2, 2); MOIHGP_X_CASE(2, 3); MOIHGP_X_CASE(2, 4);
     MOIHGP_X_CASE(3, 2); MOIHGP_X_CASE(3, 3); MOIHGP_X_CASE(3, 4);
 #undef MOIHGP_X_CASE

@@ -372,8 +372,7 @@ __global__ void __launch_bounds__(64) stack_update_kernel(double dt, const doubl
 // The few-latents team kernel of recursion_x.hip for the reference's OWN models (Matern-3/2, d = 2; Matern-5/2, d = 3: one component, J = 1):
 // its tables in the stacked layout, from the matrices IHGP::update has already put into the latent's CB block (stationary.hip) -- the same
 // AKHA, K, A, HA, S, log S to the last bit, so the two paths filter with one model; added here: the 32-row response table, the diagonal
-// block, the padded slabs and the coefficient pairs of the packed fp32 replay.  SP / NLEV stay zero: only the team kernel reads these
-// blocks, and it takes its scan powers from team_powers_kernel's table.
+// block, the padded slabs, the scan powers of 32-tick chunks with their level counts, and the coefficient pairs of the packed fp32 replay.
 template <int D>
 __global__ void __launch_bounds__(64) xc_from_cb_kernel(const double* __restrict__ cb, size_t n, double* __restrict__ xc64, float* __restrict__ xc32) {
     constexpr int NN = D * D, DB = D, J = 1;
@@ -392,6 +391,23 @@ __global__ void __launch_bounds__(64) xc_from_cb_kernel(const double* __restrict
         if (lane < D) { sG[k * D + lane] = sV1[lane]; ok = ok && (fabs(sV1[lane]) < 1e150); ok32 = ok32 && (fabs(sV1[lane]) < 1e18); }
         wmv<D>(sAKHA, sV1, sV1, lane);
     }
+    // scan powers M^(2^k), M = AKHA^32, and the levels that matter per precision, as stack_update_kernel derives them
+    __shared__ double sT1[NN], sSP[6 * L::LS];
+    for (int e = lane; e < NN; e += 64) sT1[e] = sAKHA[e];
+    lds_sync();
+    for (int q = 1; q < kChunkX; q <<= 1) wmm<D>(sT1, sT1, sT1, lane);
+    int nlev64 = 1, nlev32 = 1;
+    for (int lv = 0; lv < 6; lv++) {
+        double big = 0.0;
+        for (int e = lane; e < L::LS; e += 64) {
+            const double v = e < NN ? sT1[e] : 0.0;
+            sSP[lv * L::LS + e] = v; ok = ok && (fabs(v) < 1e150); ok32 = ok32 && (fabs(v) < 1e18); big = fmax(big, fabs(v));
+        }
+        for (int o = 32; o >= 1; o >>= 1) big = fmax(big, __shfl_xor(big, o, 64));
+        if (big * D >= 1e-20) nlev64 = lv + 1;
+        if (big * D >= 1e-10) nlev32 = lv + 1;
+        wmm<D>(sT1, sT1, sT1, lane);
+    }
     ok = __builtin_amdgcn_ballot_w64(!ok) == 0;
     ok32 = __builtin_amdgcn_ballot_w64(!ok32) == 0;
     double* o64 = xc64 + l * L::SIZE;
@@ -406,6 +422,8 @@ __global__ void __launch_bounds__(64) xc_from_cb_kernel(const double* __restrict
         else if (e == L::S) v = c[C::S];
         else if (e == L::LOGS) v = c[C::LOGS];
         else if (e == L::SCANOK) { v = ok ? 1.0 : 0.0; v32 = ok32 ? 1.0 : 0.0; split = true; }
+        else if (e == L::NLEV) { v = (double)nlev64; v32 = (double)nlev32; split = true; }
+        else if (e >= L::SP && e < L::PK) v = sSP[e - L::SP];
         else if (e >= L::AB && e < L::HA16) { const int i = e - L::AB; v = i < DB * DB ? sA[i] : 0.0; }
         else if (e >= L::HA16 && e < L::K16) { const int i = e - L::HA16; v = i < D ? sHA[i] : 0.0; }
         else if (e >= L::K16 && e < L::G) { const int i = e - L::K16; v = i < D ? sK[i] : 0.0; }

@@ -1097,6 +1097,30 @@ def test_reference_models_on_the_team_kernel_vs_oracle(env, kern, dtype, T):
         assert (torch.where(ok, yc[:, :T] - yh[:, :T], torch.zeros_like(y0[:, :T])).abs() / sc).max().item() < rt, mode
 
 
+@pytest.mark.parametrize("kern", ["Matern52", "Matern32"])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("L,T,nanf", [(3, 17, 0.0), (5, 2049, 0.02), (1030, 2100, 0.0), (1100, 4500, 0.001), (1025, 1024, 0.3), (40, 9000, 0.0)])
+def test_reference_models_through_the_stacked_kernels_vs_oracle(env, kern, dtype, L, T, nanf):
+    """Option filter_plain_x = 1: Matern-3/2 and -5/2 through every kernel of the stacked filter with one component (tables rebuilt from the CB
+    blocks: xc_from_cb_kernel) -- the many-latent sweep and its second pass for gaps, the time split, the team kernels -- against the oracle."""
+    rng = np.random.default_rng(7 * L + T)
+    prm = synth_params(L, rng)
+    bank = env["streams"].LatentBank(0.1, prm, kernel=kern)
+    bank.set_option("filter_plain_x", 1)
+    Ty = synth(L, T, rng, nan_frac=nanf)
+    x0 = 0.3 * rng.standard_normal((L, bank.d))
+    sub = np.arange(L) if L <= 64 else np.sort(rng.choice(L, size=48, replace=False))
+    o = env["cref"].filter_stream(env["cref"].ihgp_array(kern, 0.1, prm[sub]), np.ascontiguousarray(Ty[sub]), x0=x0[sub], nthreads=4)
+    yhat, xT, nll = bank.filter(to_dev(Ty, dtype), T=T, x=torch.from_numpy(x0).to(dtype).cuda())
+    torch.cuda.synchronize()
+    tol = (FP64_TIGHT if dtype == torch.float64 else FP32_TOL) * 10
+    tame = np.nan_to_num(np.abs(o["yhat"]), nan=0.0, posinf=np.inf).max(axis=1) < (1e100 if dtype == torch.float64 else 1e12)
+    assert tame.sum() >= len(sub) // 2
+    yg = yhat[:, :T].cpu().numpy().astype(np.float64)[sub][tame]
+    assert rel_err_rows(yg, o["yhat"][tame]) < tol
+    assert rel_err(xT.cpu().numpy()[sub][tame], o["x"][tame]) < tol and rel_err(nll.cpu().numpy()[sub][tame], o["nll_per_latent"][tame]) < tol
+
+
 @pytest.mark.parametrize("kern,dtype", [("Matern52x2", torch.float64), ("Matern52x4", torch.float64), ("Matern32x3", torch.float32)])
 def test_stacked_time_split_matches_unsplit(env, kern, dtype, monkeypatch):
     """Few latents: the stream is cut into time slices that start from a zero state after a warm-up (recursion_x.hip).  Same
