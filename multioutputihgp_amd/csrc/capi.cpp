@@ -721,7 +721,7 @@ static int filter_stream_io_impl(moihgp_gp* gp, int dtype, const void* Ty, size_
     // few latents, streams of 2 .. 8 segments: one workgroup per latent, eight wavefronts (the stacked filter's team kernel, recursion_x.hip)
     // (left to itself only for Matern-5/2: at d = 2 recursion.hip's own split is 5-8 % faster on streams without gaps -- 8.8 against 9.6 us at
     // 256 x 10^4 fp64 -- and 25 % slower on streams with them; at d = 3 the team kernel wins both, 10.0 against 12.1-12.9 us and 21-23 against 25-34)
-    if (gp->dxc64 && gp->opt_filter_team != 0 && (gp->d == 3 || gp->opt_filter_team == 1) && gp->opt_filter_split == 0 && variant == 0) {
+    if (gp->dxc64 && gp->opt_filter_plain_x != 0 && gp->opt_filter_team != 0 && (gp->d == 3 || gp->opt_filter_team == 1) && gp->opt_filter_split == 0 && variant == 0) {
         const int rc = launch_filter_teamc_plain(gp->d, dtype, Ty, T, ld, gp->L, gp->dxc64, gp->dxc32, gp->dtp64, gp->dtp32, x_in, x, yhat, nll, (hipStream_t)stream, e0, e1,
                                                  ld_out, nll ? nll_total : nullptr, gp->opt_filter_team);
         if (rc != -1) return rc;
