@@ -955,6 +955,41 @@ def test_stacked_full_objects_vs_oracle(env, kern, M, L):
     assert rel_err(Yhat.cpu().numpy(), out) < 1e-9
 
 
+@pytest.mark.parametrize("kern,dtype", [("Matern52", torch.float64), ("Matern52x2", torch.float64), ("Matern52x2", torch.float32), ("Matern32x2", torch.float64)])
+@pytest.mark.parametrize("nanf", [0.0005, 0.02])
+def test_configs1_shape_with_gaps(env, kern, dtype, nanf):
+    """BASELINE configs[1] shape (256 x 1e4) with missing ticks: every compute unit holds one latent, every segment of a latent is solved as a
+    scan of its chunks' own maps inside the team kernel (recursion_x.hip chunk_maps_scan / replay_gaps) and handed on through the LDS flag chain.
+    A 40-latent subset against the oracle, and the sweep in two slabs that carry the state."""
+    L, T = 256, 10000
+    stacked = "x" in kern
+    rng = np.random.default_rng(3 + int(nanf * 1e4))
+    prm = synth_params_stacked(L, int(kern[-1]), rng) if stacked else synth_params(L, rng)
+    bank = env["streams"].LatentBank(0.1, prm, kernel=kern)
+    Ty = synth(L, T, rng, nan_frac=nanf)
+    Ty[5, :] = np.nan; Ty[6, 2000:9000] = np.nan
+    Tyd = to_dev(Ty, dtype)
+    yhat, xT, nll = bank.filter(Tyd, T=T)
+    torch.cuda.synchronize()
+    sub = np.concatenate([np.arange(8), np.sort(rng.choice(np.arange(8, L), size=32, replace=False))])
+    o = env["cref"].filter_stream(env["cref"].ihgp_array(kern, 0.1, prm[sub]), np.ascontiguousarray(Ty[sub]), nthreads=8)
+    tol = (FP64_TIGHT if dtype == torch.float64 else FP32_TOL) * 10
+    tame = np.nan_to_num(np.abs(o["yhat"]), nan=0.0, posinf=np.inf).max(axis=1) < 1e6
+    assert tame.sum() >= 30
+    assert rel_err_rows(yhat[sub][:, :T].cpu().numpy().astype(np.float64)[tame], o["yhat"][tame]) < tol
+    assert rel_err(xT[sub].cpu().numpy()[tame], o["x"][tame]) < tol and rel_err(nll[sub].cpu().numpy()[tame], o["nll_per_latent"][tame]) < tol
+    assert nll[5].item() == 0.0
+    cut = 4096 + 20 * 3 + 4                              # inside a segment and inside a chunk of either chunk length; a 16-byte boundary
+    ya, xa, na = bank.filter(Tyd[:, :cut], T=cut)
+    yb, xb, nb = bank.filter(Tyd[:, cut:], T=T - cut, x=xa.clone())
+    torch.cuda.synchronize()
+    rt = 1e-9 if dtype == torch.float64 else 2e-4
+    tm = torch.from_numpy(np.isin(np.arange(L), sub[tame])).cuda()
+    whole = yhat[:, :T][tm]; parts = torch.cat([ya[:, :cut], yb[:, :T - cut]], 1)[tm]
+    assert ((parts - whole).abs() / (whole.abs().amax(dim=1, keepdim=True) + 1e-30)).max().item() < rt
+    assert rel_err((na + nb)[tm].cpu().numpy(), nll[tm].cpu().numpy()) < rt
+
+
 @pytest.mark.parametrize("kern,dtype,L,T", [("Matern52x2", torch.float64, 256, 10000), ("Matern52x4", torch.float64, 4096, 10000),
                                             ("Matern52x2", torch.float32, 4096, 10000)])
 def test_stacked_full_size_properties(env, kern, dtype, L, T):
