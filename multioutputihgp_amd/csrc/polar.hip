@@ -231,6 +231,7 @@ int polar_factor_device(double* X, size_t M, size_t L, double* work, hipStream_t
     // 0.5..1.5: 8 -> 7; Marchenko-Pastur: 11 -> 10), never one more.  The estimate comes from inside the spectrum: the iteration stays in its
     // basin (sigma / s < sqrt 3) as long as it is within 2.08 x of lambda_max (2.86 x before; 16 power steps instead of 12).
     double s2 = h[3] / 1.44;
+    if (h[3] >= 0.8 && h[3] <= 1.44) s2 = 1.0;     // already there: scaling would only move the bulk (the rigorous bound above can exceed 2 by its slack alone)
     if (!(s2 > 0.0) || s2 > bound) s2 = bound;
     bool used_bound = (s2 == bound);
     // An input that is orthonormal already to within the reach of the iteration -- the learner's case: the previous polar factor plus
@@ -240,7 +241,7 @@ int polar_factor_device(double* X, size_t M, size_t L, double* work, hipStream_t
     const bool unscaled = bound <= 2.0;
     if (unscaled) { s2 = 1.0; used_bound = true; }
     h[4] = s2;
-    if (!unscaled) {
+    if (!unscaled && s2 != 1.0) {
         MOIHGP_HIP_FATAL(hipMemcpyAsync(stats + 4, &h[4], sizeof(double), hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(scale2_kernel, dim3(nbML > nbLL ? nbML : nbLL), dim3(256), 0, s, X, M * L, G, L * L, (const double*)stats);   // G is now X^T X
     }
