@@ -84,6 +84,7 @@ struct moihgp_gp {
     int polar_its = 0;         // Newton-Schulz steps of the last device polar factor (0: single-workgroup kernel / none yet)
     double* dhp = nullptr;     // [L][gradx_hp_len(d)] HA AKHA^k rows of the stacked models' time-parallel gradient sweep (on first use)
     double* dxscratch = nullptr; // stacked kernels, few latents: per-slice NLL partials
+    int* dlinkflags = nullptr;   // stacked filter, 1024 latents and more: hand-over flags of its second pass (zero between sweeps: the second pass clears what it takes)
     double* dtp64 = nullptr;     // fewer than 1024 latents: scan powers of the chunk-templated team kernel (launch_team_powers), per update
     float* dtp32 = nullptr;
     double* dxc64 = nullptr;     // the reference's own models, fewer than 1024 latents: their tables in the stacked layout (launch_xc_from_cb), per update
@@ -116,7 +117,7 @@ struct moihgp_gp {
 
 static void gp_free(moihgp_gp* g) {
     if (!g) return;
-    void* ptrs[] = {g->dU, g->dS, g->dsqrtS, g->dinvsqrtS, g->dsigma, g->dparams, g->cb64, g->cb32, g->dx, g->dpart, g->dTy, g->dUty, g->dTyhat, g->dloss, g->dgrad, g->dscratch, g->dwork, g->dpolar, g->dfallback, g->dwin, g->dunstable, g->dxscratch, g->cbd64, g->dU32, g->dhp, g->dlink, g->dwinmiss, g->dtp64, g->dtp32, g->dxc64, g->dxc32};
+    void* ptrs[] = {g->dU, g->dS, g->dsqrtS, g->dinvsqrtS, g->dsigma, g->dparams, g->cb64, g->cb32, g->dx, g->dpart, g->dTy, g->dUty, g->dTyhat, g->dloss, g->dgrad, g->dscratch, g->dwork, g->dpolar, g->dfallback, g->dwin, g->dunstable, g->dxscratch, g->cbd64, g->dU32, g->dhp, g->dlink, g->dwinmiss, g->dtp64, g->dtp32, g->dxc64, g->dxc32, g->dlinkflags};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (void* p : g->pinned) (void)hipHostUnregister(p);
@@ -712,9 +713,13 @@ static int filter_stream_io_impl(moihgp_gp* gp, int dtype, const void* Ty, size_
         const float* xb32 = plain_x ? gp->dxc32 : gp->cb32;
         const size_t slen = gp->L < 1024 ? gp->L * 16 : 0;              // per-slice NLL partials of the time split (few latents only)
         if (slen && !gp->dxscratch) gp->dxscratch = dev_alloc<double>(slen);
-        if (gp->L >= 1024 && !gp->dlink) gp->dlink = dev_alloc<double>(gp->L * 144);     // hand-over records of the second (broken-link) pass
+        if (gp->L >= 1024 && !gp->dlink) {                                               // hand-over records and flags of the second (broken-link) pass
+            gp->dlink = dev_alloc<double>(gp->L * 144);
+            gp->dlinkflags = dev_alloc<int>(gp->L);
+            MOIHGP_HIP_FATAL(hipMemsetAsync(gp->dlinkflags, 0, gp->L * sizeof(int), (hipStream_t)stream));
+        }
         int rc = launch_filter_stream_x(kid, dtype, Ty, T, ld, gp->L, xb64, xb32, x_in, x, yhat, nll, (hipStream_t)stream, e0, e1,
-                                        gp->dxscratch, slen, gp->opt_filter_split /* test hook: 1 = off, n = slices */, ld_out, gp->L >= 1024 ? gp->dfallback : nullptr, gp->dlink, nll ? nll_total : nullptr,
+                                        gp->dxscratch, slen, gp->opt_filter_split /* test hook: 1 = off, n = slices */, ld_out, gp->L >= 1024 ? gp->dlinkflags : nullptr, gp->dlink, nll ? nll_total : nullptr,
                                         gp->opt_filter_maxlinks, gp->opt_filter_team, gp->dtp64, gp->dtp32);
         return rc;
     }

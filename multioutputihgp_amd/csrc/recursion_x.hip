@@ -400,6 +400,7 @@ __device__ __forceinline__ void filter_x_body(const T* __restrict__ Ty, size_t T
     size_t t_resume = 0;
     if (LINKS) {                                                     // second pass: resume where the first one stopped this latent
         if (!link_flags[l]) return;
+        if (lane == 0) link_flags[l] = 0;                              // (consumed: the flags are all zero again when the pass ends -- no memset per sweep)
         const double* st = link_state + l * kLinkState;
 #pragma unroll
         for (int i = 0; i < D; i++) xc[i] = (T)st[i];
@@ -1488,7 +1489,7 @@ int launch_x(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, con
     T* xs = static_cast<T*>(x);
     T* yh = static_cast<T*>(yhat);
     if (SPLIT) link_flags = nullptr;
-    if (link_flags) (void)hipMemsetAsync(link_flags, 0, L * sizeof(int), stream);
+    // (link_flags: zero when the handle allocates them, set by the first pass, cleared again by the second as it takes a latent over)
 #define MOIHGP_X_LAUNCH(W_, N_)                                                                                                              \
     do {                                                                                                                                     \
         hipExtLaunchKernelGGL((filter_x_kernel<T, DB, J, W_, N_, WPB, SPLIT, false>), grid, block, 0, stream, ev0, ev1, 0,                    \
