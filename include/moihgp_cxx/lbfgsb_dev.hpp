@@ -288,8 +288,23 @@ public:
         evaluations++;
         _ops->sub(params, oldparams, _dparams);
         _ops->sync();                                                            // (the handle works on its own stream)
-        { opt::PhaseTimer pt("objective: update_dev"); opt::dv_check(moihgp_update_dev(_gp->handle(), params.data()), "update_dev"); }           // :43
-        if (opt::phases().enabled) { opt::phases().seconds["objective: Newton-Schulz steps of the polar factor (count, not ms)"] += 1e-3 * moihgp_polar_iterations(_gp->handle()); opt::phases().calls["objective: Newton-Schulz steps of the polar factor (count, not ms)"]++; }
+        // :43 `_gp->update(params)` -- skipped when the handle already holds exactly these parameters: a solve's first evaluation is at the point
+        // the previous solve's last one was (the optimiser hands its final iterate on), and update() is a function of the parameters alone
+        // (33 ms of a 206 ms learner tick at M = L = 4096: one polar factor in six).  Two vector passes to find out.
+        bool same = false;
+        if (_have_last) {
+            opt::PhaseTimer pt("objective: same parameters as the last update?");
+            _ops->sub(params, _last, _g);
+            same = _ops->dot(_g, _g) == 0.0;
+        }
+        if (!same) {
+            { opt::PhaseTimer pt("objective: update_dev"); opt::dv_check(moihgp_update_dev(_gp->handle(), params.data()), "update_dev"); }
+            if (opt::phases().enabled) { opt::phases().seconds["objective: Newton-Schulz steps of the polar factor (count, not ms)"] += 1e-3 * moihgp_polar_iterations(_gp->handle()); opt::phases().calls["objective: Newton-Schulz steps of the polar factor (count, not ms)"]++; }
+            _last.resize(_num_param);
+            _ops->copy(params, _last);
+            _have_last = true;
+        } else updates_skipped++;
+
         double loss;
         {
             opt::PhaseTimer pt("objective: proximal term (B dp)");
@@ -341,14 +356,16 @@ public:
     std::list<Vector> Y;
     Vector ma;
     size_t evaluations = 0;          // objective evaluations so far (diagnosis / bench)
+    size_t updates_skipped = 0;      // ... of which found the handle up to date
+    void invalidate_update_cache() { _have_last = false; }      // somebody else has called update() on the handle
 private:
     MOIHGP<StateSpace>* _gp;
     opt::DevOps* _ops;
     size_t _num_output, _num_latent, _igp_num_param, _num_param, _dim, _windowsize;
     double _gamma;
     Vector _x, _dx, _Yflat;
-    opt::DVec _xd, _dxd, _loss, _dparams, _g;
-    bool _window_dirty = true;
+    opt::DVec _xd, _dxd, _loss, _dparams, _g, _last;
+    bool _window_dirty = true, _have_last = false;
 };
 
 // MOIHGPOnlineLearning of moihgp_online.hpp (moihgp_online.h:118-255) whose parameter vector, gradient and optimiser state live on the device.
@@ -404,6 +421,7 @@ public:
     // (not in the reference: start from given parameters instead of the constructor's random draw -- tests, warm starts)
     void setParams(const Vector& p) {
         _moihgp->update(p);
+        _obj->invalidate_update_cache();
         opt::dv_check(moihgp_get_params_dev(_moihgp->handle(), _params.data()), "get_params_dev");
         _ops.copy(_params, _obj->oldparams);
         _ops.sync();

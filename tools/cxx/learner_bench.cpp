@@ -17,7 +17,7 @@ template <class SS> int run(size_t M, size_t L, size_t W, int nt, bool threading
     auto rnd = [&]() { s = s * 6364136223846793005ULL + 1442695040888963407ULL; return ((s >> 11) * (1.0 / 9007199254740992.0)) - 0.5; };
     double total = 0.0, worst = 0.0;
     int evals_like = 0;
-    size_t evals0 = 0;
+    size_t evals0 = 0, skipped0 = 0;
     for (int t = 0; t < nt + 1; t++) {
         for (size_t m = 0; m < M; m++) y[m] = std::sin(0.05 * t * (1 + m % 7)) + 0.2 * rnd();
         if (t == 1 && getenv("LEARNER_BENCH_PHASES")) moihgp::opt::phases().enabled = true;            // (phase table on stderr; tick 0 excluded)
@@ -25,7 +25,7 @@ template <class SS> int run(size_t M, size_t L, size_t W, int nt, bool threading
         std::vector<double> yhat = learner.step(y);
         const double sec = std::chrono::duration<double>(clk::now() - t0).count();
         if (t > 0) { total += sec; worst = sec > worst ? sec : worst; evals_like += learner.last_iterations; }       // (tick 0 warms up: allocations, first polar factor)
-        else evals0 = learner.objective().evaluations;
+        else { evals0 = learner.objective().evaluations; skipped0 = learner.objective().updates_skipped; }
         if (!std::isfinite(yhat[0])) { fprintf(stderr, "non-finite prediction at tick %d\n", t); return 3; }
     }
     if (moihgp::opt::phases().enabled) {
@@ -34,8 +34,8 @@ template <class SS> int run(size_t M, size_t L, size_t W, int nt, bool threading
             fprintf(stderr, "  %-48s %8.2f ms per tick  (%ld calls)\n", kv.first.c_str(), kv.second / nt * 1e3, moihgp::opt::phases().calls[kv.first]);
     }
     printf("{\"outputs\": %zu, \"latents\": %zu, \"window\": %zu, \"ticks\": %d, \"seconds_per_tick\": %.6f, \"worst_tick_seconds\": %.6f, "
-           "\"lbfgs_iterations_per_tick\": %.2f, \"objective_evaluations_per_tick\": %.2f, \"threading\": %s, \"num_param\": %zu, \"final_objective\": %.10g}\n",
-           M, L, W, nt, total / nt, worst, (double)evals_like / nt, (double)(learner.objective().evaluations - evals0) / nt, threading ? "true" : "false",
+           "\"lbfgs_iterations_per_tick\": %.2f, \"objective_evaluations_per_tick\": %.2f, \"updates_skipped_per_tick\": %.2f, \"threading\": %s, \"num_param\": %zu, \"final_objective\": %.10g}\n",
+           M, L, W, nt, total / nt, worst, (double)evals_like / nt, (double)(learner.objective().evaluations - evals0) / nt, (double)(learner.objective().updates_skipped - skipped0) / nt, threading ? "true" : "false",
            learner.getNumParam(), learner.last_fx);
     return 0;
 }
