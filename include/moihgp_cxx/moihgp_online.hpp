@@ -45,7 +45,10 @@ public:
     double operator()(const Vector& params, Vector& grad) {
         Vector dparams(_num_param), Bp;
         for (size_t i = 0; i < _num_param; i++) dparams[i] = params[i] - oldparams[i];
-        _gp->update(params);                                                     // :43
+        if (!_have_last || params != _last) {                                    // :43 (skipped when the handle already holds exactly these parameters:
+            _gp->update(params);                                                 //      a solve's first evaluation is at the previous solve's last point, and
+            _last = params; _have_last = true;                                   //      update() depends on the parameters alone)
+        }
         if (bfgs_mat.get_m() > 0) bfgs_mat.apply_Hv(dparams, _gamma, Bp);        // :45-48
         else Bp = dparams;                                                       // :51
         double loss = 0.5 * opt::dot(dparams, Bp);                               // :53
@@ -100,8 +103,11 @@ private:
     size_t _num_output, _num_latent, _igp_num_param, _num_param, _dim, _windowsize;
     double _gamma;
     MOIHGP<StateSpace>* _gp;
-    Vector _x, _dx, _Yflat, _g;
-    bool _window_dirty = true, _per_tick = false;
+    Vector _x, _dx, _Yflat, _g, _last;
+    bool _window_dirty = true, _per_tick = false, _have_last = false;
+
+public:
+    void invalidate_update_cache() { _have_last = false; }      // somebody else has called update() on the handle
 };
 
 template <typename StateSpace>
@@ -158,7 +164,7 @@ public:
 
     Vector getParams() { return _moihgp->getParams(); }
     // (not in the reference: start from given parameters instead of the constructor's random draw -- tests, warm starts)
-    void setParams(const Vector& p) { _moihgp->update(p); _params = _moihgp->getParams(); _obj->oldparams = _params; }
+    void setParams(const Vector& p) { _moihgp->update(p); _obj->invalidate_update_cache(); _params = _moihgp->getParams(); _obj->oldparams = _params; }
     size_t getNumParam() { return _num_param; }
     size_t getNumOutput() { return _num_output; }
     size_t getNumLatent() { return _num_latent; }
