@@ -1732,6 +1732,7 @@ def test_device_vector_blocks_are_kept_for_reuse(env):
     t = torch.arange(n, dtype=torch.float64, device="cuda")
     ctx = lib.moihgp_dvec_ctx_new()
     back = torch.empty_like(t)
+    torch.cuda.synchronize()                              # (t was filled on torch's stream; the copies below run on the context's own)
     assert lib.moihgp_dvec_copy(C.c_void_p(ctx), C.c_void_p(p3), C.c_void_p(t.data_ptr()), C.c_size_t(n)) == 0
     assert lib.moihgp_dvec_copy(C.c_void_p(ctx), C.c_void_p(back.data_ptr()), C.c_void_p(p3), C.c_size_t(n)) == 0
     assert lib.moihgp_dvec_sync(ctx) == 0 and torch.equal(back, t)
@@ -1786,6 +1787,7 @@ def test_device_vector_kernels_vs_numpy(env):
         assert lib.moihgp_dvec_proj_grad_norm(C.c_void_p(ctx), C.c_size_t(n), P(tx), P(tg), P(tl), P(tu), C.byref(r)) == 0
         assert abs(r.value - np.abs(np.clip(x - g, lb, ub) - x).max()) < 1e-15
         y = tb.clone()
+        torch.cuda.synchronize()                                                # (the clone runs on torch's stream, the vector kernels on the context's own)
         assert lib.moihgp_dvec_axpy(C.c_void_p(ctx), C.c_size_t(n), C.c_double(-1.5), P(ta), P(y), P(tm)) == 0
         lib.moihgp_dvec_sync(C.c_void_p(ctx))
         assert np.allclose(y.cpu().numpy(), np.where(mask > 0, b - 1.5 * a, b), rtol=0, atol=1e-14)      # (fused multiply-add on the device)
