@@ -170,6 +170,9 @@ class MOIHGP(object):
         import torch
         if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and t.numel() == n):
             raise ValueError(f"{what}: a contiguous CUDA float64 tensor of {n} elements is required")
+        # the entries work on the handle's own stream and expect their operands complete at the call (include/moihgp.h): whatever torch has
+        # queued for this tensor on its current stream -- the fill of a torch.zeros, a clone -- is waited for here
+        torch.cuda.current_stream(t.device).synchronize()
         from ctypes import c_void_p
         return c_void_p(t.data_ptr())
 
