@@ -277,6 +277,17 @@ int moihgp_window_eval(moihgp_gp* gp, const double* x, const double* dx, double*
 int moihgp_update_dev(moihgp_gp* gp, const double* params_dev);
 int moihgp_window_eval_dev(moihgp_gp* gp, const double* x_dev, const double* dx_dev, double* loss_dev, double* grad_dev,
                            double* xnew_dev, double* dxnew_dev);
+/* The same two entries for callers that produce the operands on a stream of their own (`stream`: a hipStream_t; NULL = the default
+ * stream).  The handle's stream is ordered BEHIND everything queued on `stream` at the time of the call (an event, no host
+ * synchronisation): operands written by kernels or copies still in flight there are fine.
+ *   moihgp_window_eval_dev_on does not synchronise the host at all: `stream` is made to wait for the results, so whatever the caller
+ *     queues on it afterwards (an axpy of the gradient, the download of the loss) sees them; other streams need their own ordering.
+ *   moihgp_update_dev_on returns, like gpXX_update, when the new tables are complete (the polar factor's step count is decided on the
+ *     host, and the tail S | sigma | per-latent values is mirrored there), so only the ordering of its INPUT changes.
+ * Values bit-identical to the forms above (tests/test_gpu_configs.py::test_dev_entries_take_the_callers_stream). */
+int moihgp_update_dev_on(moihgp_gp* gp, const double* params_dev, void* stream);
+int moihgp_window_eval_dev_on(moihgp_gp* gp, const double* x_dev, const double* dx_dev, double* loss_dev, double* grad_dev,
+                              double* xnew_dev, double* dxnew_dev, void* stream);
 /* getParams (moihgp.h:721-738) into a DEVICE array [num_param]. */
 int moihgp_get_params_dev(moihgp_gp* gp, double* params_dev);
 
@@ -290,6 +301,7 @@ int moihgp_get_params_dev(moihgp_gp* gp, double* params_dev);
 typedef struct moihgp_dvec_ctx moihgp_dvec_ctx;
 moihgp_dvec_ctx* moihgp_dvec_ctx_new(void);
 void    moihgp_dvec_ctx_del(moihgp_dvec_ctx* c);
+void*   moihgp_dvec_ctx_stream(moihgp_dvec_ctx* c);                   /* the context's hipStream_t (for the `_on` entries above) */
 double* moihgp_dvec_alloc(size_t n);                                  /* n doubles of device memory (NULL on failure) */
 unsigned char* moihgp_dvec_alloc_mask(size_t n);
 void    moihgp_dvec_free(void* p);                                    /* as hipFree for the caller; blocks of 1 MB and more are kept for the next alloc of that size */

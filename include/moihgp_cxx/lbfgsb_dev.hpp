@@ -98,6 +98,7 @@ public:
     void upload(const std::vector<double>& h, DVec& d) { d.resize(h.size()); dv_check(moihgp_dvec_upload(m_c, d.data(), h.data(), h.size()), "dvec_upload"); }
     void download(const DVec& d, std::vector<double>& h) { h.resize(d.size()); dv_check(moihgp_dvec_download(m_c, h.data(), d.data(), d.size()), "dvec_download"); }
     void sync() { dv_check(moihgp_dvec_sync(m_c), "dvec_sync"); }
+    void* stream() { return moihgp_dvec_ctx_stream(m_c); }          // hipStream_t of the context: what the handle's `_on` entries order themselves by
 private:
     moihgp_dvec_ctx* m_c;
 };
@@ -287,7 +288,7 @@ public:
     double operator()(const opt::DVec& params, opt::DVec& grad) {
         evaluations++;
         _ops->sub(params, oldparams, _dparams);
-        _ops->sync();                                                            // (the handle works on its own stream)
+        // (no host synchronisation: the handle's `_on` entries take their place behind this context's stream by an event)
         // :43 `_gp->update(params)` -- skipped when the handle already holds exactly these parameters: a solve's first evaluation is at the point
         // the previous solve's last one was (the optimiser hands its final iterate on), and update() is a function of the parameters alone
         // (33 ms of a 206 ms learner tick at M = L = 4096: one polar factor in six).  Two vector passes to find out.
@@ -298,7 +299,8 @@ public:
             same = _ops->dot(_g, _g) == 0.0;
         }
         if (!same) {
-            { opt::PhaseTimer pt("objective: update_dev"); opt::dv_check(moihgp_update_dev(_gp->handle(), params.data()), "update_dev"); }
+            _have_last = false;                                                      // (a failing update leaves the handle half-way: the next evaluation must not skip it)
+            { opt::PhaseTimer pt("objective: update_dev"); opt::dv_check(moihgp_update_dev_on(_gp->handle(), params.data(), _ops->stream()), "update_dev"); }
             if (opt::phases().enabled) { opt::phases().seconds["objective: Newton-Schulz steps of the polar factor (count, not ms)"] += 1e-3 * moihgp_polar_iterations(_gp->handle()); opt::phases().calls["objective: Newton-Schulz steps of the polar factor (count, not ms)"]++; }
             _last.resize(_num_param);
             _ops->copy(params, _last);
@@ -320,19 +322,27 @@ public:
                 for (std::list<Vector>::iterator it = Y.begin(); it != Y.end(); ++it, ++t)
                     for (size_t m = 0; m < _num_output; m++) _Yflat[t * _num_output + m] = (*it)[m] - ma[m];       // :63
                 const int rc = moihgp_window_set(_gp->handle(), _Yflat.data(), Y.size());
-                if (rc != 0) throw std::runtime_error(std::string("moihgp_window_set: ") + moihgp_last_error());
+                if (rc != 0 && rc != 3) throw std::runtime_error(std::string("moihgp_window_set: ") + moihgp_last_error());
+                _per_tick = rc == 3;      // missing outputs beyond the batched kernel's limits: the reference's loop, tick by tick (as the host learner)
                 _ops->upload(_x, _xd); _ops->upload(_dx, _dxd);
                 _window_dirty = false;
             }
-            opt::PhaseTimer pt("objective: window_eval_dev");
-            opt::dv_check(moihgp_window_eval_dev(_gp->handle(), _xd.data(), _dxd.data(), _loss.data(), _g.data(), nullptr, nullptr), "window_eval_dev");   // :61-70
-            std::vector<double> l1;
-            _ops->download(_loss, l1);
-            loss += l1[0];
+            if (_per_tick) {
+                opt::PhaseTimer pt("objective: window, tick by tick (host)");
+                Vector gh(_num_param);
+                const double wl = window_loop_per_tick(_gp->handle(), _Yflat.data(), Y.size(), _num_output, _x, _dx, gh);
+                _ops->upload(gh, _g);
+                loss += wl;
+            } else {
+                opt::PhaseTimer pt("objective: window_eval_dev");
+                // ordered behind this context's stream on entry, in front of it on return: the download and the axpy below follow it there
+                opt::dv_check(moihgp_window_eval_dev_on(_gp->handle(), _xd.data(), _dxd.data(), _loss.data(), _g.data(), nullptr, nullptr, _ops->stream()), "window_eval_dev");   // :61-70
+                std::vector<double> l1;
+                _ops->download(_loss, l1);
+                loss += l1[0];
+            }
             _ops->axpy(1.0, _g, grad);
-            _ops->sync();
         }
-        _ops->sync();
         return loss;
     }
     // moihgp_online.h:75-93 (as OnlineObjective::push_back)
@@ -365,7 +375,7 @@ private:
     double _gamma;
     Vector _x, _dx, _Yflat;
     opt::DVec _xd, _dxd, _loss, _dparams, _g, _last;
-    bool _window_dirty = true, _have_last = false;
+    bool _window_dirty = true, _have_last = false, _per_tick = false;
 };
 
 // MOIHGPOnlineLearning of moihgp_online.hpp (moihgp_online.h:118-255) whose parameter vector, gradient and optimiser state live on the device.

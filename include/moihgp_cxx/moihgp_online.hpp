@@ -46,8 +46,9 @@ public:
         Vector dparams(_num_param), Bp;
         for (size_t i = 0; i < _num_param; i++) dparams[i] = params[i] - oldparams[i];
         if (!_have_last || params != _last) {                                    // :43 (skipped when the handle already holds exactly these parameters:
-            _gp->update(params);                                                 //      a solve's first evaluation is at the previous solve's last point, and
-            _last = params; _have_last = true;                                   //      update() depends on the parameters alone)
+            _have_last = false;                                                  //      a solve's first evaluation is at the previous solve's last point, and
+            _gp->update(params);                                                 //      update() depends on the parameters alone; a throwing update
+            _last = params; _have_last = true;                                   //      leaves the cache empty)
         }
         if (bfgs_mat.get_m() > 0) bfgs_mat.apply_Hv(dparams, _gamma, Bp);        // :45-48
         else Bp = dparams;                                                       // :51

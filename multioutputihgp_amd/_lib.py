@@ -22,9 +22,9 @@ ADDITIVE_SYMBOLS = [
     "moihgp_update_latents", "moihgp_set_mixing", "moihgp_get_latent", "moihgp_filter_stream", "moihgp_filter_stream_io", "moihgp_filter_stream_v2", "moihgp_grad_stream",
     "moihgp_project_stream", "moihgp_unproject_stream", "moihgp_stream_sync",
     "moihgp_profile_enable", "moihgp_profile_stride", "moihgp_profile_read", "moihgp_window_set", "moihgp_window_eval", "moihgp_pin_host_buffer",
-    "moihgp_update_dev", "moihgp_window_eval_dev", "moihgp_get_params_dev", "moihgp_set_option", "moihgp_release_stream",
+    "moihgp_update_dev", "moihgp_window_eval_dev", "moihgp_update_dev_on", "moihgp_window_eval_dev_on", "moihgp_get_params_dev", "moihgp_set_option", "moihgp_release_stream",
     "moihgp_ls_shard_gram", "moihgp_ls_shard_apply",
-    "moihgp_dvec_ctx_new", "moihgp_dvec_ctx_del", "moihgp_dvec_alloc", "moihgp_dvec_alloc_mask", "moihgp_dvec_free", "moihgp_dvec_trim", "moihgp_dvec_upload", "moihgp_dvec_download",
+    "moihgp_dvec_ctx_new", "moihgp_dvec_ctx_del", "moihgp_dvec_ctx_stream", "moihgp_dvec_alloc", "moihgp_dvec_alloc_mask", "moihgp_dvec_free", "moihgp_dvec_trim", "moihgp_dvec_upload", "moihgp_dvec_download",
     "moihgp_dvec_copy", "moihgp_dvec_sync", "moihgp_dvec_dot", "moihgp_dvec_axpy", "moihgp_dvec_scale", "moihgp_dvec_sub", "moihgp_dvec_clamp", "moihgp_dvec_active_set",
     "moihgp_dvec_proj_step", "moihgp_dvec_proj_grad_norm",
 ]
@@ -122,6 +122,10 @@ def load_library():
     lib.moihgp_update_dev.argtypes = [C.c_void_p, C.c_void_p]
     lib.moihgp_window_eval_dev.restype = C.c_int
     lib.moihgp_window_eval_dev.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+    lib.moihgp_update_dev_on.restype = C.c_int
+    lib.moihgp_update_dev_on.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.moihgp_window_eval_dev_on.restype = C.c_int
+    lib.moihgp_window_eval_dev_on.argtypes = [C.c_void_p] + [C.c_void_p] * 7
     lib.moihgp_get_params_dev.restype = C.c_int
     lib.moihgp_get_params_dev.argtypes = [C.c_void_p, C.c_void_p]
     lib.moihgp_set_option.restype = C.c_int

@@ -151,6 +151,22 @@ static void order_after_sweeps(moihgp_gp* g) {
     g->user_streams.clear();
 }
 
+// `_on` entries (moihgp_update_dev_on, moihgp_window_eval_dev_on): the handle's stream takes its place behind whatever the caller has queued
+// on `s` so far (the operands need not be complete on the host side), and `s` waits for what the handle has queued -- events only, no host
+// synchronisation.  s == the handle's own stream: nothing to do.
+static void wait_for_caller(moihgp_gp* g, hipStream_t s) {
+    if (s == g->stream) return;
+    if (!g->order_ev) MOIHGP_HIP_FATAL(hipEventCreateWithFlags(&g->order_ev, hipEventDisableTiming));
+    MOIHGP_HIP_FATAL(hipEventRecord(g->order_ev, s));
+    MOIHGP_HIP_FATAL(hipStreamWaitEvent(g->stream, g->order_ev, 0));
+}
+static void caller_waits(moihgp_gp* g, hipStream_t s) {
+    if (s == g->stream) return;
+    if (!g->order_ev) MOIHGP_HIP_FATAL(hipEventCreateWithFlags(&g->order_ev, hipEventDisableTiming));
+    MOIHGP_HIP_FATAL(hipEventRecord(g->order_ev, g->stream));
+    MOIHGP_HIP_FATAL(hipStreamWaitEvent(s, g->order_ev, 0));
+}
+
 static void upload_mixing(moihgp_gp* g) {
     if (g->latents_only) return;
     order_after_sweeps(g);
@@ -173,6 +189,12 @@ static void run_ihgp_update(moihgp_gp* g) {
         // the sensitivities cost nine more 100-iteration Lyapunov solves per latent at d = 12: only for handles that use them
         launch_stack_update(g->kernel, g->dt, g->dparams, g->L, g->cb64, g->cb32, g->sens_wanted ? g->cbd64 : nullptr, g->dunstable, g->stream);
         g->sens_valid = g->sens_wanted;
+        // the time-parallel gradient sweep's per-latent tables follow the sensitivity blocks: rebuilt HERE, on the handle's stream (which this
+        // function synchronises), so that hp_valid never claims a table nobody built and sweeps on any caller stream find it complete
+        if (g->dhp && g->sens_valid) {
+            if (launch_gp_table_x(g->kernel, g->cb64, g->cbd64, g->dhp, g->L, g->stream)) throw HipFailure{hipErrorLaunchFailure, "gp_table_kernel", __FILE__, __LINE__};
+            g->hp_valid = true;
+        }
         if (g->L < 1024) {
             if (!g->dtp64) { g->dtp64 = dev_alloc<double>(g->L * team_powers_elems(g->d)); g->dtp32 = dev_alloc<float>(g->L * team_powers_elems(g->d)); }
             launch_team_powers(g->kernel, g->cb64, g->L, g->dtp64, g->dtp32, g->stream);
@@ -810,12 +832,16 @@ static int grad_stream_impl(moihgp_gp* gp, int dtype, const void* Ty, size_t T, 
     note_user_stream(gp, (hipStream_t)stream);
     if (kernel_stack(gp->kernel))
         {
-        if (!gp->dhp) gp->dhp = dev_alloc<double>(gp->L * gradx_hp_len(gp->d));    // table of the time-parallel sweep (grad_scan_x.hip)
-        // (the table only changes with the hyper-parameters: rebuilt on the first sweep after an update, in this sweep's stream order)
-        const int rc = launch_grad_stream_x(gp->kernel, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cbd64, x, dx, yhat, nll, grad, (hipStream_t)stream, 1, gp->dfallback, gp->dhp,
-                                            gp->hp_valid ? 0 : 1);
-        if (rc == 0) gp->hp_valid = true;
-        return rc;
+        // tables of the time-parallel sweep (grad_scan_x.hip): they change with the hyper-parameters only and every IHGP::update rebuilds them
+        // (run_ihgp_update) once they exist; the first gradient sweep of a handle builds them here, on the handle's stream, and waits -- a sweep
+        // never builds them in its own stream order (a short sweep would skip the build, a sweep on another stream could read them half-written)
+        if (!gp->dhp) gp->dhp = dev_alloc<double>(gp->L * gradx_hp_len(gp->d));
+        if (!gp->hp_valid) {
+            if (int rc = launch_gp_table_x(gp->kernel, gp->cb64, gp->cbd64, gp->dhp, gp->L, gp->stream)) return rc;
+            MOIHGP_HIP_FATAL(hipStreamSynchronize(gp->stream));
+            gp->hp_valid = true;
+        }
+        return launch_grad_stream_x(gp->kernel, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cbd64, x, dx, yhat, nll, grad, (hipStream_t)stream, 1, gp->dfallback, gp->dhp, 0);
     }
     return launch_grad_stream(gp->d, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cb32, x, dx, yhat, nll, grad, gp->dfallback, (hipStream_t)stream);
 }
@@ -935,12 +961,16 @@ int moihgp_window_set(moihgp_gp* gp, const double* Y, size_t W) {
 }
 
 // dev == false: the reference-shaped form (host vectors in and out); dev == true: every pointer is a device pointer (moihgp_window_eval_dev)
-static int window_eval_impl(moihgp_gp* gp, const double* x, const double* dx, double* loss, double* grad, double* xnew, double* dxnew, bool dev) {
+// on != nullptr (device form only): *on is the caller's stream -- operands are ordered behind it, results in front of its later work, and the
+// host is NOT synchronised (moihgp_window_eval_dev_on)
+static int window_eval_impl(moihgp_gp* gp, const double* x, const double* dx, double* loss, double* grad, double* xnew, double* dxnew, bool dev,
+                            const hipStream_t* on = nullptr) {
     if (!gp || gp->latents_only || gp->win.W == 0) { set_last_error("window_eval: call moihgp_window_set first"); return 1; }
     if (!x || !dx || !loss || !grad) { set_last_error("window_eval: null argument"); return 1; }
     const size_t L = gp->L, d = gp->d, P = gp->P;
     WindowBufs& w = gp->win;
     order_after_sweeps(gp);        // the sweep below shares the handle's flag / list scratch with sweeps that may still be in flight on caller streams
+    if (on) wait_for_caller(gp, *on);
     const hipMemcpyKind in = dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, out = dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     MOIHGP_HIP_FATAL(hipMemcpyAsync(w.x, x, sizeof(double) * L * d, in, gp->stream));
     MOIHGP_HIP_FATAL(hipMemcpyAsync(w.dx, dx, sizeof(double) * L * P * d, in, gp->stream));
@@ -953,7 +983,8 @@ static int window_eval_impl(moihgp_gp* gp, const double* x, const double* dx, do
     }
     if (xnew) MOIHGP_HIP_FATAL(hipMemcpyAsync(xnew, w.x, sizeof(double) * L * d, out, gp->stream));
     if (dxnew) MOIHGP_HIP_FATAL(hipMemcpyAsync(dxnew, w.dx, sizeof(double) * L * P * d, out, gp->stream));
-    MOIHGP_HIP_FATAL(hipStreamSynchronize(gp->stream));
+    if (on) caller_waits(gp, *on);
+    else MOIHGP_HIP_FATAL(hipStreamSynchronize(gp->stream));
     return 0;
 }
 
@@ -968,6 +999,25 @@ int moihgp_window_eval_dev(moihgp_gp* gp, const double* x_dev, const double* dx_
 int moihgp_update_dev(moihgp_gp* gp, const double* params_dev) {
     return guard_rc([&] {
         if (!gp || gp->latents_only || !params_dev) { set_last_error("update_dev: needs a full MOIHGP object and a device parameter vector"); return 1; }
+        do_update(gp, params_dev, true);
+        return 0;
+    });
+}
+
+int moihgp_window_eval_dev_on(moihgp_gp* gp, const double* x_dev, const double* dx_dev, double* loss_dev, double* grad_dev, double* xnew_dev, double* dxnew_dev,
+                              void* stream) {
+    return guard_rc([&] {
+        const hipStream_t s = (hipStream_t)stream;
+        return window_eval_impl(gp, x_dev, dx_dev, loss_dev, grad_dev, xnew_dev, dxnew_dev, true, &s);
+    });
+}
+
+int moihgp_update_dev_on(moihgp_gp* gp, const double* params_dev, void* stream) {
+    return guard_rc([&] {
+        if (!gp || gp->latents_only || !params_dev) { set_last_error("update_dev: needs a full MOIHGP object and a device parameter vector"); return 1; }
+        // update() decides the polar factor's steps on the host and mirrors [S | sigma | per-latent values] there: it returns with the new
+        // tables complete, as gpXX_update does.  What the stream argument adds is the ordering of the INPUT behind the caller's queue.
+        wait_for_caller(gp, (hipStream_t)stream);
         do_update(gp, params_dev, true);
         return 0;
     });

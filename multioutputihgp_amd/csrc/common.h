@@ -157,6 +157,7 @@ int launch_grad_stream_x(int kernel, int dtype, const void* Ty, size_t T, size_t
 constexpr size_t gradx_hp_len(int d) { return 9 * ((size_t)(kChunkX * d + 15) / 16 * 16); }   // (grad_scan_x.hip kGxTables slab tables per latent)
 // grad_scan_x.hip: the same sweep parallel in time over the stream's whole 32-tick chunks [0, Tpar); flags[l] = 1 marks latents left
 // untouched (missing ticks, unusable scan tables), for the others (x, dx, nll, grad) hold the state after / sums over those ticks.
+int launch_gp_table_x(int kernel, const double* cb64, const double* cbd64, double* hp, size_t L, hipStream_t stream);
 int launch_grad_scan_x(int kernel, int dtype, const void* Ty, size_t Tpar, size_t ld, size_t L, const double* cb64, const double* cbd64,
                        void* x, void* dx, void* yhat, double* nll, double* grad, int* flags, double* hp, hipStream_t stream, int out_mode, int hp_build = 1);
 

@@ -609,6 +609,26 @@ int launch_gsx(const void* Ty, size_t Tpar, size_t ld, size_t L, const double* c
 
 }  // namespace
 
+// The per-latent tables of the sweep (gp_p[k] = AKHA^(CK-1-k) dK_p and the HA AKHA^k rows) alone: they change with the hyper-parameters only, so
+// the handle builds them on its own stream whenever it rewrites the sensitivity blocks (capi.cpp run_ihgp_update / grad_stream_impl) and the
+// sweeps, whatever stream they run on, only ever read them.
+int launch_gp_table_x(int kernel, const double* cb64, const double* cbd64, double* hp, size_t L, hipStream_t stream) {
+    if (L == 0) return 0;
+    const int base = kernel_base(kernel), J = kernel_stack(kernel);
+#define MOIHGP_GPT_CASE(DBB, JJ)                                                                                                        \
+    if (base == (DBB == 2 ? 0 : 1) && J == JJ) {                                                                                        \
+        hipLaunchKernelGGL((gp_table_kernel<DBB * JJ, 2 * JJ + 1>), dim3((unsigned)L), dim3(64), 0, stream, cb64, cbd64, hp, L);        \
+        hipError_t e = hipGetLastError();                                                                                               \
+        if (e != hipSuccess) { set_last_error("gp_table_kernel launch: %s", hipGetErrorString(e)); return 2; }                          \
+        return 0;                                                                                                                       \
+    }
+    MOIHGP_GPT_CASE(2, 2); MOIHGP_GPT_CASE(2, 3); MOIHGP_GPT_CASE(2, 4);
+    MOIHGP_GPT_CASE(3, 2); MOIHGP_GPT_CASE(3, 3); MOIHGP_GPT_CASE(3, 4);
+#undef MOIHGP_GPT_CASE
+    set_last_error("stacked kernel id %d is not built", kernel);
+    return 1;
+}
+
 // The whole chunks [0, Tpar) of every latent's stream; flags[l] = 1 where the latent was left untouched (missing ticks, unusable scan
 // tables), 0 where (x, dx, nll, grad) now hold the state after / the sums over those Tpar ticks.
 int launch_grad_scan_x(int kernel, int dtype, const void* Ty, size_t Tpar, size_t ld, size_t L, const double* cb64, const double* cbd64,

@@ -6,6 +6,9 @@
 // matrices L-BFGS hands to update() that is 4-6 steps.  s^2 = min(||G||_inf, trace G) with G = A^T A is a
 // rigorous upper bound of sigma_max^2.
 #include "common.h"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
 
 namespace moihgp {
 namespace {
@@ -197,6 +200,20 @@ void launch_polar_small(double* A_dev, size_t M, size_t L, int* status_dev, hipS
     MOIHGP_HIP_FATAL(hipGetLastError());
 }
 
+// MOIHGP_POLAR_TRACE=1: one line per Gram matrix on stderr; MOIHGP_POLAR_DUMP=<file> + MOIHGP_POLAR_DUMP_CALL=<n>: the first Gram matrix of
+// the n-th call, raw doubles (tools/polar_spectrum.py turns it into singular values).  Development aids, read once.
+static int polar_trace_level() { static const int v = [] { const char* e = std::getenv("MOIHGP_POLAR_TRACE"); return e ? std::atoi(e) : 0; }(); return v; }
+static void polar_dump_gram(const double* G, size_t L, hipStream_t s) {
+    static const char* path = std::getenv("MOIHGP_POLAR_DUMP");
+    static const int want = [] { const char* e = std::getenv("MOIHGP_POLAR_DUMP_CALL"); return e ? std::atoi(e) : 0; }();
+    static int call = 0;
+    if (!path || call++ != want) return;
+    std::vector<double> h(L * L);
+    MOIHGP_HIP_FATAL(hipMemcpyAsync(h.data(), G, sizeof(double) * L * L, hipMemcpyDeviceToHost, s));
+    MOIHGP_HIP_FATAL(hipStreamSynchronize(s));
+    if (FILE* f = std::fopen(path, "wb")) { std::fwrite(h.data(), sizeof(double), L * L, f); std::fclose(f); }
+}
+
 int polar_factor_device(double* X, size_t M, size_t L, double* work, hipStream_t s) {
     double* G = work;                 // L*L
     double* W = G + L * L;            // L*L
@@ -215,6 +232,7 @@ int polar_factor_device(double* X, size_t M, size_t L, double* work, hipStream_t
     MOIHGP_HIP_FATAL(hipStreamSynchronize(s));
     const double bound = fmin(h[0], h[1]);
     if (!(bound > 0.0) || h[0] != h[0]) return -1;
+    polar_dump_gram(G, L, s);
     if (bound > 2.0) {                    // (an input this close to orthonormal is not scaled at all, below: no estimate needed)
         double* v = rows;
         double* y = rows + L;
@@ -257,6 +275,7 @@ int polar_factor_device(double* X, size_t M, size_t L, double* work, hipStream_t
         MOIHGP_HIP_FATAL(hipStreamSynchronize(s));
         h[0] = hh[0]; h[1] = hh[1]; h[2] = hh[2];
         const double err = h[2], einf = hh[5];
+        if (polar_trace_level()) std::fprintf(stderr, "polar: gram %d  max|G-I| %.3e  ||G-I||inf %.3e  ||G||inf %.4f  tr/L %.6f  s2 %.4f lam_est %.4f\n", it, err, einf, hh[0], hh[1] / (double)L, h[4], h[3]);
         if (err != err) return -1;
         // converged: orthonormal to rounding (the error floor of an fp64 Gram matrix is ~ K eps), or no longer improving
         if (err < 1e-14 || (err < 1e-11 && err >= 0.5 * prev)) {

@@ -780,6 +780,394 @@ filter_seq_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, co
     if (nll) { const double* c64 = cb64 + l * Lay::SIZE; nll[l] = 0.5 * (acc / c64[Lay::S] + n * c64[Lay::LOGS]); }
 }
 
+// ===========================================================================================================================
+// LDS-DMA form of the many-latent sweep (round 4).  Same mapping and the same segment solve as above (one wavefront = one latent,
+// fast_segment / generic_segment unchanged); what changes is how the stream reaches the lanes:
+//   * the stream is fetched by `global_load_lds_dwordx4` (gfx950 LDS-DMA): no destination VGPRs, so the bytes a wave keeps in flight
+//     are bounded by its LDS ring, not by the 128-register budget of four waves per SIMD (the register-staged kernel above has room
+//     for ONE 4 KB segment in flight per wave);
+//   * a wave owns a ring of NP pieces of 1 KB (one piece = one DMA instruction = the 16 chunks of one DPP row of a segment; a
+//     segment is 4 pieces in both precisions).  Segment s lives in slots (4 s + i) mod NP; while it is solved the NP - 4 pieces behind
+//     it are on their way, and its own four slots are refilled with pieces 4 s + NP + i as soon as its results have left them;
+//   * an LDS-DMA instruction writes LDS linearly (wave-uniform base + 16 lane), so the chunk-per-lane layout is put on the SOURCE
+//     address: lane ln of a piece fetches vector (ln & 3) ^ sw(ln >> 2) of chunk ln >> 2, sw(jj) = (jj ^ (jj >> 2)) & 3 -- every piece
+//     still reads 1 KB of contiguous stream, permuted inside its 64-byte chunks -- and lane j finds vector k of its chunk at
+//     16 (k ^ sw(j & 15)) inside its 64 bytes: conflict-free for ds_read_b128 (each of its four 16-lane groups covers all 64 banks)
+//     and for ds_write_b128 (eight-lane groups, 32 banks).  No padding: 4 KB per segment instead of 5;
+//   * results go back through the segment's own slots (ds_write_b128 swizzled, ds_read_b128 linear) and leave by streaming stores
+//     with the same per-lane permutation, 1 KB contiguous per instruction;
+//   * every LDS access of the hot path is inline asm: the compiler does not track which DMA a ds_read depends on and would drain ALL
+//     DMAs in flight (s_waitcnt vmcnt(0)) before any LDS read it can see.  The waits are counted by hand: vector-memory operations of a
+//     wave complete in issue order, and behind the last piece of segment s there are always exactly NP - 4 younger DMAs and (from
+//     segment 1 on) the 4 stores of segment s - 1.  Pieces past the end of the stream are still issued -- every lane re-reads the last
+//     valid vector, one cache line per instruction -- so that the count holds to the last segment; the ring slots they fill are never read.
+#ifndef MOIHGP_FILTER_DMA
+#define MOIHGP_FILTER_DMA 1
+#endif
+constexpr int kDmaRing32 = 8, kDmaWaves32 = 4;     // fp32: 8 KB ring, 4 waves per SIMD (16 x 8.2 KB = 131 KB of the 160 KB per CU)
+constexpr int kDmaRing64 = 8, kDmaWaves64 = 2;     // fp64
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_cvoid_t;
+__device__ inline unsigned lds_addr_of(const void* p) { return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char*)p; }
+template <int N> __device__ inline void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename T> struct AsmVec;
+template <> struct AsmVec<float> { using type = nt_f4; };
+template <> struct AsmVec<double> { using type = nt_d2; };
+__device__ inline void av_unpack(const nt_f4& v, float* o) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+__device__ inline void av_unpack(const nt_d2& v, double* o) { o[0] = v.x; o[1] = v.y; }
+__device__ inline nt_f4 av_pack(const float* i) { nt_f4 v = {i[0], i[1], i[2], i[3]}; return v; }
+__device__ inline nt_d2 av_pack(const double* i) { nt_d2 v = {i[0], i[1]}; return v; }
+
+// four 16-byte LDS reads / writes at four per-lane addresses, complete on return
+template <typename AV>
+__device__ inline void lds_read4(unsigned a0, unsigned a1, unsigned a2, unsigned a3, AV (&r)[4]) {
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]) : "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "memory");
+}
+template <typename AV>
+__device__ inline void lds_write4(unsigned a0, unsigned a1, unsigned a2, unsigned a3, const AV (&r)[4]) {
+    asm volatile("ds_write_b128 %4, %0\n\tds_write_b128 %5, %1\n\tds_write_b128 %6, %2\n\tds_write_b128 %7, %3"
+                 :: "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "memory");
+}
+// N scalars of a wave-uniform table row (16-byte aligned, padded to whole vectors) from LDS: every lane reads the same address (broadcast)
+template <typename T, int N>
+__device__ inline void lds_read_uniform(unsigned addr, T* out) {
+    using AV = typename AsmVec<T>::type;
+    constexpr int EPV = 16 / sizeof(T), NV = (N + EPV - 1) / EPV;
+    static_assert(NV >= 1 && NV <= 5, "table row of 1..5 vectors");
+    AV v[5];
+    if constexpr (NV == 1) asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v[0]) : "v"(addr) : "memory");
+    else if constexpr (NV == 2) asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v[0]), "=&v"(v[1]) : "v"(addr) : "memory");
+    else if constexpr (NV == 3) asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32\n\ts_waitcnt lgkmcnt(0)"
+                                             : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]) : "v"(addr) : "memory");
+    else if constexpr (NV == 4) asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48\n\ts_waitcnt lgkmcnt(0)"
+                                             : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(addr) : "memory");
+    else asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:16\n\tds_read_b128 %2, %5 offset:32\n\tds_read_b128 %3, %5 offset:48\n\tds_read_b128 %4, %5 offset:64\n\ts_waitcnt lgkmcnt(0)"
+                      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]) : "v"(addr) : "memory");
+    T e[5 * EPV];
+#pragma unroll
+    for (int i = 0; i < NV; i++) av_unpack(v[i], &e[i * EPV]);
+#pragma unroll
+    for (int i = 0; i < N; i++) out[i] = e[i];
+}
+
+// dpp_scan (kernels_common.h) with the in-row powers M^(1,2,4,8) fetched from the wave's LDS table by the reads above
+template <typename T, int D, int SPL /* bytes per level */>
+__device__ inline void dpp_scan_dma(T* z, unsigned sp_addr, const T* pj) {
+    T t[D], m[D * D];
+    lds_read_uniform<T, D * D>(sp_addr + 0 * SPL, m);
+#pragma unroll
+    for (int i = 0; i < D; i++) t[i] = dpp0<DPP_ROW_SHR + 1, 0xF>(z[i]);
+    matvec_acc<T, D>(m, t, z);
+    lds_read_uniform<T, D * D>(sp_addr + 1 * SPL, m);
+#pragma unroll
+    for (int i = 0; i < D; i++) t[i] = dpp0<DPP_ROW_SHR + 2, 0xF>(z[i]);
+    matvec_acc<T, D>(m, t, z);
+    lds_read_uniform<T, D * D>(sp_addr + 2 * SPL, m);
+#pragma unroll
+    for (int i = 0; i < D; i++) t[i] = dpp0<DPP_ROW_SHR + 4, 0xF>(z[i]);
+    matvec_acc<T, D>(m, t, z);
+    lds_read_uniform<T, D * D>(sp_addr + 3 * SPL, m);
+#pragma unroll
+    for (int i = 0; i < D; i++) t[i] = dpp0<DPP_ROW_SHR + 8, 0xF>(z[i]);
+    matvec_acc<T, D>(m, t, z);
+#pragma unroll
+    for (int i = 0; i < D; i++) t[i] = dpp0<DPP_ROW_BCAST15, 0x2>(z[i]);
+    matvec_acc<T, D>(pj, t, z);
+#pragma unroll
+    for (int i = 0; i < D; i++) t[i] = dpp0<DPP_ROW_BCAST15, 0x4>(z[i]);
+    matvec_acc<T, D>(pj, t, z);
+#pragma unroll
+    for (int i = 0; i < D; i++) t[i] = dpp0<DPP_ROW_BCAST15, 0x8>(z[i]);
+    matvec_acc<T, D>(pj, t, z);
+}
+
+// Per-latent constants of the DMA kernel: as FastConst, the scan powers by LDS address
+template <typename T, int D, int CK>
+struct DmaConst {
+    T a[D * D], k[D], g[CK * D];
+    unsigned sp_addr;
+    T pj[D * D];
+};
+
+// the segment solve of fast_segment() on top of dpp_scan_dma.  TAIL: 0 = full segment; 1 = ragged, the stream ends on a chunk boundary (whole lanes
+// are valid or not: no per-tick mask, lanes past the end hold zeros and are simply not counted); 2 = ragged, any length (replay masked per tick)
+template <typename T, int D, int CK, int SPL, bool NLL, int TAIL>
+__device__ inline bool dma_segment(T* y, T* xin, const DmaConst<T, D, CK>& c, int lane, size_t t0, size_t Tlen, double& acc, unsigned& nobs) {
+    T z[D];
+#pragma unroll
+    for (int i = 0; i < D; i++) z[i] = T(0);
+#pragma unroll
+    for (int k = 0; k < CK; k++)
+#pragma unroll
+        for (int i = 0; i < D; i++) z[i] = fma(c.g[k * D + i], y[k], z[i]);
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < D; i++) bad |= (z[i] != z[i]);
+    if (__any(bad)) return false;
+    {
+        T x0[D], m[D * D];
+        lds_read_uniform<T, D * D>(c.sp_addr, m);      // M = M^1 (level 0 of the table)
+#pragma unroll
+        for (int i = 0; i < D; i++) x0[i] = (lane == 0) ? xin[i] : T(0);
+        matvec_acc<T, D>(m, x0, z);
+    }
+    dpp_scan_dma<T, D, SPL>(z, c.sp_addr, c.pj);
+    T xs[D];
+#pragma unroll
+    for (int i = 0; i < D; i++) xs[i] = wave_shr1(z[i], xin[i]);
+    FastConst<T, D, CK> fc;                            // replay_chunk reads a, k only (references: no copies survive inlining)
+#pragma unroll
+    for (int i = 0; i < D * D; i++) fc.a[i] = c.a[i];
+#pragma unroll
+    for (int i = 0; i < D; i++) fc.k[i] = c.k[i];
+    int jl = 63;
+    if (TAIL == 1) {
+        // whole lanes: lane j is valid iff t0 < Tlen; invalid lanes replay zeros from whatever state the scan gave them -- nobody reads them
+        double part = 0.0; unsigned none = 0;
+        replay_chunk<T, D, CK, NLL, false>(y, xs, fc, t0, Tlen, part, none);
+        const bool valid = t0 < Tlen;
+        if (NLL) { acc += valid ? part : 0.0; nobs += valid ? (unsigned)CK : 0u; }
+        jl = (int)((Tlen - 1 - (t0 - (size_t)lane * CK)) / CK);
+    } else if (TAIL == 2) {
+        replay_chunk<T, D, CK, NLL, true>(y, xs, fc, t0, Tlen, acc, nobs);
+        jl = (int)((Tlen - 1 - (t0 - (size_t)lane * CK)) / CK);
+    } else {
+        replay_chunk<T, D, CK, NLL, false>(y, xs, fc, t0, Tlen, acc, nobs);
+    }
+#pragma unroll
+    for (int i = 0; i < D; i++) xin[i] = read_lane(xs[i], jl);
+    return true;
+}
+
+template <typename T, int D, int CK, bool WRITE, bool NLL, int NP, int MINW>
+__global__ void __launch_bounds__(64 * kWavesPerBlock, MINW)
+filter_dma_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, const T* __restrict__ cbT, const double* __restrict__ cb64,
+                  const T* xin0, T* x, T* __restrict__ yhat, double* __restrict__ nll, size_t ldo) {
+    using Lay = CB<D>;
+    using AV = typename AsmVec<T>::type;
+    constexpr int EPV = 16 / sizeof(T);
+    constexpr int VPL = CK / EPV;
+    static_assert(VPL == 4, "a chunk is four 16-byte vectors in both precisions");
+    constexpr int SEG = 64 * CK;                               // ticks per segment
+    constexpr int PT = 16 * CK;                                // ticks per piece (1 KB)
+    constexpr int SPL = ((D * D * (int)sizeof(T)) + 15) / 16 * 16;   // bytes per level of the LDS power table
+    constexpr int WAVE_LDS = NP * 1024 + 4 * SPL;
+    static_assert(NP >= 8 && NP <= 40, "ring of 8 .. 40 pieces");
+    constexpr int WSTEADY = NP - 4 + (WRITE ? 4 : 0);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t l = (size_t)blockIdx.x * kWavesPerBlock + wave;
+    if (l >= L) return;
+    unsigned char* ring = smem + (size_t)wave * WAVE_LDS;
+    const unsigned ring_addr = lds_addr_of(ring);
+    const unsigned sp_addr = ring_addr + NP * 1024;
+    const T* cb = cbT + l * Lay::SIZE;
+
+    if (Tlen == 0) {                                           // nothing to sweep: the state passes through, no NLL term
+        if (lane == 0 && cb[Lay::SCANOK] != T(0)) {
+#pragma unroll
+            for (int i = 0; i < D; i++) x[l * D + i] = xin0[l * D + i];
+            if (NLL) nll[l] = 0.0;
+        }
+        return;
+    }
+    // ---- the stream first: prologue, the whole ring -----------------------------------------------------------------------------------
+    const size_t nseg = (Tlen + SEG - 1) / SEG;
+    const size_t nfullp = Tlen / PT;                           // pieces that lie entirely inside the stream
+    const unsigned jj = lane & 15, rr = lane >> 4;
+    const unsigned sw = (jj ^ (jj >> 2)) & 3;
+    // byte offset of this lane's vector inside a piece, as fetched / stored (the swizzle lives on the global side)
+    const unsigned goff = (unsigned)(((lane & ~3) | ((lane & 3) ^ (((lane >> 2) ^ (lane >> 4)) & 3))) * 16);
+    const unsigned char* rowb = reinterpret_cast<const unsigned char*>(Ty + l * ld);
+    // last vector of the row that starts inside the stream (ld >= roundup(T, EPV): it is in bounds); pieces past the end re-read it
+    const size_t lastv = ((Tlen - 1) / EPV) * 16;
+    auto issue_piece = [&](size_t p, unsigned slot, bool inside) {
+        lds_void_t* dst = (lds_void_t*)(ring + (size_t)slot * 1024);
+        if (inside) {
+            __builtin_amdgcn_global_load_lds((glb_cvoid_t*)(rowb + p * 1024 + goff), dst, 16, 0, 0);
+        } else {
+            size_t o = p * 1024 + goff;
+            o = o < lastv ? o : lastv;
+            __builtin_amdgcn_global_load_lds((glb_cvoid_t*)(rowb + o), dst, 16, 0, 0);
+        }
+    };
+    if (nfullp >= (size_t)NP) {
+#pragma unroll
+        for (int i = 0; i < NP; i++) issue_piece((size_t)i, (unsigned)i, true);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NP; i++) issue_piece((size_t)i, (unsigned)i, false);
+    }
+    // ---- per-lane constants: plain loads, issued behind the ring.  The compiler waits for them with vmcnt(0) at their first use (it does
+    // not count past LDS-DMA operations): once per sweep, inside segment 0, which needs the head of the ring anyway ------------------------
+    DmaConst<T, D, CK> c;
+#pragma unroll
+    for (int i = 0; i < D * D; i++) c.pj[i] = cb[Lay::PJ + (lane & 15) * D * D + i];
+    const T spv = cb[Lay::SP + (lane < 4 * D * D ? lane : 0)];   // lane e < 4 D D: entry e of the power table, on its way to LDS
+
+    // ---- wave-uniform constants (scalar loads: their own counter) -------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < D * D; i++) c.a[i] = cb[Lay::A + i];
+#pragma unroll
+    for (int i = 0; i < D; i++) c.k[i] = cb[Lay::K + i];
+#pragma unroll
+    for (int i = 0; i < CK * D; i++) c.g[i] = cb[Lay::G + i];
+    c.sp_addr = sp_addr;
+    const T scanok = cb[Lay::SCANOK];
+    T xin[D];
+#pragma unroll
+    for (int i = 0; i < D; i++) xin[i] = xin0[l * D + i];
+    double acc = 0.0;
+    unsigned nobs = 0;
+    size_t nobs_uniform = 0;
+    unsigned char* orowb = WRITE ? reinterpret_cast<unsigned char*>(yhat + l * ldo) : nullptr;
+
+    unsigned slot0 = 0;
+    for (size_t seg = 0; seg < nseg; seg++) {
+        // ---- wait for this segment's four pieces ------------------------------------------------------------------------------------
+        if (seg == 0) {
+            wait_vmcnt<NP - 4>();
+            // power table -> LDS, level lv at sp_addr + lv SPL
+            if (lane < 4 * D * D) {
+                const unsigned a = sp_addr + (unsigned)(lane / (D * D)) * SPL + (unsigned)(lane % (D * D)) * (unsigned)sizeof(T);
+                if constexpr (sizeof(T) == 4) asm volatile("ds_write_b32 %0, %1" :: "v"(a), "v"(spv) : "memory");
+                else asm volatile("ds_write_b64 %0, %1" :: "v"(a), "v"(spv) : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // An unstable latent (rho(AKHA) > 1: scan tables overflowed, flagged by IHGP::update) is left to filter_seq_kernel
+            if (scanok == T(0)) break;
+        } else {
+            wait_vmcnt<WSTEADY>();
+        }
+        const size_t tbase = seg * SEG;
+        const size_t t0 = tbase + (size_t)lane * CK;
+        // this lane's 64 bytes: row rr of the segment = piece 4 seg + rr, in slot (slot0 + rr) mod NP
+        unsigned sl = slot0 + rr; sl = sl >= (unsigned)NP ? sl - NP : sl;
+        const unsigned cbase = ring_addr + sl * 1024 + jj * 64;
+        const unsigned ca0 = cbase + (sw << 4), ca1 = cbase + ((sw ^ 1u) << 4), ca2 = cbase + ((sw ^ 2u) << 4), ca3 = cbase + ((sw ^ 3u) << 4);   // vector k at 16 (k ^ sw)
+        bool done;
+        {
+            AV v[4];
+            lds_read4<AV>(ca0, ca1, ca2, ca3, v);
+            T y[CK];
+#pragma unroll
+            for (int k = 0; k < 4; k++) av_unpack(v[k], &y[k * EPV]);
+            const bool full = tbase + SEG <= Tlen;
+            if (full) {
+                done = dma_segment<T, D, CK, SPL, NLL, 0>(y, xin, c, lane, t0, Tlen, acc, nobs);
+                if (done) nobs_uniform += SEG;
+            } else {
+                // ticks past the end: clamped pieces hold copies of the last vector, the row's padding anything
+#pragma unroll
+                for (int k = 0; k < CK; k++) y[k] = (t0 + k) < Tlen ? y[k] : T(0);
+                if (Tlen % CK == 0) done = dma_segment<T, D, CK, SPL, NLL, 1>(y, xin, c, lane, t0, Tlen, acc, nobs);
+                else done = dma_segment<T, D, CK, SPL, NLL, 2>(y, xin, c, lane, t0, Tlen, acc, nobs);
+            }
+            if (!done) {
+                // missing data: the chunk goes back to the lane's 64 bytes in natural order for generic_segment (whose LDS accesses the
+                // compiler sees and orders behind every DMA in flight: correct, and this path is bound by its arithmetic)
+#pragma unroll
+                for (int k = 0; k < 4; k++) v[k] = av_pack(&y[k * EPV]);
+                lds_write4<AV>(cbase, cbase + 16, cbase + 32, cbase + 48, v);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wave_lds_fence();
+                T* chunk = reinterpret_cast<T*>(ring + (size_t)sl * 1024 + jj * 64);
+                generic_segment<T, D, CK, NLL>(chunk, xin, cb, lane, t0, Tlen, acc, nobs);
+                wave_lds_fence();
+                if (WRITE) {
+                    lds_read4<AV>(cbase, cbase + 16, cbase + 32, cbase + 48, v);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) av_unpack(v[k], &y[k * EPV]);
+                }
+            }
+            if (WRITE) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) v[k] = av_pack(&y[k * EPV]);
+                lds_write4<AV>(ca0, ca1, ca2, ca3, v);
+            }
+        }
+        // ---- results: LDS (linear per piece) -> streaming stores, 1 KB contiguous per instruction -----------------------------------
+        unsigned s1 = slot0 + 1, s2 = slot0 + 2, s3 = slot0 + 3;
+        s1 = s1 >= (unsigned)NP ? s1 - NP : s1; s2 = s2 >= (unsigned)NP ? s2 - NP : s2; s3 = s3 >= (unsigned)NP ? s3 - NP : s3;
+        if (WRITE) {
+            AV o[4];
+            const unsigned la = ring_addr + (unsigned)lane * 16;
+            lds_read4<AV>(la + slot0 * 1024, la + s1 * 1024, la + s2 * 1024, la + s3 * 1024, o);
+            unsigned char* po = orowb + tbase * sizeof(T) + goff;
+            if (tbase + SEG <= Tlen) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) __builtin_nontemporal_store(o[i], reinterpret_cast<AV*>(po + i * 1024));
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if (tbase * sizeof(T) + i * 1024 + goff < Tlen * sizeof(T)) __builtin_nontemporal_store(o[i], reinterpret_cast<AV*>(po + i * 1024));
+            }
+        }
+        // ---- refill the four slots with the pieces NP ahead (only while another segment will wait on the count) ---------------------
+        if (seg + 1 < nseg) {
+            const size_t pn = 4 * seg + NP;
+            if (pn + 4 <= nfullp) { issue_piece(pn + 0, slot0, true); issue_piece(pn + 1, s1, true); issue_piece(pn + 2, s2, true); issue_piece(pn + 3, s3, true); }
+            else { issue_piece(pn + 0, slot0, false); issue_piece(pn + 1, s1, false); issue_piece(pn + 2, s2, false); issue_piece(pn + 3, s3, false); }
+        }
+        slot0 += 4; slot0 = slot0 >= (unsigned)NP ? slot0 - NP : slot0;
+    }
+    wait_vmcnt<0>();                                           // no DMA may land in LDS that the next workgroup already owns
+
+    if (scanok == T(0)) return;
+    if (NLL) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            acc += __shfl_xor(acc, o);
+            nobs += __shfl_xor(nobs, o);
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < D; i++) x[l * D + i] = xin[i];
+        if (NLL) {
+            const double* c64 = cb64 + l * Lay::SIZE;
+            const double n = (double)nobs_uniform + (double)nobs;
+            nll[l] = 0.5 * (acc / c64[Lay::S] + n * c64[Lay::LOGS]);   // sum of ihgp.h:207 terms
+        }
+    }
+}
+
+template <typename T, int D, int CK, int NP, int MINW>
+int launch_filter_dma_t(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, const double* cb64, const void* xin, void* x,
+                        void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, int n_unstable, double* total, size_t ldo) {
+    constexpr int SPL = ((D * D * (int)sizeof(T)) + 15) / 16 * 16;
+    constexpr size_t smem = (size_t)kWavesPerBlock * (NP * 1024 + 4 * SPL);
+    dim3 block(64 * kWavesPerBlock), grid((unsigned)((L + kWavesPerBlock - 1) / kWavesPerBlock));
+    const T* ty = static_cast<const T*>(Ty);
+    const T* xi = static_cast<const T*>(xin);
+    T* xs = static_cast<T*>(x);
+    T* yh = static_cast<T*>(yhat);
+#define MOIHGP_DMA_LAUNCH(W_, N_)                                                                                                     \
+    do {                                                                                                                              \
+        auto kfn = filter_dma_kernel<T, D, CK, W_, N_, NP, MINW>;                                                                     \
+        if (smem > 65536) {                                                                                                           \
+            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+            if (attr != hipSuccess) { set_last_error("filter_dma_kernel: %zu bytes of LDS refused: %s", smem, hipGetErrorString(attr)); return 2; } \
+        }                                                                                                                             \
+        hipExtLaunchKernelGGL(kfn, grid, block, smem, stream, ev0, ev1, 0, ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, ldo);         \
+    } while (0)
+    if (yhat && nll) MOIHGP_DMA_LAUNCH(true, true);
+    else if (yhat) MOIHGP_DMA_LAUNCH(true, false);
+    else if (nll) MOIHGP_DMA_LAUNCH(false, true);
+    else MOIHGP_DMA_LAUNCH(false, false);
+#undef MOIHGP_DMA_LAUNCH
+    if (n_unstable > 0)
+        hipLaunchKernelGGL((filter_seq_kernel<T, D>), dim3((unsigned)((L + 63) / 64)), dim3(64), 0, stream, ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, ldo);
+    if (total && nll) hipLaunchKernelGGL(nll_total_kernel, dim3(1), dim3(1024), 0, stream, nll, L, total);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_last_error("filter_dma_kernel launch: %s", hipGetErrorString(e)); return 2; }
+    return 0;
+}
+
 template <typename T, int D, int CK, int MINW, bool SPLIT>
 int launch_filter_t(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, const double* cb64, const void* xin, void* x,
                     void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, int nsplit, size_t Tslice, int n_unstable,
@@ -876,9 +1264,30 @@ int launch_filter_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, 
         return 0;
     }
     if (variant == 1 && dtype == 1 && d == 3) MOIHGP_FILTER_CASE(float, 3, kChunk32, 1, cb32);
+    // LDS-DMA kernel, ring length / waves per SIMD probes (d = 3): 20 + k
+    if (variant >= 20 && variant < 30 && d == 3 && nsplit == 1) {
+#define MOIHGP_DMA_PROBE(V_, NP_, MW_)                                                                                                  \
+        if (variant == V_) return dtype == 0 ? launch_filter_dma_t<double, 3, kChunk64, NP_, MW_>(Ty, T, ld, L, cb64, cb64, xin, x, yhat, nll, stream, ev0, ev1, n_unstable, total, ldo) \
+                                             : launch_filter_dma_t<float, 3, kChunk32, NP_, MW_>(Ty, T, ld, L, cb32, cb64, xin, x, yhat, nll, stream, ev0, ev1, n_unstable, total, ldo)
+        MOIHGP_DMA_PROBE(20, 8, 4); MOIHGP_DMA_PROBE(21, 9, 4); MOIHGP_DMA_PROBE(22, 12, 3); MOIHGP_DMA_PROBE(23, 16, 2); MOIHGP_DMA_PROBE(24, 8, 3);
+        MOIHGP_DMA_PROBE(25, 12, 2); MOIHGP_DMA_PROBE(26, 8, 2); MOIHGP_DMA_PROBE(27, 20, 2);
+#undef MOIHGP_DMA_PROBE
+    }
+    if (variant == 10) variant = 0;      // 10: the register-staged kernel whatever the default
+    else if (variant == 0) variant = -1; // 0: the shipped default (below)
 #else
     if (variant != 0) { set_last_error("filter variant %d: tuning probes are compiled only with -DMOIHGP_TUNING", variant); return 1; }
+    variant = -1;
 #endif
+    // many latents (no time split): the LDS-DMA kernel
+    if (variant == -1 && nsplit == 1 && MOIHGP_FILTER_DMA) {
+        if (dtype == 0) {
+            if (d == 2) return launch_filter_dma_t<double, 2, kChunk64, kDmaRing64, kDmaWaves64>(Ty, T, ld, L, cb64, cb64, xin, x, yhat, nll, stream, ev0, ev1, n_unstable, total, ldo);
+            return launch_filter_dma_t<double, 3, kChunk64, kDmaRing64, kDmaWaves64>(Ty, T, ld, L, cb64, cb64, xin, x, yhat, nll, stream, ev0, ev1, n_unstable, total, ldo);
+        }
+        if (d == 2) return launch_filter_dma_t<float, 2, kChunk32, kDmaRing32, kDmaWaves32>(Ty, T, ld, L, cb32, cb64, xin, x, yhat, nll, stream, ev0, ev1, n_unstable, total, ldo);
+        return launch_filter_dma_t<float, 3, kChunk32, kDmaRing32, kDmaWaves32>(Ty, T, ld, L, cb32, cb64, xin, x, yhat, nll, stream, ev0, ev1, n_unstable, total, ldo);
+    }
     if (dtype == 0) {
         if (d == 2) MOIHGP_FILTER_CASE(double, 2, kChunk64, 1, cb64);
         MOIHGP_FILTER_CASE(double, 3, kChunk64, 1, cb64);

@@ -160,6 +160,7 @@ moihgp_dvec_ctx* moihgp_dvec_ctx_new(void) {
     if (rc) { moihgp_dvec_ctx_del(c); return nullptr; }
     return c;
 }
+void* moihgp_dvec_ctx_stream(moihgp_dvec_ctx* c) { return c ? (void*)c->stream : nullptr; }
 void moihgp_dvec_ctx_del(moihgp_dvec_ctx* c) {
     if (!c) return;
     if (c->partial) (void)hipFree(c->partial);

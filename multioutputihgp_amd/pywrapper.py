@@ -170,20 +170,30 @@ class MOIHGP(object):
         import torch
         if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and t.numel() == n):
             raise ValueError(f"{what}: a contiguous CUDA float64 tensor of {n} elements is required")
-        # the entries work on the handle's own stream and expect their operands complete at the call (include/moihgp.h): whatever torch has
-        # queued for this tensor on its current stream -- the fill of a torch.zeros, a clone -- is waited for here
-        torch.cuda.current_stream(t.device).synchronize()
         from ctypes import c_void_p
         return c_void_p(t.data_ptr())
 
-    def update_dev(self, params_dev):
-        """`update` (pywrapper.py:199-201) from a parameter vector that lives on the device: no 8 (M L + ..)-byte host copy."""
-        rc = self.__lib.moihgp_update_dev(self.__obj, self.__dev_ptr(params_dev, self.num_param, "params_dev"))
+    @staticmethod
+    def __stream_ptr(stream, t):
+        """hipStream_t the `_on` entries order themselves by: the given torch stream, else torch's current stream on the tensor's device
+        -- whatever torch has queued there for the operands (the fill of a torch.zeros, a clone, a producer kernel) is waited for by an
+        event on the device, not by the host (include/moihgp.h: moihgp_update_dev_on / moihgp_window_eval_dev_on)."""
+        import torch
+        from ctypes import c_void_p
+        s = torch.cuda.current_stream(t.device) if stream is None else stream
+        return c_void_p(s.cuda_stream)
+
+    def update_dev(self, params_dev, stream=None):
+        """`update` (pywrapper.py:199-201) from a parameter vector that lives on the device: no 8 (M L + ..)-byte host copy.  Ordered behind
+        `stream` (default: torch's current stream); returns, like `update`, when the new tables are complete."""
+        rc = self.__lib.moihgp_update_dev_on(self.__obj, self.__dev_ptr(params_dev, self.num_param, "params_dev"), self.__stream_ptr(stream, params_dev))
         if rc != 0:
-            raise MoihgpError(last_error(self.__lib) or "moihgp_update_dev failed", rc)
+            raise MoihgpError(last_error(self.__lib) or "moihgp_update_dev_on failed", rc)
 
     def params_dev(self, out):
         """`params` into a device vector."""
+        import torch
+        torch.cuda.current_stream(out.device).synchronize()          # (this entry works on the handle's stream and has no stream argument)
         rc = self.__lib.moihgp_get_params_dev(self.__obj, self.__dev_ptr(out, self.num_param, "out"))
         if rc != 0:
             raise MoihgpError(last_error(self.__lib) or "moihgp_get_params_dev failed", rc)
@@ -196,17 +206,18 @@ class MOIHGP(object):
         if rc != 0:
             raise MoihgpError(last_error(self.__lib) or "moihgp_window_set failed", rc)
 
-    def window_objective_dev(self, x_dev, dx_dev, loss_dev, grad_dev, xnew_dev=None, dxnew_dev=None):
+    def window_objective_dev(self, x_dev, dx_dev, loss_dev, grad_dev, xnew_dev=None, dxnew_dev=None, stream=None):
         """`window_objective` on the installed window with every operand on the device: state in, loss (1-element tensor) and gradient
-        [num_param] out, optionally the state after the window."""
+        [num_param] out, optionally the state after the window.  Asynchronous: operands are taken in `stream`'s order (default: torch's
+        current stream) and the results are ordered in front of whatever is queued on it afterwards; the host is not synchronised."""
         L, d, P = self.num_latent, self.igp_dim, self.num_igp_param
-        rc = self.__lib.moihgp_window_eval_dev(
+        rc = self.__lib.moihgp_window_eval_dev_on(
             self.__obj, self.__dev_ptr(x_dev, L * d, "x_dev"), self.__dev_ptr(dx_dev, L * P * d, "dx_dev"), self.__dev_ptr(loss_dev, 1, "loss_dev"),
             self.__dev_ptr(grad_dev, self.num_param, "grad_dev"),
             None if xnew_dev is None else self.__dev_ptr(xnew_dev, L * d, "xnew_dev"),
-            None if dxnew_dev is None else self.__dev_ptr(dxnew_dev, L * P * d, "dxnew_dev"))
+            None if dxnew_dev is None else self.__dev_ptr(dxnew_dev, L * P * d, "dxnew_dev"), self.__stream_ptr(stream, x_dev))
         if rc != 0:
-            raise MoihgpError(last_error(self.__lib) or "moihgp_window_eval_dev failed", rc)
+            raise MoihgpError(last_error(self.__lib) or "moihgp_window_eval_dev_on failed", rc)
 
     @property
     def num_output(self):

@@ -149,6 +149,8 @@ def lib(native: bool = False, wide: bool = False):
     L.orc_filter_stream_f32.restype = C.c_double
     L.orc_grad_stream.argtypes = [C.POINTER(OrcIHGP), C.c_size_t, C.c_size_t, _dp, C.c_size_t, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_int]
     L.orc_grad_stream.restype = C.c_double
+    L.orc_filter_stream_fast.argtypes = [C.POINTER(OrcIHGP), C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, _dp, C.c_int, C.c_int]
+    L.orc_filter_stream_fast.restype = C.c_double
     L.orc_filter_stream_refshaped.argtypes = [C.POINTER(OrcIHGP), C.c_size_t, C.c_size_t, _dp, C.c_size_t, C.c_int, _dp, _dp]
     L.orc_filter_stream_refshaped.restype = C.c_double
     L.orc_max_threads.restype = C.c_int
@@ -319,6 +321,22 @@ def filter_stream(igps, Ty, ld=None, layout=0, x0=None, want_yhat=True, nthreads
         nll = Lb.orc_filter_stream_f32(igps, L, T, _ptr(Ty, _fp), ld, layout, _ptr(x, _fp), _ptr(yhat, _fp), _ptr(nll_l), nthreads)
     else:
         nll = Lb.orc_filter_stream(igps, L, T, _ptr(Ty), ld, layout, _ptr(x), _ptr(yhat), _ptr(nll_l), nthreads)
+    return dict(yhat=yhat, x=x, nll=float(nll), nll_per_latent=nll_l)
+
+
+def filter_stream_fast(igps, Ty, ld=None, layout=0, x0=None, want_yhat=True, nthreads=1, native=False):
+    """The fair-optimised CPU baseline (orc_filter_stream_fast: d-specialised, SIMD across latents); same contract as filter_stream."""
+    Lb = lib(native, isinstance(igps[0], OrcIHGPX))
+    f32 = Ty.dtype == np.float32
+    Ty = np.ascontiguousarray(Ty)
+    L, T = Ty.shape if layout == 0 else Ty.shape[::-1]
+    ld = Ty.shape[1] if ld is None else ld
+    d = igps[0].d
+    dt = np.float32 if f32 else np.float64
+    x = np.zeros((L, d), dtype=dt) if x0 is None else np.array(x0, dtype=dt).reshape(L, d).copy()
+    yhat = np.zeros_like(Ty) if want_yhat else None
+    nll_l = np.zeros(L)
+    nll = Lb.orc_filter_stream_fast(igps, L, T, Ty.ctypes.data, ld, layout, x.ctypes.data, yhat.ctypes.data if want_yhat else None, _ptr(nll_l), nthreads, int(f32))
     return dict(yhat=yhat, x=x, nll=float(nll), nll_per_latent=nll_l)
 
 

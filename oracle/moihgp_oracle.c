@@ -796,6 +796,104 @@ double orc_filter_stream_f32(const orc_ihgp* g, size_t L, size_t T, const float*
     return total;
 }
 
+/* ---------------------------------------------------------------- fair-optimised CPU baseline (BASELINE.md variant (ii), round 4)
+ * The same filter sweep as orc_filter_stream (ihgp.h:81-93 + :204-209 per tick and latent) written the way a CPU wants it, so that the
+ * number bench.py prints next to the GPU's is a fair one: state dimension fixed at compile time (one instantiation per d), the layout
+ * branch hoisted out of the tick loop, no division and no isnan branch per tick, and FB latents side by side in the lanes of a SIMD
+ * register (struct-of-arrays constants and states per block; the tick loop is `omp simd` over the block).  Series-major streams are
+ * transposed tile by tile (FT ticks x FB latents) so that the recursion reads and writes contiguous vectors.  Innovation form
+ * (v = y - HA x, x' = A x + K v; a missing tick is v = 0: ihgp.h:83-87), Sum v^2 accumulated per tile in stream precision and in fp64 across
+ * tiles: results equal orc_filter_stream's to rounding (tests/test_oracle.py), not bit for bit.  Timed by bench.py only. */
+#define FB64 8
+#define FB32 16
+#define FT 64
+
+#define ORC_DEF_FAST(N, REAL, FB, SUF)                                                                                            \
+static void fast_block_##N##SUF(const orc_ihgp* g, size_t nb, size_t T, const REAL* Ty, size_t ld, int layout, size_t l0,         \
+                                REAL* x, REAL* yhat, double* nllp) {                                                             \
+    REAL A[N * N][FB], K[N][FB], HA[N][FB], xs[N][FB], yb[FT][FB], ob[FT][FB], part[FB];                                          \
+    double Sinv[FB], logS[FB], acc[FB], cnt[FB];                                                                                  \
+    for (size_t b = 0; b < FB; b++) {                                                                                             \
+        const orc_ihgp* gl = &g[b < nb ? b : 0];                                                                                  \
+        for (int i = 0; i < N * N; i++) A[i][b] = (REAL)gl->A[i];                                                                 \
+        for (int i = 0; i < N; i++) { K[i][b] = (REAL)gl->K[i]; HA[i][b] = (REAL)gl->HA[i]; xs[i][b] = b < nb ? x[(l0 + b) * N + i] : (REAL)0; } \
+        Sinv[b] = 1.0 / gl->S; logS[b] = log(gl->S); acc[b] = 0.0; cnt[b] = 0.0;                                                   \
+    }                                                                                                                             \
+    for (size_t t0 = 0; t0 < T; t0 += FT) {                                                                                       \
+        const size_t tt = T - t0 < FT ? T - t0 : FT;                                                                              \
+        if (layout == 0) {                                                                                                        \
+            for (size_t b = 0; b < FB; b++) {                                                                                     \
+                if (b < nb) { const REAL* r = Ty + (l0 + b) * ld + t0; for (size_t t = 0; t < tt; t++) yb[t][b] = r[t]; }         \
+                else for (size_t t = 0; t < tt; t++) yb[t][b] = (REAL)NAN;                                                        \
+            }                                                                                                                     \
+        } else {                                                                                                                  \
+            for (size_t t = 0; t < tt; t++) { const REAL* r = Ty + (t0 + t) * ld + l0; for (size_t b = 0; b < FB; b++) yb[t][b] = b < nb ? r[b] : (REAL)NAN; } \
+        }                                                                                                                         \
+        for (size_t b = 0; b < FB; b++) part[b] = (REAL)0;                                                                        \
+        for (size_t t = 0; t < tt; t++) {                                                                                         \
+            _Pragma("omp simd")                                                                                                   \
+            for (size_t b = 0; b < FB; b++) {                                                                                     \
+                const REAL y = yb[t][b];                                                                                          \
+                const int obs = (y == y);                                                                                         \
+                REAL hx = (REAL)0, xn[N];                                                                                         \
+                for (int i = 0; i < N; i++) hx += HA[i][b] * xs[i][b];                                                            \
+                const REAL v = obs ? y - hx : (REAL)0;                                                                            \
+                part[b] += v * v;                                                                                                 \
+                cnt[b] += obs ? 1.0 : 0.0;                                                                                        \
+                for (int i = 0; i < N; i++) { REAL s_ = K[i][b] * v; for (int k = 0; k < N; k++) s_ += A[i * N + k][b] * xs[k][b]; xn[i] = s_; } \
+                for (int i = 0; i < N; i++) xs[i][b] = xn[i];                                                                     \
+                ob[t][b] = xn[0];                                                                                                 \
+            }                                                                                                                     \
+        }                                                                                                                         \
+        for (size_t b = 0; b < FB; b++) acc[b] += (double)part[b];                                                                \
+        if (yhat) {                                                                                                               \
+            if (layout == 0) { for (size_t b = 0; b < nb; b++) { REAL* r = yhat + (l0 + b) * ld + t0; for (size_t t = 0; t < tt; t++) r[t] = ob[t][b]; } } \
+            else { for (size_t t = 0; t < tt; t++) { REAL* r = yhat + (t0 + t) * ld + l0; for (size_t b = 0; b < nb; b++) r[b] = ob[t][b]; } } \
+        }                                                                                                                         \
+    }                                                                                                                             \
+    for (size_t b = 0; b < nb; b++) {                                                                                             \
+        for (int i = 0; i < N; i++) x[(l0 + b) * N + i] = xs[i][b];                                                               \
+        nllp[b] = 0.5 * (acc[b] * Sinv[b] + cnt[b] * logS[b]);                                                                    \
+    }                                                                                                                             \
+}
+
+ORC_DEF_FAST(2, double, FB64, d) ORC_DEF_FAST(3, double, FB64, d) ORC_DEF_FAST(2, float, FB32, f) ORC_DEF_FAST(3, float, FB32, f)
+#if ORC_DMAX >= 12
+ORC_DEF_FAST(4, double, FB64, d) ORC_DEF_FAST(6, double, FB64, d) ORC_DEF_FAST(8, double, FB64, d) ORC_DEF_FAST(9, double, FB64, d) ORC_DEF_FAST(12, double, FB64, d)
+ORC_DEF_FAST(4, float, FB32, f) ORC_DEF_FAST(6, float, FB32, f) ORC_DEF_FAST(8, float, FB32, f) ORC_DEF_FAST(9, float, FB32, f) ORC_DEF_FAST(12, float, FB32, f)
+#endif
+
+/* is_f32: Ty / x / yhat are float arrays (the fp32 configs), else double.  Returns the total NLL, or NAN for a state dimension without an
+ * instantiation (or latents of mixed dimension). */
+double orc_filter_stream_fast(const orc_ihgp* g, size_t L, size_t T, const void* Ty, size_t ld, int layout, void* x, void* yhat,
+                              double* nll_per_latent, int nthreads, int is_f32) {
+    if (L == 0) return 0.0;
+    const int n = g[0].d;
+    for (size_t l = 1; l < L; l++) if (g[l].d != n) return NAN;
+    const size_t fb = is_f32 ? FB32 : FB64, nblk = (L + fb - 1) / fb;
+    double total = 0.0;
+    int bad = 0;
+    (void)nthreads;
+#pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) reduction(+ : total) schedule(static)
+    for (long bi = 0; bi < (long)nblk; bi++) {
+        const size_t l0 = (size_t)bi * fb, nb = L - l0 < fb ? L - l0 : fb;
+        double nl[FB32];
+#define ORC_FAST_CASE(N)                                                                                                          \
+        case N: { if (is_f32) fast_block_##N##f(g + l0, nb, T, (const float*)Ty, ld, layout, l0, (float*)x, (float*)yhat, nl);    \
+                  else fast_block_##N##d(g + l0, nb, T, (const double*)Ty, ld, layout, l0, (double*)x, (double*)yhat, nl); } break;
+        switch (n) {
+            ORC_FAST_CASE(2) ORC_FAST_CASE(3)
+#if ORC_DMAX >= 12
+            ORC_FAST_CASE(4) ORC_FAST_CASE(6) ORC_FAST_CASE(8) ORC_FAST_CASE(9) ORC_FAST_CASE(12)
+#endif
+            default: bad = 1; for (size_t b = 0; b < nb; b++) nl[b] = NAN;
+        }
+#undef ORC_FAST_CASE
+        for (size_t b = 0; b < nb; b++) { if (nll_per_latent) nll_per_latent[l0 + b] = nl[b]; total += nl[b]; }
+    }
+    return bad ? NAN : total;
+}
+
 double orc_grad_stream(const orc_ihgp* g, size_t L, size_t T, const double* Ty, size_t ld, int layout,
                        double* x, double* dx, double* yhat, double* nll_per_latent, double* grad, int nthreads) {
     double total = 0.0;

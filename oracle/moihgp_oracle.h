@@ -120,6 +120,9 @@ double orc_filter_stream_f32(const orc_ihgp* g, size_t L, size_t T, const float*
 double orc_filter_stream_refshaped(const orc_ihgp* g, size_t L, size_t T, const double* Ty, size_t ld, int layout,
                                    double* x, double* yhat);
 
+/* fair-optimised CPU baseline (round 4): d-specialised, layout hoisted, FB latents per SIMD register; equal to orc_filter_stream to rounding */
+double orc_filter_stream_fast(const orc_ihgp* g, size_t L, size_t T, const void* Ty, size_t ld, int layout, void* x, void* yhat,
+                              double* nll_per_latent, int nthreads, int is_f32);
 int orc_max_threads(void);
 
 #ifdef __cplusplus

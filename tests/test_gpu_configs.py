@@ -210,6 +210,62 @@ def test_gradient_sweep_at_full_size(env, kern, dtype):
     assert max(d) < tol, d
 
 
+def test_dev_entries_take_the_callers_stream(env):
+    """moihgp_update_dev_on / moihgp_window_eval_dev_on (include/moihgp.h): the operands may still be in flight on the caller's stream when
+    the call is made, and the results are ordered on that stream -- no host synchronisation in between.  200 iterations: a producer
+    (a large GEMM to keep the stream busy, then the arithmetic that writes the parameter vector and the start state) is queued on a torch
+    SIDE stream and the two entries are called at once; the results are copied out on the same stream.  Bit-equal to the path that
+    synchronises before every call and uses the plain entries."""
+    import ctypes as C
+    from multioutputihgp_amd import load_library
+    lib = load_library()
+    M, L, W, d, P = 96, 48, 8, 3, 3
+    rng = np.random.default_rng(SEED + 11)
+    dev = torch.device("cuda", 0)
+    gp = env["MOIHGP"](0.1, M, L, kernel="Matern52ss")
+    S = rng.uniform(0.5, 2.0, L); sigma = 0.04
+    base = np.concatenate([(np.eye(M, L) + 0.02 * rng.standard_normal((M, L))).ravel(), S, [sigma], synth_params(L, rng).ravel()])
+    delta = np.concatenate([0.01 * rng.standard_normal(M * L), np.zeros(L + 1 + L * P)])
+    gp.set_window(0.5 * rng.standard_normal((W, M)))
+    base_d, delta_d = torch.from_numpy(base).to(dev), torch.from_numpy(delta).to(dev)
+    x0_d = torch.from_numpy(0.2 * rng.standard_normal((L, d))).to(dev); dx0_d = torch.from_numpy(0.05 * rng.standard_normal((L, P, d))).to(dev)
+    busy = torch.randn((2048, 2048), device=dev)
+    n_it = 200
+    def run(synced):
+        losses = torch.zeros(n_it, dtype=torch.float64, device=dev); gsum = torch.zeros(n_it, dtype=torch.float64, device=dev)
+        gfirst = None
+        side = torch.cuda.Stream()
+        p_d = torch.empty_like(base_d); x_d = torch.empty_like(x0_d); g_d = torch.empty_like(base_d); l_d = torch.zeros(1, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        for k in range(n_it):
+            with torch.cuda.stream(side):
+                if not synced:
+                    (busy @ busy).sum()                                   # keeps the stream busy in front of the producer
+                torch.add(base_d, delta_d, alpha=float(k % 7), out=p_d)   # the producer: parameters and start state of this iteration
+                torch.mul(x0_d, 1.0 + 0.01 * (k % 5), out=x_d)
+                if synced:
+                    side.synchronize()
+                    rc = lib.moihgp_update_dev(gp.handle, C.c_void_p(p_d.data_ptr()))
+                    assert rc == 0
+                    rc = lib.moihgp_window_eval_dev(gp.handle, C.c_void_p(x_d.data_ptr()), C.c_void_p(dx0_d.data_ptr()), C.c_void_p(l_d.data_ptr()),
+                                                    C.c_void_p(g_d.data_ptr()), None, None)
+                    assert rc == 0
+                else:
+                    gp.update_dev(p_d, stream=side)
+                    gp.window_objective_dev(x_d, dx0_d, l_d, g_d, stream=side)
+                losses[k:k + 1].copy_(l_d)                                # consumers on the same stream
+                gsum[k:k + 1].copy_(g_d.sum().reshape(1))
+                if k == n_it - 1:
+                    gfirst = g_d.clone()
+        side.synchronize()
+        return losses.cpu().numpy(), gsum.cpu().numpy(), gfirst.cpu().numpy()
+    a = run(True)
+    b = run(False)
+    assert np.isfinite(a[0]).all() and len(set(a[0].tolist())) > 5
+    for u, v in zip(a, b):
+        assert np.array_equal(u, v)
+
+
 # ------------------------------------------------------------------------------------------ configs[2] at its worded size
 def test_c3_learning_loop_at_full_size(env):
     """BASELINE.json configs[2] as worded -- "M=4096 outputs, T=10000, Matern-5/2, fp32, online-learning L-BFGS outer loop" -- at

@@ -1453,6 +1453,50 @@ def test_stacked_gradstream_long_streams_vs_oracle(env, kern, dtype, L, T, gap):
         assert err(r["grad"].cpu().numpy(), o["grad"], 1e-6) < tol * 10
 
 
+@pytest.mark.parametrize("kern", ["Matern32x2", "Matern52x2", "Matern52x4"])
+def test_stacked_gradient_tables_follow_every_update(env, kern):
+    """The time-parallel gradient sweep of the stacked models reads per-latent tables that depend on the hyper-parameters
+    (gp_table_kernel).  They are rebuilt by every update -- not by the first long sweep after it: update(p2), a SHORT sweep
+    (below the 512-tick threshold: tick-by-tick kernel, touches no table), then a LONG sweep must use p2's tables; and a long
+    sweep issued on a side stream right behind an update must find them complete.  Compared with a fresh handle built at p2
+    and with the oracle."""
+    J = int(kern[-1])
+    rng = np.random.default_rng(77 + J)
+    L, Tl, Ts = 5, 4096, 100
+    p1, p2 = synth_params_stacked(L, J, rng), synth_params_stacked(L, J, rng)
+    bank = env["streams"].LatentBank(0.1, p1, kernel=kern)
+    d, P = bank.d, bank.P
+    Ty = synth(L, Tl, rng)
+    dev = to_dev(Ty, torch.float64)
+    def sweep(b, T, stream=None):
+        x = torch.zeros((L, d), dtype=torch.float64, device="cuda"); dx = torch.zeros((L, P, d), dtype=torch.float64, device="cuda")
+        if stream is None:
+            r = b.grad(dev, T=T, x=x, dx=dx, want_yhat=False)
+        else:
+            with torch.cuda.stream(stream):
+                r = b.grad(dev, T=T, x=x, dx=dx, want_yhat=False)
+        torch.cuda.synchronize()
+        return r
+    sweep(bank, Tl)                                  # tables of p1 now exist
+    bank.update(p2)
+    sweep(bank, Ts)                                  # short sweep: no table involved
+    r = sweep(bank, Tl)                              # must see p2's tables
+    fresh = env["streams"].LatentBank(0.1, p2, kernel=kern)
+    f = sweep(fresh, Tl)
+    o = env["cref"].grad_stream(env["cref"].ihgp_array(kern, 0.1, p2), Ty)
+    tame = np.abs(o["yhat"]).max(axis=1) < 1e6
+    assert tame.any()
+    for key, ok in (("grad", "grad"), ("nll", "nll_per_latent"), ("x", "x")):
+        a, b, c = r[key].cpu().numpy()[tame], f[key].cpu().numpy()[tame], o[ok][tame]
+        assert np.array_equal(a, b), key
+        assert np.abs(a - c).max() <= 1e-8 * max(np.abs(c).max(), 1e-6), key
+    # straight behind an update, on a side stream
+    side = torch.cuda.Stream()
+    bank.update(p1); bank.update(p2)
+    r2 = sweep(bank, Tl, side)
+    assert np.array_equal(r2["grad"].cpu().numpy()[tame], f["grad"].cpu().numpy()[tame])
+
+
 @pytest.mark.parametrize("kern", ["Matern52", "Matern52x2"])
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 def test_filter_separate_start_state(env, kern, dtype):

@@ -377,3 +377,33 @@ def test_step_overloads_do_not_depend_on_threading():
     assert a.negLogLikelihood(x, y) == b.negLogLikelihood(x, y)
     one = cref.GP(0.1, 3, 1, "Matern32", threading=True)
     assert one.threading is False                                            # :128-135
+
+
+@pytest.mark.parametrize("kern", ["Matern32", "Matern52", "Matern52x2", "Matern32x4", "Matern52x4"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("layout", [0, 1])
+def test_fair_cpu_baseline_equals_the_literal_sweep(kern, dtype, layout):
+    """orc_filter_stream_fast (the CPU figure bench.py prints beside the GPU's: d-specialised, SIMD across latents, innovation form) computes
+    what orc_filter_stream does -- ihgp.h:81-93 + :204-209 per tick and latent, missing ticks included -- to rounding: ragged block of latents,
+    ragged tile of ticks, both stream layouts, both precisions."""
+    rng = np.random.default_rng(5)
+    L, T = 37, 203
+    if cref.is_wide(kern):
+        J = int(kern[-1])
+        prm = np.column_stack([rng.uniform(0.5, 2, L) if c % 2 == 0 else rng.uniform(0.8, 2, L) for c in range(2 * J)] + [rng.uniform(0.05, 0.2, L)])
+    else:
+        prm = np.column_stack([rng.uniform(0.5, 2, L), rng.uniform(0.5, 2, L), rng.uniform(0.05, 0.2, L)])
+    igps = cref.ihgp_array(kern, 0.1, prm)
+    Ty = np.sin(0.05 * np.arange(T)[None, :] * (1 + np.arange(L)[:, None] % 7)) + 0.1 * rng.standard_normal((L, T))
+    Ty[3, 10:40] = np.nan; Ty[7, ::13] = np.nan; Ty[11, :] = np.nan
+    Y = np.ascontiguousarray((Ty if layout == 0 else Ty.T).astype(dtype))
+    x0 = 0.1 * rng.standard_normal((L, igps[0].d))
+    a = cref.filter_stream(igps, Y, layout=layout, x0=x0, nthreads=2)
+    b = cref.filter_stream_fast(igps, Y, layout=layout, x0=x0, nthreads=2)
+    tame = np.nan_to_num(np.abs(a["yhat"] if layout == 0 else a["yhat"].T), nan=0.0).max(axis=1) < 1e6      # (the literal DARE leaves some draws unstable)
+    assert tame.sum() > L // 2
+    tol = 1e-11 if dtype == np.float64 else 2e-4
+    ya, yb = (a["yhat"], b["yhat"]) if layout == 0 else (a["yhat"].T, b["yhat"].T)
+    assert np.abs(ya[tame] - yb[tame]).max() <= tol * np.abs(ya[tame]).max()
+    assert np.abs(a["x"][tame] - b["x"][tame]).max() <= tol * max(np.abs(a["x"][tame]).max(), 1e-3)
+    assert np.abs(a["nll_per_latent"][tame] - b["nll_per_latent"][tame]).max() <= tol * np.abs(a["nll_per_latent"][tame]).max()

@@ -15,6 +15,7 @@ ap.add_argument("--dtype", default="f32"); ap.add_argument("--L", type=int, defa
 ap.add_argument("--variants", default="0,1,2,3,4,5"); ap.add_argument("--rounds", type=int, default=5); ap.add_argument("--per", type=int, default=10)
 ap.add_argument("--nan", type=float, default=0.0); ap.add_argument("--mode", default="fn", help="f=yhat, n=nll")
 ap.add_argument("--cold", action="store_true", help="evict L2 / Infinity Cache before every launch (1 GiB write)")
+ap.add_argument("--rotate", type=int, default=0, help="rotate every launch over N distinct (input, output) stream pairs (bench.py's cold leg uses >= 768 MiB of them)")
 a = ap.parse_args()
 dtype = torch.float32 if a.dtype == "f32" else torch.float64
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)
@@ -27,6 +28,8 @@ yhat = torch.empty_like(Ty); nll = torch.empty((a.L,), dtype=torch.float64, devi
 x = torch.zeros((a.L, 3), dtype=dtype, device=dev)
 variants = [int(v) for v in a.variants.split(",")]
 evict = torch.zeros(256 * 1024 * 1024, dtype=torch.float32, device=dev) if a.cold else None
+rot = [(Ty, yhat)] + [(Ty.clone(), torch.empty_like(yhat)) for _ in range(max(0, a.rotate - 1))]
+launch_no = 0
 es = 4 if dtype == torch.float32 else 8
 nbytes = (("f" in a.mode) + 1) * es * a.L * a.T
 times = {v: [] for v in variants}; ref = None
@@ -38,14 +41,15 @@ for rnd in range(a.rounds):
             if a.cold:
                 evict.add_(1.0)
             x.zero_()
-            bank.filter(Ty, T=a.T, x=x, yhat=yhat, nll=nll, want_yhat="f" in a.mode, want_nll="n" in a.mode)
+            ty_k, yh_k = rot[launch_no % len(rot)]; launch_no += 1
+            bank.filter(ty_k, T=a.T, x=x, yhat=yh_k, nll=nll, want_yhat="f" in a.mode, want_nll="n" in a.mode)
         times[v] += bank.profile_read()
         torch.cuda.synchronize()
         if "n" in a.mode:
             tot = nll.sum().item()
             if ref is None: ref = tot
             assert v == 9 or abs(tot - ref) <= 1e-5 * abs(ref), (v, tot, ref)
-print(f"dtype={a.dtype} L={a.L} T={a.T} mode={a.mode} nan={a.nan} cold={a.cold} bytes/launch={nbytes/1e6:.1f} MB")
+print(f"dtype={a.dtype} L={a.L} T={a.T} mode={a.mode} nan={a.nan} cold={a.cold} rotate={a.rotate} bytes/launch={nbytes/1e6:.1f} MB", flush=True)
 for v in variants:
     t = np.array(times[v]) * 1e3
     print(f"variant {v}: min {t.min():7.1f} us  median {np.median(t):7.1f} us  -> {nbytes/np.median(t)/1e6:6.2f} TB/s ({nbytes/np.median(t)/1e6/8*100:4.1f}% of 8 TB/s)")
