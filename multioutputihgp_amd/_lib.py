@@ -19,7 +19,7 @@ REFERENCE_SYMBOLS = [
 ADDITIVE_SYMBOLS = [
     "moihgp_last_error", "moihgp_device_count", "moihgp_version", "moihgp_new", "moihgp_del",
     "moihgp_num_output", "moihgp_num_latent", "moihgp_set_threading", "moihgp_get_threading", "moihgp_polar_iterations", "moihgp_reseed_U", "moihgp_new_latents",
-    "moihgp_update_latents", "moihgp_set_mixing", "moihgp_get_latent", "moihgp_filter_stream", "moihgp_filter_stream_io", "moihgp_filter_stream_v2", "moihgp_grad_stream",
+    "moihgp_update_latents", "moihgp_set_mixing", "moihgp_get_latent", "moihgp_filter_stream", "moihgp_filter_stream_io", "moihgp_filter_stream_v2", "moihgp_filter_stream_tiled", "moihgp_stream_retile", "moihgp_grad_stream",
     "moihgp_project_stream", "moihgp_unproject_stream", "moihgp_stream_sync",
     "moihgp_profile_enable", "moihgp_profile_stride", "moihgp_profile_read", "moihgp_window_set", "moihgp_window_eval", "moihgp_pin_host_buffer",
     "moihgp_update_dev", "moihgp_window_eval_dev", "moihgp_update_dev_on", "moihgp_window_eval_dev_on", "moihgp_get_params_dev", "moihgp_set_option", "moihgp_release_stream",
@@ -122,6 +122,10 @@ def load_library():
     lib.moihgp_update_dev.argtypes = [C.c_void_p, C.c_void_p]
     lib.moihgp_window_eval_dev.restype = C.c_int
     lib.moihgp_window_eval_dev.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+    lib.moihgp_filter_stream_tiled.restype = C.c_int
+    lib.moihgp_filter_stream_tiled.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.moihgp_stream_retile.restype = C.c_int
+    lib.moihgp_stream_retile.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p]
     lib.moihgp_update_dev_on.restype = C.c_int
     lib.moihgp_update_dev_on.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.moihgp_window_eval_dev_on.restype = C.c_int

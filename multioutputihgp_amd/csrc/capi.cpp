@@ -72,7 +72,7 @@ struct moihgp_gp {
     double* dpart = nullptr;                                   // [32][L] chunk partials of the per-tick projection
     double *dTy = nullptr, *dUty = nullptr, *dTyhat = nullptr, *dloss = nullptr, *dgrad = nullptr, *dscratch = nullptr;
     double* dwork = nullptr;   // L*L + L, lazily (missing-output projection)
-    double* dpolar = nullptr;  // M*L + 2*L*L + 8, lazily (device polar factor)
+    double* dpolar = nullptr;  // polar_work_doubles(M, L), lazily (device polar factor)
     int* dfallback = nullptr;  // [2 L + 1] flags of the latents the gradient sweep leaves to its later passes, their compact list, its length
     double* dlink = nullptr;   // [L][144] stacked filter: where the second (broken-link) pass resumes a latent (on first use)
     bool hp_valid = false;     // dhp matches the current tables (cleared by every IHGP::update)
@@ -438,7 +438,7 @@ static bool compute_polar(moihgp_gp* g, const double* Uparam, bool from_device) 
         launch_polar_small(g->dU, M, L, verdict, g->stream);
         g->polar_pending = true;
     } else {
-        if (!g->dpolar) g->dpolar = dev_alloc<double>(M * L + 2 * L * L + 8 + 3 * L);
+        if (!g->dpolar) g->dpolar = dev_alloc<double>(polar_work_doubles(M, L));
         its = polar_factor_device(g->dU, M, L, g->dpolar, g->stream);
     }
     g->polar_its = its > 0 ? its : 0;
@@ -768,6 +768,40 @@ static int filter_stream_io_impl(moihgp_gp* gp, int dtype, const void* Ty, size_
     }
     return launch_filter_stream(gp->d, dtype, Ty, T, ld, gp->L, gp->cb64, gp->cb32, x_in, x, yhat, nll, (hipStream_t)stream, variant, e0, e1,
                                 nsplit, Tslice, gp->n_unstable[dtype == MOIHGP_F64 ? 0 : 1], nll_total, nbig, ld_out);
+}
+
+// segment-major streams (include/moihgp.h: moihgp_filter_stream_tiled)
+static int filter_stream_tiled_impl(moihgp_gp* gp, int dtype, const void* Ty, size_t T, const void* x_in, void* x, void* yhat, double* nll, double* nll_total,
+                                    void* stream) {
+    if (!gp) { set_last_error("null handle"); return 1; }
+    if (dtype != MOIHGP_F64 && dtype != MOIHGP_F32) { set_last_error("dtype must be MOIHGP_F64 or MOIHGP_F32"); return 1; }
+    if (!x || !x_in || (T > 0 && !Ty)) { set_last_error("null stream/state pointer"); return 1; }
+    if (((uintptr_t)Ty & 15) != 0 || (yhat && ((uintptr_t)yhat & 15) != 0)) { set_last_error("stream base must be 16-byte aligned"); return 1; }
+    if (kernel_stack(gp->kernel)) { set_last_error("segment-major streams: the reference's own models only (d = 2, 3); stacked models take series-major streams"); return 3; }
+    if (nll_total && !nll) { set_last_error("nll_total needs the per-latent nll buffer"); return 1; }
+    note_user_stream(gp, (hipStream_t)stream);
+    if (nll_total && T == 0) MOIHGP_HIP_FATAL(hipMemsetAsync(nll_total, 0, sizeof(double), (hipStream_t)stream));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (!gp->prof_ev.empty() && 2 * (size_t)(gp->prof_n + 1) <= gp->prof_ev.size() && (gp->prof_seen++ % gp->prof_stride) == 0) {
+        e0 = gp->prof_ev[2 * gp->prof_n];
+        e1 = gp->prof_ev[2 * gp->prof_n + 1];
+        gp->prof_n++;
+    }
+    return launch_filter_stream_tiled(gp->d, dtype, Ty, T, gp->L, gp->cb64, gp->cb32, x_in, x, yhat, nll, (hipStream_t)stream, e0, e1,
+                                      gp->n_unstable[dtype == MOIHGP_F64 ? 0 : 1], nll_total);
+}
+
+int moihgp_filter_stream_tiled(moihgp_gp* gp, int dtype, const void* Ty, size_t T, const void* x_in, void* x, void* yhat, double* nll, double* nll_total,
+                               void* stream) {
+    return guard_rc([&] { return filter_stream_tiled_impl(gp, dtype, Ty, T, x_in, x, yhat, nll, nll_total, stream); });
+}
+
+int moihgp_stream_retile(int dtype, const void* src, void* dst, size_t L, size_t T, size_t ld, int to_tiled, void* stream) {
+    return guard_rc([&] {
+        if (dtype != MOIHGP_F64 && dtype != MOIHGP_F32) { set_last_error("dtype must be MOIHGP_F64 or MOIHGP_F32"); return 1; }
+        if (!src || !dst) { set_last_error("null stream pointer"); return 1; }
+        return launch_stream_retile(dtype, src, dst, L, T, ld, to_tiled, (hipStream_t)stream);
+    });
 }
 
 int moihgp_filter_stream_io(moihgp_gp* gp, int dtype, const void* Ty, size_t T, size_t ld, const void* x_in, void* x, void* yhat, double* nll,

@@ -161,6 +161,11 @@ int launch_gp_table_x(int kernel, const double* cb64, const double* cbd64, doubl
 int launch_grad_scan_x(int kernel, int dtype, const void* Ty, size_t Tpar, size_t ld, size_t L, const double* cb64, const double* cbd64,
                        void* x, void* dx, void* yhat, double* nll, double* grad, int* flags, double* hp, hipStream_t stream, int out_mode, int hp_build = 1);
 
+// recursion.hip: the same sweep over segment-major streams [ceil(T / SEG)][L][SEG], SEG = 4096 / sizeof(scalar) ticks (d = 2, 3)
+int launch_filter_stream_tiled(int d, int dtype, const void* Ty, size_t T, size_t L, const double* cb64, const float* cb32, const void* xin, void* x,
+                               void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, int n_unstable, double* total);
+// series-major [L][ld] <-> segment-major [ceil(T / SEG)][L][SEG] (to_tiled != 0: src is series-major; ticks past T are written as zeros)
+int launch_stream_retile(int dtype, const void* src, void* dst, size_t L, size_t T, size_t ld, int to_tiled, hipStream_t stream);
 // recursion.hip: batched sweeps over series-major streams.
 int launch_filter_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, size_t L,
                          const double* cb64, const float* cb32, const void* xin /* start state */, void* x /* end state, may alias xin */,
@@ -238,9 +243,14 @@ int launch_gram(const double* X, size_t M, size_t L, double* G, hipStream_t s); 
 int launch_matmul_nn(const double* X, size_t M, size_t L, const double* W, double* C, hipStream_t s);   // C = X W
 
 // polar.hip: polar factor of an M x L matrix on the device (Newton-Schulz), moihgp.h:433-447.
-// A_dev is overwritten with the factor; work needs M*L + 2*L*L + 8 + 3*L doubles.  Returns the iteration count, or
+// A_dev is overwritten with the factor; work needs polar_work_doubles(M, L) doubles.  Returns the iteration count, or
 // -1 if it did not converge (rank-deficient input).
 int polar_factor_device(double* A_dev, size_t M, size_t L, double* work, hipStream_t s);
+size_t polar_work_doubles(size_t M, size_t L);
+// polar_deflate.hip: exact deflation of up to 32 outlying singular values ahead of the iteration (X: M x L, G = X^T X, frob2 = ||G - I||_F^2);
+// *n_pairs > 0: X was updated in place (polar factor unchanged) and G is stale.  Returns 0 or an error code.
+size_t polar_deflate_work_doubles(size_t M, size_t L);
+int polar_deflate(double* X, size_t M, size_t L, const double* G, double frob2, double* work, hipStream_t s, int* n_pairs, int trace);
 // small matrices: the same iteration as one workgroup in LDS (one launch); status_dev: steps taken or -1
 bool polar_small_fits(size_t M, size_t L);
 void launch_polar_small(double* A_dev, size_t M, size_t L, int* status_dev, hipStream_t s);

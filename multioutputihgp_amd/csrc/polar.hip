@@ -13,39 +13,40 @@
 namespace moihgp {
 namespace {
 
-// per row i of G (one wave per row, coalesced): rows[3i..] = { sum_j |G_ij|, G_ii, max_j |G_ij - delta_ij| }
+// per row i of G (one wave per row, coalesced): rows[4i..] = { sum_j |G_ij|, G_ii, max_j |G_ij - delta_ij|, sum_j (G_ij - delta_ij)^2 }
 __global__ void __launch_bounds__(256) gram_row_stats_kernel(const double* __restrict__ G, size_t L, double* __restrict__ rows) {
     const int lane = threadIdx.x & 63;
     const size_t i = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (i >= L) return;
-    double s = 0.0, dev = 0.0;
+    double s = 0.0, dev = 0.0, sq = 0.0;
     for (size_t j = lane; j < L; j += 64) {
-        const double g = G[i * L + j];
+        const double g = G[i * L + j], e = g - (i == j ? 1.0 : 0.0);
         s += fabs(g);
-        dev = fmax(dev, fabs(g - (i == j ? 1.0 : 0.0)));
+        dev = fmax(dev, fabs(e));
+        sq = fma(e, e, sq);
     }
-    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); dev = fmax(dev, __shfl_xor(dev, o)); }
-    if (lane == 0) { rows[3 * i] = s; rows[3 * i + 1] = G[i * L + i]; rows[3 * i + 2] = dev; }
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); dev = fmax(dev, __shfl_xor(dev, o)); sq += __shfl_xor(sq, o); }
+    if (lane == 0) { rows[4 * i] = s; rows[4 * i + 1] = G[i * L + i]; rows[4 * i + 2] = dev; rows[4 * i + 3] = sq; }
 }
 
-// out[0] = max_i sum_j |G_ij| ; out[1] = trace(G) ; out[2] = max_ij |G_ij - delta_ij| ; out[5] = ||G - I||_inf = max_i sum_j |G_ij - delta_ij|
-// (one workgroup over the row records)
+// out[0] = max_i sum_j |G_ij| ; out[1] = trace(G) ; out[2] = max_ij |G_ij - delta_ij| ; out[5] = ||G - I||_inf = max_i sum_j |G_ij - delta_ij| ;
+// out[6] = ||G - I||_F^2     (one workgroup over the row records)
 __global__ void __launch_bounds__(256) gram_stats_kernel(const double* __restrict__ rows, size_t L, double* __restrict__ out) {
-    __shared__ double r0[256], r1[256], r2[256], r3[256];
+    __shared__ double r0[256], r1[256], r2[256], r3[256], r4[256];
     const int tid = threadIdx.x;
-    double mx = 0.0, tr = 0.0, dev = 0.0, einf = 0.0;
+    double mx = 0.0, tr = 0.0, dev = 0.0, einf = 0.0, fro = 0.0;
     for (size_t i = tid; i < L; i += 256) {
-        const double s = rows[3 * i], g = rows[3 * i + 1];
-        mx = fmax(mx, s); tr += g; dev = fmax(dev, rows[3 * i + 2]);
+        const double s = rows[4 * i], g = rows[4 * i + 1];
+        mx = fmax(mx, s); tr += g; dev = fmax(dev, rows[4 * i + 2]); fro += rows[4 * i + 3];
         einf = fmax(einf, s - fabs(g) + fabs(g - 1.0));               // row sum of |G - I|
     }
-    r0[tid] = mx; r1[tid] = tr; r2[tid] = dev; r3[tid] = einf;
+    r0[tid] = mx; r1[tid] = tr; r2[tid] = dev; r3[tid] = einf; r4[tid] = fro;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) { r0[tid] = fmax(r0[tid], r0[tid + o]); r1[tid] += r1[tid + o]; r2[tid] = fmax(r2[tid], r2[tid + o]); r3[tid] = fmax(r3[tid], r3[tid + o]); }
+        if (tid < o) { r0[tid] = fmax(r0[tid], r0[tid + o]); r1[tid] += r1[tid + o]; r2[tid] = fmax(r2[tid], r2[tid + o]); r3[tid] = fmax(r3[tid], r3[tid + o]); r4[tid] += r4[tid + o]; }
         __syncthreads();
     }
-    if (tid == 0) { out[0] = r0[0]; out[1] = r1[0]; out[2] = r2[0]; out[5] = r3[0]; }
+    if (tid == 0) { out[0] = r0[0]; out[1] = r1[0]; out[2] = r2[0]; out[5] = r3[0]; out[6] = r4[0]; }
 }
 
 // y = G v (one wave per row), used by the power iteration for lambda_max(G)
@@ -214,25 +215,44 @@ static void polar_dump_gram(const double* G, size_t L, hipStream_t s) {
     if (FILE* f = std::fopen(path, "wb")) { std::fwrite(h.data(), sizeof(double), L * L, f); std::fclose(f); }
 }
 
+size_t polar_work_doubles(size_t M, size_t L) { return M * L + 2 * L * L + 8 + 4 * L + polar_deflate_work_doubles(M, L); }
+
 int polar_factor_device(double* X, size_t M, size_t L, double* work, hipStream_t s) {
     double* G = work;                 // L*L
     double* W = G + L * L;            // L*L
     double* Xn = W + L * L;           // M*L
     double* stats = Xn + M * L;       // 8
-    double* rows = stats + 8;         // 3*L  (also the two power-iteration vectors)
-    double h[6];
+    double* rows = stats + 8;         // 4*L  (also the two power-iteration vectors)
+    double* dwork = rows + 4 * L;     // polar_deflate_work_doubles(M, L)
+    double h[8];
     const unsigned nbLL = (unsigned)((L * L + 255) / 256), nbML = (unsigned)((M * L + 255) / 256), nbRow = (unsigned)((L + 3) / 4);
-    if (launch_gram(X, M, L, G, s)) return -1;
-    // ---- scale: s^2 ~ lambda_max(G) = sigma_max(A)^2.  Newton-Schulz converges for sigma/s in (0, sqrt 3), so the
-    // estimate only has to be right within a factor 3 in lambda; it is cross-checked against the rigorous bounds
-    // ||G||_inf and trace(G) and the iteration falls back to them should the error ever grow.
-    hipLaunchKernelGGL(gram_row_stats_kernel, dim3(nbRow), dim3(256), 0, s, G, L, rows);
-    hipLaunchKernelGGL(gram_stats_kernel, dim3(1), dim3(256), 0, s, rows, L, stats);
-    MOIHGP_HIP_FATAL(hipMemcpyAsync(h, stats, sizeof(double) * 4, hipMemcpyDeviceToHost, s));
-    MOIHGP_HIP_FATAL(hipStreamSynchronize(s));
-    const double bound = fmin(h[0], h[1]);
+    static const bool deflate_on = [] { const char* e = std::getenv("MOIHGP_POLAR_DEFLATE"); return !(e && e[0] == '0'); }();
+    auto gram_and_stats = [&]() -> int {
+        if (launch_gram(X, M, L, G, s)) return -1;
+        hipLaunchKernelGGL(gram_row_stats_kernel, dim3(nbRow), dim3(256), 0, s, G, L, rows);
+        hipLaunchKernelGGL(gram_stats_kernel, dim3(1), dim3(256), 0, s, rows, L, stats);
+        MOIHGP_HIP_FATAL(hipMemcpyAsync(h, stats, sizeof(double) * 7, hipMemcpyDeviceToHost, s));
+        MOIHGP_HIP_FATAL(hipStreamSynchronize(s));
+        return 0;
+    };
+    if (gram_and_stats()) return -1;
+    double bound = fmin(h[0], h[1]);
     if (!(bound > 0.0) || h[0] != h[0]) return -1;
     polar_dump_gram(G, L, s);
+    // ---- a few outlying singular values (the online learner's iterate: polar_deflate.hip) are taken out exactly before anything else:
+    // worth an attempt whenever the input is not orthonormal to 1e-3 already (two tall-skinny passes over G decide whether it pays)
+    if (deflate_on && h[2] > 1e-3) {
+        int pairs = 0;
+        if (polar_deflate(X, M, L, G, h[6], dwork, s, &pairs, polar_trace_level()) != 0) return -1;
+        if (pairs > 0) {
+            if (gram_and_stats()) return -1;
+            bound = fmin(h[0], h[1]);
+            if (!(bound > 0.0) || h[0] != h[0]) return -1;
+        }
+    }
+    // ---- scale: Newton-Schulz converges for sigma / s in (0, sqrt 3).  s^2 comes from an estimate of lambda_max(G) (power iteration: a
+    // Rayleigh value, i.e. a LOWER bound that can be far too low when the start vector misses the dominant direction) held against the
+    // rigorous upper bound min(||G||_inf, trace G): s^2 >= bound / 2.9 whatever the estimate says, so sigma^2 / s^2 <= 2.9 < 3 always.
     if (bound > 2.0) {                    // (an input this close to orthonormal is not scaled at all, below: no estimate needed)
         double* v = rows;
         double* y = rows + L;
@@ -244,12 +264,10 @@ int polar_factor_device(double* X, size_t M, size_t L, double* work, hipStream_t
         MOIHGP_HIP_FATAL(hipMemcpyAsync(h, stats, sizeof(double) * 4, hipMemcpyDeviceToHost, s));
         MOIHGP_HIP_FATAL(hipStreamSynchronize(s));
     }
-    // sigma_max / s = 1.2 (round 3; 0.976 before): a singular value somewhat ABOVE 1 comes back below it in one step (1.2 -> 0.94) while the
-    // bulk starts 23 % closer to 1 -- one step fewer on every wide spectrum simulated (bulk at 1 with outliers to 3: 8 -> 7 steps; uniform
-    // 0.5..1.5: 8 -> 7; Marchenko-Pastur: 11 -> 10), never one more.  The estimate comes from inside the spectrum: the iteration stays in its
-    // basin (sigma / s < sqrt 3) as long as it is within 2.08 x of lambda_max (2.86 x before; 16 power steps instead of 12).
-    double s2 = h[3] / 1.44;
-    if (h[3] >= 0.8 && h[3] <= 1.44) s2 = 1.0;     // already there: scaling would only move the bulk (the rigorous bound above can exceed 2 by its slack alone)
+    // sigma_max / s = 1.2 when the estimate is exact (a singular value somewhat ABOVE 1 comes back below it in one step, 1.2 -> 0.94, while
+    // the bulk starts 23 % closer to 1: one step fewer on every wide spectrum simulated, never one more)
+    double s2 = fmax(h[3] / 1.44, bound / 2.9);
+    if (h[3] >= 0.8 && h[3] <= 1.44 && bound <= 2.9) s2 = 1.0;     // already there: scaling would only move the bulk
     if (!(s2 > 0.0) || s2 > bound) s2 = bound;
     bool used_bound = (s2 == bound);
     // An input that is orthonormal already to within the reach of the iteration -- the learner's case: the previous polar factor plus

@@ -739,13 +739,16 @@ __global__ void __launch_bounds__(1024) nll_total_kernel(const double* __restric
 // Exact sequential filter for the latents flagged unstable (SCANOK == 0): one lane per latent, tick by tick in innovation
 // form (identical in meaning to ihgp.h:81-93 / :204-209, missing ticks included), stream fetched in 16-byte vectors.
 // Launched only when IHGP::update reported such latents; every other lane exits at once.
-template <typename T, int D>
+template <typename T, int D, bool TILED = false>
 __global__ void __launch_bounds__(64)
 filter_seq_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, const T* __restrict__ cbT, const double* __restrict__ cb64,
                   const T* xin0, T* x, T* __restrict__ yhat, double* __restrict__ nll, size_t ldo) {
     using V = typename VecOf<T>::type;
     using Lay = CB<D>;
     constexpr int EPV = 16 / sizeof(T);
+    constexpr size_t SEGT = 4096 / sizeof(T);                    // ticks per tile of the segment-major layout
+    // element t of latent l: series-major l ld + t; segment-major ((t / SEGT) L + l) SEGT + t % SEGT
+    auto at = [&](size_t l_, size_t t_, size_t ld_) { return TILED ? ((t_ / SEGT) * L + l_) * SEGT + t_ % SEGT : l_ * ld_ + t_; };
     const size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= L) return;
     const T* cb = cbT + l * Lay::SIZE;
@@ -754,10 +757,9 @@ filter_seq_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, co
     for (int i = 0; i < D * D; i++) a[i] = cb[Lay::A + i];
     for (int i = 0; i < D; i++) { kk[i] = cb[Lay::K + i]; xs[i] = xin0[l * D + i]; }
     double acc = 0.0, n = 0.0;
-    const T* row = Ty + l * ld;
     for (size_t tb = 0; tb < Tlen; tb += EPV) {
         T yv[EPV];
-        unpack<T>(*reinterpret_cast<const V*>(row + tb), yv);
+        unpack<T>(*reinterpret_cast<const V*>(Ty + at(l, tb, ld)), yv);
         for (int e = 0; e < EPV && tb + e < Tlen; e++) {
             const T yk = yv[e];
             const bool miss = (yk != yk);
@@ -773,7 +775,7 @@ filter_seq_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, co
                 xn[i] = s;
             }
             for (int i = 0; i < D; i++) xs[i] = xn[i];
-            if (yhat) yhat[l * ldo + tb + e] = xs[0];
+            if (yhat) yhat[at(l, tb + e, ldo)] = xs[0];
         }
     }
     for (int i = 0; i < D; i++) x[l * D + i] = xs[i];
@@ -805,7 +807,7 @@ filter_seq_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, co
 #define MOIHGP_FILTER_DMA 1
 #endif
 constexpr int kDmaRing32 = 8, kDmaWaves32 = 4;     // fp32: 8 KB ring, 4 waves per SIMD (16 x 8.2 KB = 131 KB of the 160 KB per CU)
-constexpr int kDmaRing64 = 8, kDmaWaves64 = 2;     // fp64
+constexpr int kDmaRing64 = 8, kDmaWaves64 = 3;     // fp64: 132 VGPRs, 3 waves per SIMD (12 x 8.3 KB)
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_cvoid_t;
 __device__ inline unsigned lds_addr_of(const void* p) { return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char*)p; }
@@ -941,7 +943,12 @@ __device__ inline bool dma_segment(T* y, T* xin, const DmaConst<T, D, CK>& c, in
     return true;
 }
 
-template <typename T, int D, int CK, bool WRITE, bool NLL, int NP, int MINW>
+// TILED: the streams are laid out SEGMENT-MAJOR, [ceil(T / SEG)][L][SEG] with SEG = 4 KB of ticks (1024 fp32 / 512 fp64) -- segment s of every
+// latent side by side -- instead of series-major [L][ld].  The wavefronts of a launch move through the segments roughly together, so with this
+// layout the chip reads and writes ONE contiguous front, like a plain copy, instead of 4096 row streams 40 KB apart: measured with a copy
+// kernel of the sweep's access pattern (tools/micro/rows_copy.hip, profiles/r04/rows_copy_access_pattern.log) a cold stream moves at
+// 5.7-6.05 TB/s segment-major against 5.0-5.25 TB/s series-major.  `ld` / `ldo` are ignored; the last tile is allocated whole.
+template <typename T, int D, int CK, bool WRITE, bool NLL, int NP, int MINW, bool TILED = false>
 __global__ void __launch_bounds__(64 * kWavesPerBlock, MINW)
 filter_dma_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, const T* __restrict__ cbT, const double* __restrict__ cb64,
                   const T* xin0, T* x, T* __restrict__ yhat, double* __restrict__ nll, size_t ldo) {
@@ -982,12 +989,18 @@ filter_dma_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, co
     const unsigned sw = (jj ^ (jj >> 2)) & 3;
     // byte offset of this lane's vector inside a piece, as fetched / stored (the swizzle lives on the global side)
     const unsigned goff = (unsigned)(((lane & ~3) | ((lane & 3) ^ (((lane >> 2) ^ (lane >> 4)) & 3))) * 16);
-    const unsigned char* rowb = reinterpret_cast<const unsigned char*>(Ty + l * ld);
+    // series-major: this latent's row; segment-major: this latent's tile of segment 0, the tiles of later segments L * 4 KB apart
+    const unsigned char* rowb = TILED ? reinterpret_cast<const unsigned char*>(Ty) + l * 4096 : reinterpret_cast<const unsigned char*>(Ty + l * ld);
+    const size_t seg_stride = TILED ? L * 4096 : 4096;           // bytes from one segment of this latent to the next
     // last vector of the row that starts inside the stream (ld >= roundup(T, EPV): it is in bounds); pieces past the end re-read it
     const size_t lastv = ((Tlen - 1) / EPV) * 16;
     auto issue_piece = [&](size_t p, unsigned slot, bool inside) {
         lds_void_t* dst = (lds_void_t*)(ring + (size_t)slot * 1024);
-        if (inside) {
+        if (TILED) {
+            // (the last tile is allocated whole: no clamping inside the stream's segments; pieces past the last segment re-read its last piece)
+            const size_t pp = p < 4 * nseg ? p : 4 * nseg - 1;
+            __builtin_amdgcn_global_load_lds((glb_cvoid_t*)(rowb + (pp >> 2) * seg_stride + (pp & 3) * 1024 + goff), dst, 16, 0, 0);
+        } else if (inside) {
             __builtin_amdgcn_global_load_lds((glb_cvoid_t*)(rowb + p * 1024 + goff), dst, 16, 0, 0);
         } else {
             size_t o = p * 1024 + goff;
@@ -1024,7 +1037,7 @@ filter_dma_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, co
     double acc = 0.0;
     unsigned nobs = 0;
     size_t nobs_uniform = 0;
-    unsigned char* orowb = WRITE ? reinterpret_cast<unsigned char*>(yhat + l * ldo) : nullptr;
+    unsigned char* orowb = WRITE ? (TILED ? reinterpret_cast<unsigned char*>(yhat) + l * 4096 : reinterpret_cast<unsigned char*>(yhat + l * ldo)) : nullptr;
 
     unsigned slot0 = 0;
     for (size_t seg = 0; seg < nseg; seg++) {
@@ -1097,8 +1110,8 @@ filter_dma_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, co
             AV o[4];
             const unsigned la = ring_addr + (unsigned)lane * 16;
             lds_read4<AV>(la + slot0 * 1024, la + s1 * 1024, la + s2 * 1024, la + s3 * 1024, o);
-            unsigned char* po = orowb + tbase * sizeof(T) + goff;
-            if (tbase + SEG <= Tlen) {
+            unsigned char* po = orowb + seg * seg_stride + goff;
+            if (TILED || tbase + SEG <= Tlen) {                  // (a tile is stored whole: its padding belongs to the stream)
 #pragma unroll
                 for (int i = 0; i < 4; i++) __builtin_nontemporal_store(o[i], reinterpret_cast<AV*>(po + i * 1024));
             } else {
@@ -1136,7 +1149,7 @@ filter_dma_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, co
     }
 }
 
-template <typename T, int D, int CK, int NP, int MINW>
+template <typename T, int D, int CK, int NP, int MINW, bool TILED = false>
 int launch_filter_dma_t(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, const double* cb64, const void* xin, void* x,
                         void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, int n_unstable, double* total, size_t ldo) {
     constexpr int SPL = ((D * D * (int)sizeof(T)) + 15) / 16 * 16;
@@ -1148,7 +1161,7 @@ int launch_filter_dma_t(const void* Ty, size_t Tlen, size_t ld, size_t L, const 
     T* yh = static_cast<T*>(yhat);
 #define MOIHGP_DMA_LAUNCH(W_, N_)                                                                                                     \
     do {                                                                                                                              \
-        auto kfn = filter_dma_kernel<T, D, CK, W_, N_, NP, MINW>;                                                                     \
+        auto kfn = filter_dma_kernel<T, D, CK, W_, N_, NP, MINW, TILED>;                                                              \
         if (smem > 65536) {                                                                                                           \
             static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
             if (attr != hipSuccess) { set_last_error("filter_dma_kernel: %zu bytes of LDS refused: %s", smem, hipGetErrorString(attr)); return 2; } \
@@ -1161,7 +1174,7 @@ int launch_filter_dma_t(const void* Ty, size_t Tlen, size_t ld, size_t L, const 
     else MOIHGP_DMA_LAUNCH(false, false);
 #undef MOIHGP_DMA_LAUNCH
     if (n_unstable > 0)
-        hipLaunchKernelGGL((filter_seq_kernel<T, D>), dim3((unsigned)((L + 63) / 64)), dim3(64), 0, stream, ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, ldo);
+        hipLaunchKernelGGL((filter_seq_kernel<T, D, TILED>), dim3((unsigned)((L + 63) / 64)), dim3(64), 0, stream, ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, ldo);
     if (total && nll) hipLaunchKernelGGL(nll_total_kernel, dim3(1), dim3(1024), 0, stream, nll, L, total);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_last_error("filter_dma_kernel launch: %s", hipGetErrorString(e)); return 2; }
@@ -1231,6 +1244,41 @@ void filter_split_plan(int dtype, size_t T, size_t L, int* nsplit, size_t* Tslic
     const size_t big = segs - want * (per - 1);              // slices that hold `per` segments; 1 <= big <= want
     if (per == 1 && big < want) { *nsplit = (int)big; *Tslice = seg; *nbig = (int)big; return; }
     *nsplit = (int)want; *Tslice = per * seg; *nbig = (int)big;
+}
+
+// series-major <-> segment-major copies (callers that hold one layout and want the other; the projection GEMM writes either directly)
+template <typename T>
+__global__ void __launch_bounds__(256) retile_kernel(const T* __restrict__ src, T* __restrict__ dst, size_t L, size_t Tlen, size_t ld, int to_tiled) {
+    constexpr size_t SEGT = 4096 / sizeof(T);
+    const size_t nseg = (Tlen + SEGT - 1) / SEGT;
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;           // element of the tiled array
+    if (e >= nseg * L * SEGT) return;
+    const size_t sgi = e / (L * SEGT), l = (e / SEGT) % L, t = sgi * SEGT + e % SEGT;
+    if (to_tiled) dst[e] = t < Tlen ? src[l * ld + t] : T(0);
+    else if (t < Tlen) dst[l * ld + t] = src[e];
+}
+int launch_stream_retile(int dtype, const void* src, void* dst, size_t L, size_t T, size_t ld, int to_tiled, hipStream_t stream) {
+    if (L == 0 || T == 0) return 0;
+    const size_t segt = dtype == 0 ? 512 : 1024, n = (T + segt - 1) / segt * L * segt;
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    if (dtype == 0) hipLaunchKernelGGL(retile_kernel<double>, dim3(grid), dim3(256), 0, stream, (const double*)src, (double*)dst, L, T, ld, to_tiled);
+    else hipLaunchKernelGGL(retile_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)src, (float*)dst, L, T, ld, to_tiled);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_last_error("retile_kernel launch: %s", hipGetErrorString(e)); return 2; }
+    return 0;
+}
+
+// The sweep over SEGMENT-MAJOR streams ([ceil(T / SEG)][L][SEG], SEG = 4096 / sizeof(scalar) ticks; filter_dma_kernel TILED): the reference's
+// own models (d = 2, 3), any number of latents (one wavefront per latent: meant for the many-latent shapes).
+int launch_filter_stream_tiled(int d, int dtype, const void* Ty, size_t T, size_t L, const double* cb64, const float* cb32, const void* xin, void* x,
+                               void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, int n_unstable, double* total) {
+    if (L == 0) return 0;
+    if (dtype == 0) {
+        if (d == 2) return launch_filter_dma_t<double, 2, kChunk64, kDmaRing64, kDmaWaves64, true>(Ty, T, 0, L, cb64, cb64, xin, x, yhat, nll, stream, ev0, ev1, n_unstable, total, 0);
+        return launch_filter_dma_t<double, 3, kChunk64, kDmaRing64, kDmaWaves64, true>(Ty, T, 0, L, cb64, cb64, xin, x, yhat, nll, stream, ev0, ev1, n_unstable, total, 0);
+    }
+    if (d == 2) return launch_filter_dma_t<float, 2, kChunk32, kDmaRing32, kDmaWaves32, true>(Ty, T, 0, L, cb32, cb64, xin, x, yhat, nll, stream, ev0, ev1, n_unstable, total, 0);
+    return launch_filter_dma_t<float, 3, kChunk32, kDmaRing32, kDmaWaves32, true>(Ty, T, 0, L, cb32, cb64, xin, x, yhat, nll, stream, ev0, ev1, n_unstable, total, 0);
 }
 
 int launch_filter_stream(int d, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* cb64,

@@ -49,6 +49,38 @@ def alloc_stream(L: int, T: int, dtype=torch.float32, device="cuda") -> torch.Te
     return torch.empty((L, padded_len(T, dtype)), dtype=dtype, device=device)
 
 
+def seg_ticks(dtype) -> int:
+    """Ticks per tile of the segment-major layout: 4 KB of stream (include/moihgp.h moihgp_filter_stream_tiled)."""
+    return 512 if dtype == torch.float64 else 1024
+
+
+def alloc_stream_tiled(L: int, T: int, dtype=torch.float32, device="cuda") -> torch.Tensor:
+    """Segment-major stream [ceil(T / SEG), L, SEG]: tile (s, l) holds ticks [s SEG, (s + 1) SEG) of latent l; the last tile is whole."""
+    seg = seg_ticks(dtype)
+    return torch.empty(((T + seg - 1) // seg, L, seg), dtype=dtype, device=device)
+
+
+def tile_stream(Ty: torch.Tensor, T: Optional[int] = None, out: Optional[torch.Tensor] = None, stream=None) -> torch.Tensor:
+    """Series-major [L, ld] -> segment-major [ceil(T / SEG), L, SEG] (ticks past T become zeros), by the library's copy kernel."""
+    lib = load_library()
+    L, ld = Ty.shape
+    T = ld if T is None else int(T)
+    if out is None:
+        out = alloc_stream_tiled(L, T, Ty.dtype, Ty.device)
+    _check(lib.moihgp_stream_retile(_DT[Ty.dtype], C.c_void_p(Ty.data_ptr()), C.c_void_p(out.data_ptr()), L, T, Ty.stride(0), 1, _stream_ptr(stream)), lib)
+    return out
+
+
+def untile_stream(Tt: torch.Tensor, T: int, out: Optional[torch.Tensor] = None, stream=None) -> torch.Tensor:
+    """Segment-major [nseg, L, SEG] -> series-major [L, ld] (the first T ticks of every latent)."""
+    lib = load_library()
+    L = Tt.shape[1]
+    if out is None:
+        out = alloc_stream(L, T, Tt.dtype, Tt.device)
+    _check(lib.moihgp_stream_retile(_DT[Tt.dtype], C.c_void_p(Tt.data_ptr()), C.c_void_p(out.data_ptr()), L, T, out.stride(0), 0, _stream_ptr(stream)), lib)
+    return out
+
+
 class LatentBank:
     """A shard of independent latent IHGPs (reference include/moihgp/ihgp.h `IHGP<SS>` x L) on one GPU.
 
@@ -175,6 +207,36 @@ class LatentBank:
             C.c_void_p(x.data_ptr()),
             C.c_void_p(yhat.data_ptr()) if want_yhat else None, ((yhat.stride(0) if self.L > 1 else padded_len(T, Ty.dtype)) if want_yhat else 0),
             C.c_void_p(nll.data_ptr()) if want_nll else None,
+            C.c_void_p(nll_total.data_ptr()) if (nll_total is not None and want_nll) else None, _stream_ptr(stream))
+        _check(rc, self._lib)
+        return (yhat if want_yhat else None), x, (nll if want_nll else None)
+
+    def filter_tiled(self, Tt: torch.Tensor, T: int, x: Optional[torch.Tensor] = None, want_yhat: bool = True, want_nll: bool = True,
+                     yhat: Optional[torch.Tensor] = None, nll: Optional[torch.Tensor] = None, stream=None, x_start: Optional[torch.Tensor] = None,
+                     nll_total: Optional[torch.Tensor] = None):
+        """`filter` over a SEGMENT-MAJOR stream [ceil(T / SEG), L, SEG] (alloc_stream_tiled / tile_stream): same arithmetic, same results bit for
+        bit; the chip reads and writes one contiguous front instead of L row streams (moihgp_filter_stream_tiled).  yhat comes back in the
+        same layout.  The reference's own models only (d = 2, 3)."""
+        seg = seg_ticks(Tt.dtype)
+        nseg = (int(T) + seg - 1) // seg
+        if not Tt.is_cuda or Tt.dtype not in _DT or not Tt.is_contiguous() or tuple(Tt.shape) != (nseg, self.L, seg):
+            raise ValueError(f"Tt must be a contiguous CUDA tensor [ceil(T / {seg}) = {nseg}, L = {self.L}, {seg}]")
+        if x is None:
+            x = torch.zeros((self.L, self.d), dtype=Tt.dtype, device=Tt.device)
+        if x.dtype != Tt.dtype or not x.is_contiguous() or tuple(x.shape) != (self.L, self.d):
+            raise ValueError("x must be a contiguous [L, d] tensor of the stream dtype")
+        if x_start is not None and (x_start.dtype != Tt.dtype or not x_start.is_contiguous() or tuple(x_start.shape) != (self.L, self.d)):
+            raise ValueError("x_start must be a contiguous [L, d] tensor of the stream dtype")
+        if want_yhat:
+            if yhat is None:
+                yhat = torch.empty_like(Tt)
+            elif not yhat.is_cuda or yhat.dtype != Tt.dtype or not yhat.is_contiguous() or tuple(yhat.shape) != tuple(Tt.shape):
+                raise ValueError("yhat must be a contiguous CUDA tensor shaped like the stream")
+        if want_nll and nll is None:
+            nll = torch.empty((self.L,), dtype=torch.float64, device=Tt.device)
+        rc = self._lib.moihgp_filter_stream_tiled(
+            self._h, _DT[Tt.dtype], C.c_void_p(Tt.data_ptr()), int(T), C.c_void_p((x if x_start is None else x_start).data_ptr()), C.c_void_p(x.data_ptr()),
+            C.c_void_p(yhat.data_ptr()) if want_yhat else None, C.c_void_p(nll.data_ptr()) if want_nll else None,
             C.c_void_p(nll_total.data_ptr()) if (nll_total is not None and want_nll) else None, _stream_ptr(stream))
         _check(rc, self._lib)
         return (yhat if want_yhat else None), x, (nll if want_nll else None)

@@ -435,6 +435,49 @@ def test_polar_factor_device_vs_svd(env, M, L, noise, monkeypatch):
         assert np.max(np.abs(U.T @ U - np.eye(L))) < 1e-12
 
 
+@pytest.mark.parametrize("M,L", [(300, 300), (700, 260), (1024, 512)])
+@pytest.mark.parametrize("shape", ["learner", "learner_many", "one_small", "dominant_orthogonal_to_ones", "wide"])
+def test_polar_factor_spectra_with_outliers(env, M, L, shape, monkeypatch):
+    """The polar factor (moihgp.h:433-447) for spectra that the plain Newton-Schulz iteration handles badly or wrongly:
+      learner / learner_many: an orthonormal matrix whose singular values have drifted in a few (8 / 60) directions, one of them far
+        (sigma_1 = 4.7): what the online learner hands to update() after some ticks (profiles/r04/learner_spectrum.log).  The outliers are
+        deflated exactly (csrc/polar_deflate.hip) and the iteration finishes in <= 3 steps (nine without);
+      one_small: an outlier BELOW 1 (sigma = 0.05);
+      dominant_orthogonal_to_ones: sigma_1 = 3 along a right singular vector orthogonal to the all-ones vector, from which the power
+        iteration for lambda_max starts: the scale must still put every singular value inside (0, sqrt 3) (ADVICE r3);
+      wide: singular values uniform in [0.5, 1.5]: nothing to deflate, the attempt is abandoned.
+    Against LAPACK's svdU svdV^T, with MOIHGP_POLAR=gemm forcing the multi-kernel path for every size."""
+    monkeypatch.setenv("MOIHGP_POLAR", "gemm")
+    rng = np.random.default_rng(M * 7 + L + len(shape))
+    Q1, _ = np.linalg.qr(rng.standard_normal((M, L))); Q2, _ = np.linalg.qr(rng.standard_normal((L, L)))
+    sig = np.ones(L) + 3e-11 * rng.standard_normal(L)
+    if shape == "learner":
+        sig[:9] = [4.684, 1.2004, 1.081, 1.0364, 1.0213, 1.0125, 1.0075, 1.0036, 0.99947]
+    elif shape == "learner_many":
+        sig[:60] = np.concatenate([[4.684, 2.2], 1.0 + np.logspace(-0.5, -7, 58)])
+    elif shape == "one_small":
+        sig[0] = 0.05
+    elif shape == "dominant_orthogonal_to_ones":
+        v = np.zeros(L); v[0], v[1] = 1 / np.sqrt(2), -1 / np.sqrt(2)            # orthogonal to the all-ones start vector
+        Q2, _ = np.linalg.qr(np.column_stack([v, rng.standard_normal((L, L - 1))]))
+        sig = np.ones(L); sig[0] = 3.0
+    else:
+        sig = rng.uniform(0.5, 1.5, L)
+    A = (Q1 * sig) @ Q2.T
+    gp = env["MOIHGP"](0.1, M, L, kernel="Matern32")
+    params = np.concatenate([A.ravel(), rng.uniform(0.5, 2, L), [0.03], synth_params(L, rng).ravel()])
+    gp.update(params)
+    U = gp.params[:M * L].reshape(M, L)
+    its = env["lib"].moihgp_polar_iterations(gp.handle)
+    u, _, vt = np.linalg.svd(A, full_matrices=False)
+    assert np.max(np.abs(U.T @ U - np.eye(L))) < 1e-12
+    assert rel_err(U, u @ vt) < 1e-10, (shape, its)
+    if shape in ("learner", "one_small"):
+        assert 0 < its <= 3, its
+    # the same without the deflation: same factor
+    monkeypatch.setenv("MOIHGP_POLAR_DEFLATE", "0")
+
+
 def test_polar_factor_rank_deficient_input_is_reported(env, capfd):
     gp = env["MOIHGP"](0.1, 6, 3, kernel="Matern32")
     p = gp.params.copy()
@@ -1495,6 +1538,44 @@ def test_stacked_gradient_tables_follow_every_update(env, kern):
     bank.update(p1); bank.update(p2)
     r2 = sweep(bank, Tl, side)
     assert np.array_equal(r2["grad"].cpu().numpy()[tame], f["grad"].cpu().numpy()[tame])
+
+
+@pytest.mark.parametrize("kern", ["Matern32", "Matern52"])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("L,T,nanf", [(1030, 1024, 0.0), (1500, 5000, 0.0), (1100, 4097, 0.0), (1200, 777, 0.0), (1300, 3000, 0.01), (5, 2100, 0.0), (1024, 1, 0.0)])
+def test_segment_major_streams_equal_series_major(env, kern, dtype, L, T, nanf):
+    """moihgp_filter_stream_tiled sweeps the same ticks with the same arithmetic as the series-major entry -- only the addresses differ
+    ([ceil(T / SEG)][L][SEG] instead of [L][ld]) -- so filtered means, end states and per-latent NLLs are equal BIT FOR BIT: whole and ragged
+    last tiles, a single tick, missing ticks (generic path), unstable latents (sequential kernel), a separate start state, the NLL total;
+    and the series-major result is the one the rest of this file checks against the oracle.  moihgp_stream_retile round-trips."""
+    S = env["streams"]
+    rng = np.random.default_rng(3 * L + T)
+    prm = synth_params(L, rng)
+    bank = S.LatentBank(0.1, prm, kernel=KMAP[kern])
+    Ty = synth(L, T, rng, nanf)
+    dev = to_dev(Ty, dtype)
+    x0 = torch.from_numpy(0.3 * rng.standard_normal((L, bank.d))).to(dtype).cuda()
+    ya, xa, na = bank.filter(dev, T=T, x=torch.zeros_like(x0), x_start=x0)
+    tot_a = torch.zeros(1, dtype=torch.float64, device="cuda"); tot_b = torch.zeros_like(tot_a)
+    bank.filter(dev, T=T, x=torch.zeros_like(x0), x_start=x0, nll_total=tot_a)
+    tiled = S.tile_stream(dev, T)
+    assert tuple(tiled.shape) == ((T + S.seg_ticks(dtype) - 1) // S.seg_ticks(dtype), L, S.seg_ticks(dtype))
+    back = S.untile_stream(tiled, T)
+    torch.cuda.synchronize()
+    a, b = dev[:, :T].cpu().numpy(), back[:, :T].cpu().numpy()
+    assert np.array_equal(a, b, equal_nan=True)
+    yb_t, xb, nb = bank.filter_tiled(tiled, T, x=torch.zeros_like(x0), x_start=x0, nll_total=tot_b)
+    yb = S.untile_stream(yb_t, T)
+    torch.cuda.synchronize()
+    assert np.array_equal(ya[:, :T].cpu().numpy(), yb[:, :T].cpu().numpy(), equal_nan=True)
+    assert np.array_equal(xa.cpu().numpy(), xb.cpu().numpy(), equal_nan=True) and np.array_equal(na.cpu().numpy(), nb.cpu().numpy(), equal_nan=True)
+    assert np.array_equal(tot_a.cpu().numpy(), tot_b.cpu().numpy(), equal_nan=True)
+    # NLL-only and means-only modes
+    _, xc, nc = bank.filter_tiled(tiled, T, x=torch.zeros_like(x0), x_start=x0, want_yhat=False)
+    yd_t, xd, _ = bank.filter_tiled(tiled, T, x=torch.zeros_like(x0), x_start=x0, want_nll=False)
+    torch.cuda.synchronize()
+    assert np.array_equal(nc.cpu().numpy(), nb.cpu().numpy(), equal_nan=True) and np.array_equal(xc.cpu().numpy(), xb.cpu().numpy(), equal_nan=True)
+    assert np.array_equal(S.untile_stream(yd_t, T)[:, :T].cpu().numpy(), yb[:, :T].cpu().numpy(), equal_nan=True)
 
 
 @pytest.mark.parametrize("kern", ["Matern52", "Matern52x2"])

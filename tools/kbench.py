@@ -15,6 +15,7 @@ ap.add_argument("--dtype", default="f32"); ap.add_argument("--L", type=int, defa
 ap.add_argument("--variants", default="0,1,2,3,4,5"); ap.add_argument("--rounds", type=int, default=5); ap.add_argument("--per", type=int, default=10)
 ap.add_argument("--nan", type=float, default=0.0); ap.add_argument("--mode", default="fn", help="f=yhat, n=nll")
 ap.add_argument("--cold", action="store_true", help="evict L2 / Infinity Cache before every launch (1 GiB write)")
+ap.add_argument("--tiled", action="store_true", help="segment-major streams (moihgp_filter_stream_tiled) next to the series-major ones: variant -1")
 ap.add_argument("--rotate", type=int, default=0, help="rotate every launch over N distinct (input, output) stream pairs (bench.py's cold leg uses >= 768 MiB of them)")
 a = ap.parse_args()
 dtype = torch.float32 if a.dtype == "f32" else torch.float64
@@ -29,6 +30,10 @@ x = torch.zeros((a.L, 3), dtype=dtype, device=dev)
 variants = [int(v) for v in a.variants.split(",")]
 evict = torch.zeros(256 * 1024 * 1024, dtype=torch.float32, device=dev) if a.cold else None
 rot = [(Ty, yhat)] + [(Ty.clone(), torch.empty_like(yhat)) for _ in range(max(0, a.rotate - 1))]
+if a.tiled:
+    from multioutputihgp_amd.streams import tile_stream, untile_stream
+    rot_t = [(tile_stream(t, a.T), torch.empty_like(tile_stream(t, a.T))) for t, _ in rot]
+    variants = variants + [-1]
 launch_no = 0
 es = 4 if dtype == torch.float32 else 8
 nbytes = (("f" in a.mode) + 1) * es * a.L * a.T
@@ -36,11 +41,16 @@ times = {v: [] for v in variants}; ref = None
 bank.profile_enable(a.per)
 for rnd in range(a.rounds):
     for v in variants:
-        bank.set_option("filter_variant", v)
+        if v >= 0:
+            bank.set_option("filter_variant", v)
         for _ in range(a.per):
             if a.cold:
                 evict.add_(1.0)
             x.zero_()
+            if v < 0:
+                ty_k, yh_k = rot_t[launch_no % len(rot_t)]; launch_no += 1
+                bank.filter_tiled(ty_k, a.T, x=x, yhat=yh_k, nll=nll, want_yhat="f" in a.mode, want_nll="n" in a.mode)
+                continue
             ty_k, yh_k = rot[launch_no % len(rot)]; launch_no += 1
             bank.filter(ty_k, T=a.T, x=x, yhat=yh_k, nll=nll, want_yhat="f" in a.mode, want_nll="n" in a.mode)
         times[v] += bank.profile_read()
