@@ -83,7 +83,9 @@ def filter_kernel_name(bank, L, T, dtype):
         if few and not (fp32 and bank.d > 6):
             return "filter_x_teamc_kernel" if (fp32 or bank.d <= 8) else "filter_x_team_kernel"
         return "filter_x_kernel"
-    return "filter_x_teamc_kernel" if (few and bank.d == 3) else "filter_scan_kernel"
+    if few and bank.d == 3:
+        return "filter_x_teamc_kernel"
+    return "filter_dma_kernel" if L > 512 else "filter_scan_kernel"     # (many latents: the LDS-DMA sweep; up to 512: the time split of recursion.hip)
 
 
 def synth_stream(L, lo, T, dtype, device, seed):
@@ -459,20 +461,25 @@ def valu_side(d, dtype, steps_per_s):
     return {"flops_per_step": flops, "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak}
 
 
-def cold_leg(bank, Ty, yhat, x, x_zero, nll, T, alg_bytes, es):
+def cold_leg(bank, Ty, yhat, x, x_zero, nll, T, alg_bytes, es, tiled=False):
     """Cold-stream figure of a filter configuration: the timed passes sweep ONE resident stream, so between passes part of its input is
     served by the 256 MiB Infinity Cache (and FETCH_SIZE counts those hits): roofline.frac is cache-assisted whenever the input fits.
     Here the same launch rotates over enough distinct (input, output) pairs that nothing it reads can still be on chip."""
-    L = Ty.shape[0]
-    pair_bytes = 2 * es * L * Ty.shape[1]
+    pair_bytes = 2 * es * Ty.numel()
     nrot = max(2, min(8, int((3 * 256 * 2 ** 20 + pair_bytes - 1) // pair_bytes)))
+
+    def sweep(a, b):
+        if tiled:
+            bank.filter_tiled(a, T, x=x, x_start=x_zero, yhat=b, nll=nll)
+        else:
+            bank.filter(a, T=T, x=x, x_start=x_zero, yhat=b, nll=nll)
     try:
         rot = [(Ty, yhat)] + [(Ty.clone(), torch.empty_like(yhat)) for _ in range(nrot - 1)]
         for k in range(nrot):
-            bank.filter(rot[k][0], T=T, x=x, x_start=x_zero, yhat=rot[k][1], nll=nll)
+            sweep(*rot[k])
         bank.profile_enable(3 * nrot)
         for k in range(3 * nrot):
-            bank.filter(rot[k % nrot][0], T=T, x=x, x_start=x_zero, yhat=rot[k % nrot][1], nll=nll)
+            sweep(*rot[k % nrot])
         cold_ms = float(np.mean(bank.profile_read()))
         del rot
         return {"frac_cold": alg_bytes / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "achieved_cold": alg_bytes / (cold_ms * 1e-3) / 1e9,
@@ -556,7 +563,8 @@ def slab_row(device, passes=5, warm=2, world=1, rank=0, reduce=None):
     slab4 = SLAB["c4"]; nsl = T4 // slab4
     prm_all = synth_params(L4 * world, 0, np.random.default_rng(SEED), k4)
     b4 = LatentBank(0.1, prm_all[rank * L4:(rank + 1) * L4], kernel=k4)
-    slabs = [synth_stream(L4, rank * L4, slab4, dt4, device, SEED + 100 + 17 * rank + k) for k in range(nsl)]
+    from multioutputihgp_amd.streams import tile_stream
+    slabs = [tile_stream(synth_stream(L4, rank * L4, slab4, dt4, device, SEED + 100 + 17 * rank + k), slab4) for k in range(nsl)]   # segment-major slabs
     outs = [torch.empty_like(t) for t in slabs]
     n4 = torch.empty((L4,), dtype=torch.float64, device=device); acc = torch.zeros_like(n4)
     x4 = torch.zeros((L4, b4.d), dtype=dt4, device=device); xz = torch.zeros_like(x4)
@@ -564,7 +572,7 @@ def slab_row(device, passes=5, warm=2, world=1, rank=0, reduce=None):
     def one():
         acc.zero_()
         for k in range(nsl):
-            b4.filter(slabs[k], T=slab4, x=x4, x_start=xz if k == 0 else None, yhat=outs[k], nll=n4)
+            b4.filter_tiled(slabs[k], slab4, x=x4, x_start=xz if k == 0 else None, yhat=outs[k], nll=n4)
             acc.add_(n4)
         return reduce(acc) if reduce is not None else acc.sum()
 
@@ -591,6 +599,7 @@ def slab_row(device, passes=5, warm=2, world=1, rank=0, reduce=None):
     row = {"workload": desc4, "dtype": "f32", "ms_per_step": wall * 1e3, "value": world * L4 * T4 / wall, "n_gpus": world,
            "kernel_ms": kms, "kernel_ms_is": "per slab launch", "bound": "hbm", "achieved_GBps": alg / (kms * 1e-3) / 1e9,
            "frac": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "frac_is": "cold by construction (3.3 GB working set per GPU)",
+           "layout": "segment-major slabs [ceil(10^4 / SEG)][L][SEG]",
            "nll_total": float(tot.item() if hasattr(tot, "item") else tot)}
     del b4, slabs, outs
     return row
@@ -736,6 +745,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=None, help="untimed passes before the timed ones (default: 5 for the headline c3; 150 for the other shapes, whose fp64 "
                     "stacked kernels settle over their first ~100 launches: tools/micro/launch_dist.py)")
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS) + ["c1", "c3learn", "c3loop", "c3grad", "c5grad"])
+    ap.add_argument("--layout", default="auto", choices=["auto", "series", "tiled"],
+                    help="stream layout of the timed sweep: series-major [L][ld] or segment-major [T/SEG][L][SEG] (include/moihgp.h moihgp_filter_stream_tiled); "
+                         "auto = tiled where the sweep supports it (the reference's own models, many latents), series otherwise")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / parity leg")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold-stream leg (roofline.frac_cold): profiled runs, so that a kernel trace holds the timed launches only")
     ap.add_argument("--no-others", action="store_true", help="skip the other BASELINE configurations that the default line carries in other_configs")
@@ -823,6 +835,18 @@ def main():
         yhat_slabs = [torch.empty_like(t) for t in Ty_slabs]
 
     x_zero = torch.zeros_like(x)               # every pass starts from this state; it is never written
+    # stream layout of the timed sweep: segment-major where the kernel takes it (the reference's own models through the one-wavefront-per-
+    # latent sweep), series-major otherwise; the other layout's kernel figures ride along in roofline.other_layout (N = 1)
+    can_tile = (not stub) and (not bank.stacked) and L > 512
+    tiled = can_tile if args.layout == "auto" else (args.layout == "tiled")
+    if tiled and not can_tile:
+        raise SystemExit(f"--layout tiled: config {args.config} has no segment-major sweep (stacked model or too few latents)")
+    if tiled:
+        from multioutputihgp_amd.streams import tile_stream, untile_stream
+        if nslab > 1:
+            Tt_slabs = [tile_stream(t, t.shape[1]) for t in Ty_slabs]; yt_slabs = [torch.empty_like(t) for t in Tt_slabs]
+        else:
+            Tt = tile_stream(Ty, T); yt = torch.empty_like(Tt)
 
     tot_ring = [torch.zeros((1,), dtype=torch.float64, device=device) for _ in range(4)]   # NLL totals of the passes in flight
     pass_no = [0]
@@ -832,11 +856,17 @@ def main():
             # the library queues its own one-workgroup total behind the sweep (measured against torch's .sum() on this shape:
             # 58.7 vs 59.8-61.2 us per pass); the path's only exchange is the all-reduce of that 8-byte scalar
             tot = tot_ring[pass_no[0] % len(tot_ring)]; pass_no[0] += 1
-            bank.filter(Ty, T=T, x=x, x_start=x_zero, yhat=yhat, nll=nll, nll_total=tot)
+            if tiled:
+                bank.filter_tiled(Tt, T, x=x, x_start=x_zero, yhat=yt, nll=nll, nll_total=tot)
+            else:
+                bank.filter(Ty, T=T, x=x, x_start=x_zero, yhat=yhat, nll=nll, nll_total=tot)
             return (allreduce_total_async if reduce is allreduce_nll_async else allreduce_total)(tot)
         nll_acc.zero_()
         for k in range(nslab):                 # slabs carry the state x from one launch to the next
-            bank.filter(Ty_slabs[k], T=Ty_slabs[k].shape[1], x=x, x_start=x_zero if k == 0 else None, yhat=yhat_slabs[k], nll=nll)
+            if tiled:
+                bank.filter_tiled(Tt_slabs[k], Ty_slabs[k].shape[1], x=x, x_start=x_zero if k == 0 else None, yhat=yt_slabs[k], nll=nll)
+            else:
+                bank.filter(Ty_slabs[k], T=Ty_slabs[k].shape[1], x=x, x_start=x_zero if k == 0 else None, yhat=yhat_slabs[k], nll=nll)
             nll_acc.add_(nll)
         return reduce(nll_acc)
 
@@ -902,8 +932,32 @@ def main():
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         traffic, traffic_source = pmc_traffic(args.config)
         cold = {}
+        other_layout = None
         if nslab == 1 and not args.no_cold and not stub:
-            cold = cold_leg(bank, Ty, yhat, x, x_zero, nll, T, alg_bytes, es)
+            cold = cold_leg(bank, Tt if tiled else Ty, yt if tiled else yhat, x, x_zero, nll, T, alg_bytes, es, tiled=tiled)
+            if can_tile and world == 1:
+                # the same sweep in the OTHER layout: kernel durations only (resident: bracketed launches with the total between them, as the
+                # headline's second loop; cold: rotating pairs)
+                try:
+                    if tiled:
+                        o_in, o_out = Ty, yhat
+                    else:
+                        from multioutputihgp_amd.streams import tile_stream
+                        o_in = tile_stream(Ty, T); o_out = torch.empty_like(o_in)
+                    bank.profile_enable(20)
+                    for _ in range(20):
+                        if tiled:
+                            bank.filter(o_in, T=T, x=x, x_start=x_zero, yhat=o_out, nll=nll, nll_total=tot_ring[0])
+                        else:
+                            bank.filter_tiled(o_in, T, x=x, x_start=x_zero, yhat=o_out, nll=nll, nll_total=tot_ring[0])
+                    o_ms = float(np.mean(bank.profile_read()))
+                    o_cold = cold_leg(bank, o_in, o_out, x, x_zero, nll, T, alg_bytes, es, tiled=not tiled)
+                    bank.profile_enable(0)
+                    other_layout = {"layout": "series-major [L][ld]" if tiled else "segment-major [T/SEG][L][SEG]",
+                                    "kernel_ms_resident": o_ms, "frac_resident": alg_bytes / (o_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                    "kernel_ms_cold": o_cold.get("kernel_ms_cold"), "frac_cold": o_cold.get("frac_cold")}
+                except Exception as e:
+                    other_layout = {"error": str(e)}
         # roofline.frac is the HBM-honest figure.  One resident stream pair swept again and again is partly served by the 256 MiB Infinity
         # Cache (C3's input is 164 MB), so `frac` / `achieved` / `kernel_ms` are those of the COLD leg -- the same launch rotating over
         # enough distinct stream pairs that nothing it reads is still on chip -- and the resident figures are reported next to them.  A
@@ -921,7 +975,7 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if dtype == torch.float32 else "f64", "data": "synthetic",
             "config": {"workload": desc, "latents_per_gpu": Lg_per, "latents_total": Lglobal, "ticks": T, "state_dim": bank.d,
-                       "layout": "series-major [L][ld], HBM-resident", "sharding": f"latents x{world}, NLL scalar all-reduce per pass" + ("" if world == 1 else (" (stream-ordered)" if args.sync_allreduce else " (overlapped with the next pass)"))},
+                       "layout": ("segment-major [ceil(T/SEG)][L][SEG], SEG = 4 KB of ticks" if tiled else "series-major [L][ld]") + ", HBM-resident", "sharding": f"latents x{world}, NLL scalar all-reduce per pass" + ("" if world == 1 else (" (stream-ordered)" if args.sync_allreduce else " (overlapped with the next pass)"))},
             "roofline": {"bound": "hbm", "achieved": head_achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": head_achieved / HBM_PEAK_GBPS,
                          "frac_is": head_kind,
                          "traffic": traffic, "traffic_source": traffic_source,
@@ -932,7 +986,9 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "frac_of_measured_copy_peak": head_achieved / HBM_COPY_GBPS,
                          # what a plain copy with this sweep's access pattern reaches on this chip (tools/micro/rows_copy.hip, profiles/r04/
                          # rows_copy_access_pattern.log: 4096 row streams 40 KB apart, one wavefront each): the layout's own ceiling
-                         "access_pattern_copy_ceiling_GBps": {"resident": 6820.0, "cold": 5250.0, "source": "profiles/r04/rows_copy_access_pattern.log"},
+                         "access_pattern_copy_ceiling_GBps": ({"resident": 6900.0, "cold": 5940.0} if tiled else {"resident": 6820.0, "cold": 5250.0}),
+                         "access_pattern_copy_ceiling_source": "profiles/r04/rows_copy_access_pattern.log (one wavefront per latent, 4 KB per step, this layout)",
+                         "other_layout": other_layout,
                          # the other wall (mode F is 2 d^2 + 2 d flop per step; the d = 12 fp64 configuration sits on this one)
                          "vector_alu": valu_side(bank.d, dtype, L * min(slab, T) / (kern_ms * 1e-3))},
             "ms_per_step_with_event_pairs": ms_per_step_bracketed,
@@ -996,8 +1052,13 @@ def main():
                 except Exception as e:
                     others["c3loop"] = {"error": str(e)}
                 out["other_configs"] = others
+            if tiled:                                   # the parity leg reads series-major means
+                if nslab > 1:
+                    yhat_slabs = [untile_stream(yt_slabs[k], Ty_slabs[k].shape[1]) for k in range(nslab)]
+                else:
+                    yhat = untile_stream(yt, T)
             if nslab > 1:
-                yhat = torch.cat(yhat_slabs, dim=1)
+                yhat = torch.cat([y[:, :Ty_slabs[k].shape[1]] for k, y in enumerate(yhat_slabs)], dim=1)
             sub = np.arange(0, L, max(1, L // 64))[:64]
             cb, nll_rel, mean_rel = cpu_baseline(prm, Ty[:, :T].cpu().numpy(), T, float(total.item()), yhat[sub][:, :T].double().cpu().numpy(), sub, kernel)
             out["cpu_baseline"] = cb
