@@ -227,8 +227,8 @@ int polar_factor_device(double* X, size_t M, size_t L, double* work, hipStream_t
     double h[8];
     const unsigned nbLL = (unsigned)((L * L + 255) / 256), nbML = (unsigned)((M * L + 255) / 256), nbRow = (unsigned)((L + 3) / 4);
     static const bool deflate_on = [] { const char* e = std::getenv("MOIHGP_POLAR_DEFLATE"); return !(e && e[0] == '0'); }();
-    auto gram_and_stats = [&]() -> int {
-        if (launch_gram(X, M, L, G, s)) return -1;
+    auto gram_and_stats = [&](bool form = true) -> int {
+        if (form && launch_gram(X, M, L, G, s)) return -1;
         hipLaunchKernelGGL(gram_row_stats_kernel, dim3(nbRow), dim3(256), 0, s, G, L, rows);
         hipLaunchKernelGGL(gram_stats_kernel, dim3(1), dim3(256), 0, s, rows, L, stats);
         MOIHGP_HIP_FATAL(hipMemcpyAsync(h, stats, sizeof(double) * 7, hipMemcpyDeviceToHost, s));
@@ -245,7 +245,7 @@ int polar_factor_device(double* X, size_t M, size_t L, double* work, hipStream_t
         int pairs = 0;
         if (polar_deflate(X, M, L, G, h[6], dwork, s, &pairs, polar_trace_level()) != 0) return -1;
         if (pairs > 0) {
-            if (gram_and_stats()) return -1;
+            if (gram_and_stats(false)) return -1;          // (the deflation has updated G along with X)
             bound = fmin(h[0], h[1]);
             if (!(bound > 0.0) || h[0] != h[0]) return -1;
         }

@@ -259,6 +259,40 @@ __global__ void __launch_bounds__(256) rank_update_kernel(double* __restrict__ X
     }
 }
 
+// ---- the Gram matrix after the deflation, without forming it again: with W = I + V D V^T (V: the Ritz vectors, orthonormal; D = diag d) and
+// G V = V + E V,  V^T G V = I + Lambda (Galerkin),   W G W = G + V D (G V)^T + (G V) D V^T + V D (I + Lambda) D V^T  -- three rank-NB terms, one
+// pass over G instead of a 2 M L^2 product.  G_ij += sum_c p1_ic B_jc + p2_ic V_jc,  B = V + E V, p1 = V d, p2 = B d + V d^2 (1 + lambda).
+__global__ void __launch_bounds__(256) gram_update_kernel(double* __restrict__ G, size_t L, const double* __restrict__ Wm, const double* __restrict__ YZ,
+                                                          const double* __restrict__ d, const double* __restrict__ lam) {
+    constexpr int ROWS = 32;
+    __shared__ double p1[ROWS][NB], p2[ROWS][NB];
+    const int tid = threadIdx.x;
+    const size_t j = (size_t)blockIdx.x * 256 + tid, i0 = (size_t)blockIdx.y * ROWS;
+    for (int e = tid; e < ROWS * NB; e += 256) {
+        const size_t i = i0 + e / NB;
+        const int c = e % NB;
+        double a = 0.0, b = 0.0;
+        if (i < L) {
+            const double v = Wm[i * NB + c], bb = v + YZ[i * NB + c], dc = d[c], mc = dc * dc * (1.0 + lam[c]);
+            a = v * dc; b = bb * dc + v * mc;
+        }
+        p1[e / NB][c] = a; p2[e / NB][c] = b;
+    }
+    double vj[NB], bj[NB];
+#pragma unroll
+    for (int c = 0; c < NB; c++) { vj[c] = j < L ? Wm[j * NB + c] : 0.0; bj[c] = j < L ? vj[c] + YZ[j * NB + c] : 0.0; }
+    __syncthreads();
+    if (j >= L) return;
+    for (int r = 0; r < ROWS; r++) {
+        const size_t i = i0 + r;
+        if (i >= L) break;
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < NB; c++) s = fma(p1[r][c], bj[c], fma(p2[r][c], vj[c], s));
+        G[i * L + j] += s;
+    }
+}
+
 // ---- deterministic start block: +-1 / sqrt(L) from a hash of (row, column)
 __global__ void init_block_kernel(double* __restrict__ V, size_t L) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -281,9 +315,9 @@ size_t polar_deflate_work_doubles(size_t M, size_t L) {
     return 4 * L * NB + M * NB + nblk * NB * NB + nblk * 2 * NB + 3 * NB * NB + 6 * NB + 64;
 }
 
-// X (M x L, device) with Gram matrix G (L x L, device) = X^T X and frob2 = ||G - I||_F^2.  On success *n_pairs pairs were deflated (X
-// updated in place when > 0; G is then stale).  Returns 0, or a HIP / launch error code.
-int polar_deflate(double* X, size_t M, size_t L, const double* G, double frob2, double* work, hipStream_t s, int* n_pairs, int trace) {
+// X (M x L, device) with Gram matrix G (L x L, device) = X^T X and frob2 = ||G - I||_F^2.  On success *n_pairs pairs were deflated: when > 0,
+// X and G are both updated in place (G <- W G W by three rank-NB terms, not by a new product).  Returns 0, or a HIP / launch error code.
+int polar_deflate(double* X, size_t M, size_t L, double* G, double frob2, double* work, hipStream_t s, int* n_pairs, int trace) {
     *n_pairs = 0;
     if (L < 2 * NB || !(frob2 > 0.0)) return 0;
     const int nblk = (int)((L + GR - 1) / GR);
@@ -323,7 +357,7 @@ int polar_deflate(double* X, size_t M, size_t L, const double* G, double frob2, 
     int n_ok = 0;
     constexpr int kMaxIter = 6;
     for (int it = 0; it < kMaxIter; it++) {
-        hipLaunchKernelGGL((ts_mm_kernel<true>), dim3(rb16), dim3(256), 0, s, G, L, L, L, (const double*)V, Y);              // Y = E V
+        hipLaunchKernelGGL((ts_mm_kernel<true>), dim3(rb16), dim3(256), 0, s, (const double*)G, L, L, L, (const double*)V, Y);              // Y = E V
         gram(V, Y, T, 1);                                                                                                    // T = V^T E V
         hipLaunchKernelGGL(jacobi32_kernel, dim3(1), dim3(256), 0, s, (const double*)T, lam, Z);
         hipLaunchKernelGGL(ts_rotate_kernel, dim3(rb8), dim3(256), 0, s, (const double*)V, L, (const double*)Z, (const double*)nullptr, 0, Wm);   // Ritz vectors
@@ -358,8 +392,10 @@ int polar_deflate(double* X, size_t M, size_t L, const double* G, double frob2, 
         // next basis: the columns of E W are nearly orthogonal with norms |lambda_i|: normalise, then orthonormalise
         hipLaunchKernelGGL(ts_rotate_kernel, dim3(rb8), dim3(256), 0, s, (const double*)YZ, L, (const double*)nullptr, (const double*)(cst + NB), 2, Y);
         orthonormalise(Y, V);
-        orthonormalise(V, Y);
-        MOIHGP_HIP_FATAL(hipMemcpyAsync(V, Y, sizeof(double) * L * NB, hipMemcpyDeviceToDevice, s));
+        if (it == 0) {                                                   // (from the second Rayleigh-Ritz on the normalised columns are near-orthonormal: one pass)
+            orthonormalise(V, Y);
+            MOIHGP_HIP_FATAL(hipMemcpyAsync(V, Y, sizeof(double) * L * NB, hipMemcpyDeviceToDevice, s));
+        }
     }
     if (n_ok == 0) return 0;
     for (int i = 0; i < NB; i++) if (!accept[i]) h_d[i] = 0.0;
@@ -367,6 +403,9 @@ int polar_deflate(double* X, size_t M, size_t L, const double* G, double frob2, 
     hipLaunchKernelGGL((ts_mm_kernel<false>), dim3((unsigned)((M + 15) / 16)), dim3(256), 0, s, (const double*)X, L, M, L, (const double*)Wm, P);    // P = A W
     hipLaunchKernelGGL(rank_update_kernel, dim3((unsigned)((L + 255) / 256), (unsigned)((M + 31) / 32)), dim3(256), 0, s, X, M, L, (const double*)P, (const double*)dvec,
                        (const double*)Wm);
+    // G <- W G W: the Gram matrix of the updated X (polar.hip continues from it)
+    hipLaunchKernelGGL(gram_update_kernel, dim3((unsigned)((L + 255) / 256), (unsigned)((L + 31) / 32)), dim3(256), 0, s, G, L, (const double*)Wm, (const double*)YZ,
+                       (const double*)dvec, (const double*)lam);
     if (int rc = check_launch("polar_deflate (update)")) return rc;
     MOIHGP_HIP_FATAL(hipStreamSynchronize(s));                            // (h_d is on this frame's stack)
     *n_pairs = n_ok;
