@@ -172,7 +172,8 @@ int moihgp_release_stream(moihgp_gp* gp, void* stream);
  * handle is created -- nothing below consults the environment per launch):
  *   "filter_split"    0 = automatic time split for few latents, 1 = off, n > 1 = n slices      (env MOIHGP_FILTER_SPLIT)
  *   "filter_team"     few latents: -1 = automatic, 0 = never, 1 = always take a one-workgroup-per-latent kernel when the stream fits one
- *                     (2 .. 8 segments of 1024 .. 2048 ticks), 2 = the 2048-tick form only (stacked models)        (env MOIHGP_FILTER_TEAM)
+ *                     (2 .. 8 segments of 1024 .. 2048 ticks), 2 = the 2048-tick form only -- stacked models; the reference's own models have
+ *                     no such form and take the chunk-templated kernel under 2 as under 1                        (env MOIHGP_FILTER_TEAM)
  *   "filter_plain_x"  Matern-3/2 and -5/2 through the stacked filter's kernels (one component): -1 = automatic, 0 = never, 1 = always
  *   "filter_maxlinks" -1 = automatic; chunks with a gap per segment that the stacked filter's second pass takes as broken links
  *                                                                                               (env MOIHGP_FILTER_MAXLINKS)
@@ -316,7 +317,8 @@ void*   moihgp_dvec_ctx_stream(moihgp_dvec_ctx* c);                   /* the con
 double* moihgp_dvec_alloc(size_t n);                                  /* n doubles of device memory (NULL on failure) */
 unsigned char* moihgp_dvec_alloc_mask(size_t n);
 void    moihgp_dvec_free(void* p);                                    /* as hipFree for the caller; blocks of 1 MB and more are kept for the next alloc of that size */
-void    moihgp_dvec_trim(void);                                       /* hand the kept blocks (at most 32 GB) back to the driver */
+void    moihgp_dvec_trim(void);                                       /* hand the kept blocks back to the driver */
+void    moihgp_dvec_cache_limit(size_t bytes);                        /* most the cache may hold (default 8 GB, or MOIHGP_DVEC_CACHE_GB; 0: keep nothing); trims if over */
 int moihgp_dvec_upload(moihgp_dvec_ctx* c, double* dst_dev, const double* src_host, size_t n);     /* synchronous */
 int moihgp_dvec_download(moihgp_dvec_ctx* c, double* dst_host, const double* src_dev, size_t n);   /* synchronous */
 int moihgp_dvec_copy(moihgp_dvec_ctx* c, double* dst_dev, const double* src_dev, size_t n);

@@ -24,7 +24,7 @@ ADDITIVE_SYMBOLS = [
     "moihgp_profile_enable", "moihgp_profile_stride", "moihgp_profile_read", "moihgp_window_set", "moihgp_window_eval", "moihgp_pin_host_buffer",
     "moihgp_update_dev", "moihgp_window_eval_dev", "moihgp_update_dev_on", "moihgp_window_eval_dev_on", "moihgp_get_params_dev", "moihgp_set_option", "moihgp_release_stream",
     "moihgp_ls_shard_gram", "moihgp_ls_shard_apply",
-    "moihgp_dvec_ctx_new", "moihgp_dvec_ctx_del", "moihgp_dvec_ctx_stream", "moihgp_dvec_alloc", "moihgp_dvec_alloc_mask", "moihgp_dvec_free", "moihgp_dvec_trim", "moihgp_dvec_upload", "moihgp_dvec_download",
+    "moihgp_dvec_ctx_new", "moihgp_dvec_ctx_del", "moihgp_dvec_ctx_stream", "moihgp_dvec_alloc", "moihgp_dvec_alloc_mask", "moihgp_dvec_free", "moihgp_dvec_trim", "moihgp_dvec_cache_limit", "moihgp_dvec_upload", "moihgp_dvec_download",
     "moihgp_dvec_copy", "moihgp_dvec_sync", "moihgp_dvec_dot", "moihgp_dvec_axpy", "moihgp_dvec_scale", "moihgp_dvec_sub", "moihgp_dvec_clamp", "moihgp_dvec_active_set",
     "moihgp_dvec_proj_step", "moihgp_dvec_proj_grad_norm",
 ]

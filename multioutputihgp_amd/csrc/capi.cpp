@@ -788,7 +788,7 @@ static int filter_stream_tiled_impl(moihgp_gp* gp, int dtype, const void* Ty, si
         gp->prof_n++;
     }
     return launch_filter_stream_tiled(gp->d, dtype, Ty, T, gp->L, gp->cb64, gp->cb32, x_in, x, yhat, nll, (hipStream_t)stream, e0, e1,
-                                      gp->n_unstable[dtype == MOIHGP_F64 ? 0 : 1], nll_total);
+                                      gp->n_unstable[dtype == MOIHGP_F64 ? 0 : 1], nll_total, gp->opt_filter_variant);
 }
 
 int moihgp_filter_stream_tiled(moihgp_gp* gp, int dtype, const void* Ty, size_t T, const void* x_in, void* x, void* yhat, double* nll, double* nll_total,

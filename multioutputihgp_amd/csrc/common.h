@@ -163,7 +163,7 @@ int launch_grad_scan_x(int kernel, int dtype, const void* Ty, size_t Tpar, size_
 
 // recursion.hip: the same sweep over segment-major streams [ceil(T / SEG)][L][SEG], SEG = 4096 / sizeof(scalar) ticks (d = 2, 3)
 int launch_filter_stream_tiled(int d, int dtype, const void* Ty, size_t T, size_t L, const double* cb64, const float* cb32, const void* xin, void* x,
-                               void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, int n_unstable, double* total);
+                               void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, int n_unstable, double* total, int variant = 0);
 // series-major [L][ld] <-> segment-major [ceil(T / SEG)][L][SEG] (to_tiled != 0: src is series-major; ticks past T are written as zeros)
 int launch_stream_retile(int dtype, const void* src, void* dst, size_t L, size_t T, size_t ld, int to_tiled, hipStream_t stream);
 // recursion.hip: batched sweeps over series-major streams.

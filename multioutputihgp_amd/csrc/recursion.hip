@@ -1271,8 +1271,19 @@ int launch_stream_retile(int dtype, const void* src, void* dst, size_t L, size_t
 // The sweep over SEGMENT-MAJOR streams ([ceil(T / SEG)][L][SEG], SEG = 4096 / sizeof(scalar) ticks; filter_dma_kernel TILED): the reference's
 // own models (d = 2, 3), any number of latents (one wavefront per latent: meant for the many-latent shapes).
 int launch_filter_stream_tiled(int d, int dtype, const void* Ty, size_t T, size_t L, const double* cb64, const float* cb32, const void* xin, void* x,
-                               void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, int n_unstable, double* total) {
+                               void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, int n_unstable, double* total, int variant) {
     if (L == 0) return 0;
+#ifdef MOIHGP_TUNING
+    if (variant >= 20 && variant < 30 && d == 3) {        // ring length / waves per SIMD probes, as for the series-major sweep
+#define MOIHGP_DMA_PROBE_T(V_, NP_, MW_)                                                                                                \
+        if (variant == V_) return dtype == 0 ? launch_filter_dma_t<double, 3, kChunk64, NP_, MW_, true>(Ty, T, 0, L, cb64, cb64, xin, x, yhat, nll, stream, ev0, ev1, n_unstable, total, 0) \
+                                             : launch_filter_dma_t<float, 3, kChunk32, NP_, MW_, true>(Ty, T, 0, L, cb32, cb64, xin, x, yhat, nll, stream, ev0, ev1, n_unstable, total, 0)
+        MOIHGP_DMA_PROBE_T(21, 9, 4); MOIHGP_DMA_PROBE_T(22, 12, 3); MOIHGP_DMA_PROBE_T(23, 16, 2); MOIHGP_DMA_PROBE_T(24, 8, 3); MOIHGP_DMA_PROBE_T(25, 12, 2);
+#undef MOIHGP_DMA_PROBE_T
+    }
+#else
+    (void)variant;
+#endif
     if (dtype == 0) {
         if (d == 2) return launch_filter_dma_t<double, 2, kChunk64, kDmaRing64, kDmaWaves64, true>(Ty, T, 0, L, cb64, cb64, xin, x, yhat, nll, stream, ev0, ev1, n_unstable, total, 0);
         return launch_filter_dma_t<double, 3, kChunk64, kDmaRing64, kDmaWaves64, true>(Ty, T, 0, L, cb64, cb64, xin, x, yhat, nll, stream, ev0, ev1, n_unstable, total, 0);

@@ -26,6 +26,7 @@
 #error "compile with -DMOIHGP_X_TU=<DB J> (21, 31, 22, 23, 24, 32, 33, 34): csrc/Makefile"
 #endif
 #include "x_common.h"
+#include <atomic>
 #include <hip/hip_ext.h>
 #include <cstdlib>
 
@@ -1563,16 +1564,16 @@ int launch_x_teamc(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cb
 // as the runtime computes it; asked once per instantiation and wavefront count
 template <typename T, int DB, int J, int CK>
 int teamc_blocks_per_cu(int nw, size_t smem, bool w, bool n) {
-    static int cache[4][kTeamCWaves + 1] = {};
-    int& slot = cache[(w ? 2 : 0) + (n ? 1 : 0)][nw];
-    if (slot == 0) {
+    static std::atomic<int> cache[4][kTeamCWaves + 1] = {};          // (sweeps may be issued from several host threads: the answer is the same, the write atomic)
+    std::atomic<int>& slot = cache[(w ? 2 : 0) + (n ? 1 : 0)][nw];
+    if (slot.load(std::memory_order_relaxed) == 0) {
         const void* fn = w ? (n ? reinterpret_cast<const void*>(filter_x_teamc_kernel<T, DB, J, true, true, CK>) : reinterpret_cast<const void*>(filter_x_teamc_kernel<T, DB, J, true, false, CK>))
                            : (n ? reinterpret_cast<const void*>(filter_x_teamc_kernel<T, DB, J, false, true, CK>) : reinterpret_cast<const void*>(filter_x_teamc_kernel<T, DB, J, false, false, CK>));
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * nw, smem) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 1; }
-        slot = nb;
+        slot.store(nb, std::memory_order_relaxed);
     }
-    return slot;
+    return slot.load(std::memory_order_relaxed);
 }
 
 // the chunk-templated team kernel for a stream of Tlen ticks, if one of its chunk lengths gives 2 .. kTeamCWaves segments that fit a compute unit

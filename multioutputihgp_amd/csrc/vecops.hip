@@ -7,6 +7,7 @@
 // (fixed order per thread, a tree per workgroup), a second one-workgroup kernel adds the partials in index order; the scalar goes to
 // a page-locked host word.  HBM-bound by construction (one or two streams per element, no reuse).
 #include "common.h"
+#include <cstdlib>
 #include "../../include/moihgp.h"
 
 #include <map>
@@ -144,7 +145,10 @@ static std::map<size_t, std::vector<void*>> g_pool;            // bytes -> free 
 static std::unordered_map<void*, size_t> g_live;               // every block this file handed out and has not returned to the driver
 static size_t g_pool_bytes = 0;
 constexpr size_t kPoolMinBytes = 1 << 20;                      // smaller blocks go straight back to the driver
-constexpr size_t kPoolMaxBytes = (size_t)32 << 30;             // cached at most (MI355X: 288 GB)
+// cached at most: 8 GB unless told otherwise (MOIHGP_DVEC_CACHE_GB at first use, moihgp_dvec_cache_limit() at any time; 0 = keep nothing).
+// The online learner at M = L = 4096 frees and re-allocates 2.7 GB of correction pairs per solve; a library that shares the GPU with a
+// framework's own allocator should not sit on much more than its caller's working set.
+static size_t g_pool_max = [] { const char* e = std::getenv("MOIHGP_DVEC_CACHE_GB"); return (size_t)((e ? std::atof(e) : 8.0) * (double)((size_t)1 << 30)); }();
 
 extern "C" {
 
@@ -209,7 +213,7 @@ void moihgp_dvec_free(void* p) {
     if (bytes != 0 && bytes >= kPoolMinBytes) {
         (void)hipDeviceSynchronize();                                // (what hipFree would have waited for)
         std::lock_guard<std::mutex> lock(g_pool_mutex);
-        if (g_pool_bytes + bytes <= kPoolMaxBytes) { g_pool[bytes].push_back(p); g_pool_bytes += bytes; return; }
+        if (g_pool_bytes + bytes <= g_pool_max) { g_pool[bytes].push_back(p); g_pool_bytes += bytes; return; }
     }
     {
         std::lock_guard<std::mutex> lock(g_pool_mutex);
@@ -226,6 +230,12 @@ void moihgp_dvec_trim(void) {
         g_pool_bytes = 0;
     }
     for (void* p : blocks) (void)hipFree(p);
+}
+void moihgp_dvec_cache_limit(size_t bytes) {
+    { std::lock_guard<std::mutex> lock(g_pool_mutex); g_pool_max = bytes; }
+    bool over;
+    { std::lock_guard<std::mutex> lock(g_pool_mutex); over = g_pool_bytes > bytes; }
+    if (over) moihgp_dvec_trim();
 }
 int moihgp_dvec_upload(moihgp_dvec_ctx* c, double* dst_dev, const double* src_host, size_t n) {
     return dv_guard([&] { MOIHGP_HIP_FATAL(hipMemcpyAsync(dst_dev, src_host, n * sizeof(double), hipMemcpyHostToDevice, c->stream)); MOIHGP_HIP_FATAL(hipStreamSynchronize(c->stream)); return 0; });

@@ -297,6 +297,11 @@ class ShardedMOIHGP:
                        formed on the local rows, then summed with the NLL scalar."""
         from .streams import LatentBank, project_stream, unproject_stream
         import math
+        # the kernels behind this method take Y's base pointer and assume [T][M] rows: a view or a slice would be read wrongly
+        if not (isinstance(Y, torch.Tensor) and Y.is_cuda and Y.dim() == 2 and Y.shape[1] == self.M and Y.dtype in (torch.float32, torch.float64)):
+            raise ValueError(f"Y must be a CUDA tensor [T, {self.M}] of float32 or float64")
+        if not Y.is_contiguous():
+            Y = Y.contiguous()
         T = Y.shape[0]
         missing = torch.isnan(Y)
         if (self.world > 1 or FORCE_COLLECTIVES) and bool(missing.any()):

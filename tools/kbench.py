@@ -33,7 +33,7 @@ rot = [(Ty, yhat)] + [(Ty.clone(), torch.empty_like(yhat)) for _ in range(max(0,
 if a.tiled:
     from multioutputihgp_amd.streams import tile_stream, untile_stream
     rot_t = [(tile_stream(t, a.T), torch.empty_like(tile_stream(t, a.T))) for t, _ in rot]
-    variants = variants + [-1]
+    variants = variants + [-1] + [-v for v in variants if 20 <= v < 30]     # -1: the tiled sweep as shipped; -2x: tiled with ring probe 2x
 launch_no = 0
 es = 4 if dtype == torch.float32 else 8
 nbytes = (("f" in a.mode) + 1) * es * a.L * a.T
@@ -41,8 +41,7 @@ times = {v: [] for v in variants}; ref = None
 bank.profile_enable(a.per)
 for rnd in range(a.rounds):
     for v in variants:
-        if v >= 0:
-            bank.set_option("filter_variant", v)
+        bank.set_option("filter_variant", v if v >= 0 else (0 if v == -1 else -v))
         for _ in range(a.per):
             if a.cold:
                 evict.add_(1.0)
