@@ -750,6 +750,9 @@ def main():
     ap.add_argument("--layout", default="auto", choices=["auto", "series", "tiled"],
                     help="stream layout of the timed sweep: series-major [L][ld] or segment-major [T/SEG][L][SEG] (include/moihgp.h moihgp_filter_stream_tiled); "
                          "auto = tiled where the sweep supports it (the reference's own models, many latents), series otherwise")
+    ap.add_argument("--rotate", action="store_true",
+                    help="every pass of every loop (warm-up, timed, bracketed) sweeps the NEXT of enough distinct stream pairs that nothing it reads is still "
+                         "on chip: a run whose kernel trace holds cold launches only (profiles/: the rocprofv3 summary that `roofline.frac` is checked against)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / parity leg")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold-stream leg (roofline.frac_cold): profiled runs, so that a kernel trace holds the timed launches only")
     ap.add_argument("--no-others", action="store_true", help="skip the other BASELINE configurations that the default line carries in other_configs")
@@ -851,17 +854,30 @@ def main():
             Tt = tile_stream(Ty, T); yt = torch.empty_like(Tt)
 
     tot_ring = [torch.zeros((1,), dtype=torch.float64, device=device) for _ in range(4)]   # NLL totals of the passes in flight
+    # the stream pair(s) the passes sweep: one (the default: `value` is the throughput of repeated sweeps of one HBM-resident stream), or with
+    # --rotate enough distinct copies that every launch of the run is a cold one
+    rot_pairs = []
+    if nslab == 1 and not stub:
+        rot_pairs = [(Tt, yt) if tiled else (Ty, yhat)]
+        if args.rotate:
+            in_b = rot_pairs[0][0].numel() * rot_pairs[0][0].element_size()
+            for _ in range(max(1, min(9, int((3 * 256 * 2 ** 20 + in_b - 1) // in_b) - 1))):
+                rot_pairs.append((rot_pairs[0][0].clone(), torch.empty_like(rot_pairs[0][1])))
+    elif nslab == 1:
+        rot_pairs = [(Ty, yhat)]
     pass_no = [0]
 
     def one_pass(reduce=allreduce_nll):
         if nslab == 1:
             # the library queues its own one-workgroup total behind the sweep (measured against torch's .sum() on this shape:
             # 58.7 vs 59.8-61.2 us per pass); the path's only exchange is the all-reduce of that 8-byte scalar
-            tot = tot_ring[pass_no[0] % len(tot_ring)]; pass_no[0] += 1
+            tot = tot_ring[pass_no[0] % len(tot_ring)]
+            a_in, a_out = rot_pairs[pass_no[0] % len(rot_pairs)]
+            pass_no[0] += 1
             if tiled:
-                bank.filter_tiled(Tt, T, x=x, x_start=x_zero, yhat=yt, nll=nll, nll_total=tot)
+                bank.filter_tiled(a_in, T, x=x, x_start=x_zero, yhat=a_out, nll=nll, nll_total=tot)
             else:
-                bank.filter(Ty, T=T, x=x, x_start=x_zero, yhat=yhat, nll=nll, nll_total=tot)
+                bank.filter(a_in, T=T, x=x, x_start=x_zero, yhat=a_out, nll=nll, nll_total=tot)
             return (allreduce_total_async if reduce is allreduce_nll_async else allreduce_total)(tot)
         nll_acc.zero_()
         for k in range(nslab):                 # slabs carry the state x from one launch to the next
@@ -968,6 +984,8 @@ def main():
             head_ms, head_kind = cold["kernel_ms_cold"], "cold: " + cold["cold_note"]
         elif nslab > 1:
             head_ms, head_kind = kern_ms, f"cold by construction: {nslab} slabs of one {2 * es * L * T / 2 ** 30:.1f} GiB working set"
+        elif args.rotate and len(rot_pairs) > 1:
+            head_ms, head_kind = kern_ms, f"cold: --rotate, every pass of the run sweeps the next of {len(rot_pairs)} distinct stream pairs"
         else:
             head_ms, head_kind = kern_ms, "RESIDENT stream (cold leg skipped): cache-assisted when the input fits the 256 MiB Infinity Cache"
         head_achieved = alg_bytes / (head_ms * 1e-3) / 1e9

@@ -177,6 +177,10 @@ int moihgp_release_stream(moihgp_gp* gp, void* stream);
  *   "filter_plain_x"  Matern-3/2 and -5/2 through the stacked filter's kernels (one component): -1 = automatic, 0 = never, 1 = always
  *   "filter_maxlinks" -1 = automatic; chunks with a gap per segment that the stacked filter's second pass takes as broken links
  *                                                                                               (env MOIHGP_FILTER_MAXLINKS)
+ *   "polar_warm_start" 0 (default) / 1: update() starts the deflation of outlying singular values (csrc/polar_deflate.hip) from the subspace the
+ *                     previous update() of this handle found -- consecutive objective evaluations of a learner differ by one line-search step,
+ *                     and one pass over the Gram matrix is saved.  The factor is the same to rounding (<= 1e-12), but no longer a function of
+ *                     the argument alone bit for bit: off unless asked (include/moihgp_cxx/lbfgsb_dev.hpp asks).
  *   "filter_variant"  kernel tiling probes; accepted only by a library built with -DMOIHGP_TUNING (make TUNING=1), rc 1 otherwise:
  *                     the probe instantiations (some of which do no arithmetic) are not part of the shipped library.
  * Returns 0, or 1 for an unknown name / a value out of range. */

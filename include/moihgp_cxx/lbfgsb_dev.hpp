@@ -400,6 +400,7 @@ public:
         opt::dv_check(moihgp_get_params_dev(_moihgp->handle(), _params.data()), "get_params_dev");
         _LBFGSB_param.m = 10; _LBFGSB_param.max_iterations = 5; _LBFGSB_param.max_linesearch = 20; _LBFGSB_param.max_step = 1e-1;     // :153-159
         _LBFGSB_param.ftol = 1e-8; _LBFGSB_param.epsilon = 1e-8; _LBFGSB_param.epsilon_rel = 1e-8;
+        moihgp_set_option(_moihgp->handle(), "polar_warm_start", 1);        // consecutive evaluations share their outlying subspace: one pass fewer per update
         _solver = new opt::DevLBFGSBSolver(_LBFGSB_param, &_ops);
         _obj = new OnlineObjectiveDev<StateSpace>(_moihgp, &_ops, gamma, _windowsize);
     }

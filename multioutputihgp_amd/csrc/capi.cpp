@@ -82,6 +82,8 @@ struct moihgp_gp {
     size_t winmiss_cap = 0;
     bool win_has_nan = false;
     int polar_its = 0;         // Newton-Schulz steps of the last device polar factor (0: single-workgroup kernel / none yet)
+    int polar_warm = 0;        // dpolar holds the outlying subspace of the previous polar factor (polar_deflate.hip warm start)
+    int opt_polar_warm = 0;    // option "polar_warm_start": use it (off by default: update() is then a function of its argument alone, bit for bit)
     double* dhp = nullptr;     // [L][gradx_hp_len(d)] HA AKHA^k rows of the stacked models' time-parallel gradient sweep (on first use)
     double* dxscratch = nullptr; // stacked kernels, few latents: per-slice NLL partials
     int* dlinkflags = nullptr;   // stacked filter, 1024 latents and more: hand-over flags of its second pass (zero between sweeps: the second pass clears what it takes)
@@ -439,7 +441,7 @@ static bool compute_polar(moihgp_gp* g, const double* Uparam, bool from_device) 
         g->polar_pending = true;
     } else {
         if (!g->dpolar) g->dpolar = dev_alloc<double>(polar_work_doubles(M, L));
-        its = polar_factor_device(g->dU, M, L, g->dpolar, g->stream);
+        its = polar_factor_device(g->dU, M, L, g->dpolar, g->stream, g->opt_polar_warm ? &g->polar_warm : nullptr);
     }
     g->polar_its = its > 0 ? its : 0;
     if (its < 0) return false;
@@ -1094,6 +1096,7 @@ int moihgp_set_option(moihgp_gp* gp, const char* name, long value) {
     if (!gp || !name) { set_last_error("set_option: null argument"); return 1; }
     const std::string n(name);
     if (n == "filter_split") { if (value < 0 || value > 64) { set_last_error("filter_split: 0 (automatic), 1 (off) or a slice count"); return 1; } gp->opt_filter_split = (int)value; return 0; }
+    if (n == "polar_warm_start") { if (value < 0 || value > 1) { set_last_error("polar_warm_start: 0 or 1"); return 1; } gp->opt_polar_warm = (int)value; gp->polar_warm = 0; return 0; }
     if (n == "filter_plain_x") { if (value < -1 || value > 1) { set_last_error("filter_plain_x: -1 (automatic), 0 (never), 1 (always: the stacked filter's kernels for Matern-3/2 and -5/2)"); return 1; } gp->opt_filter_plain_x = (int)value; return 0; }
     if (n == "filter_team") { if (value < -1 || value > 2) { set_last_error("filter_team: -1 (automatic), 0 (never), 1 (whenever the stream fits), 2 (the 32-tick-chunk form only)"); return 1; } gp->opt_filter_team = (int)value; return 0; }
     if (n == "filter_maxlinks") { if (value < -1 || value > 64) { set_last_error("filter_maxlinks: -1 (automatic) .. 64"); return 1; } gp->opt_filter_maxlinks = (int)value; return 0; }

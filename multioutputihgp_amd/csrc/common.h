@@ -245,12 +245,12 @@ int launch_matmul_nn(const double* X, size_t M, size_t L, const double* W, doubl
 // polar.hip: polar factor of an M x L matrix on the device (Newton-Schulz), moihgp.h:433-447.
 // A_dev is overwritten with the factor; work needs polar_work_doubles(M, L) doubles.  Returns the iteration count, or
 // -1 if it did not converge (rank-deficient input).
-int polar_factor_device(double* A_dev, size_t M, size_t L, double* work, hipStream_t s);
+int polar_factor_device(double* A_dev, size_t M, size_t L, double* work, hipStream_t s, int* deflate_warm = nullptr /* in / out: see polar_deflate */);
 size_t polar_work_doubles(size_t M, size_t L);
 // polar_deflate.hip: exact deflation of up to 32 outlying singular values ahead of the iteration (X: M x L, G = X^T X, frob2 = ||G - I||_F^2);
 // *n_pairs > 0: X (polar factor unchanged) and G (= the new X^T X) were updated in place.  Returns 0 or an error code.
 size_t polar_deflate_work_doubles(size_t M, size_t L);
-int polar_deflate(double* X, size_t M, size_t L, double* G, double frob2, double* work, hipStream_t s, int* n_pairs, int trace);
+int polar_deflate(double* X, size_t M, size_t L, double* G, double frob2, double* work, hipStream_t s, int* n_pairs, int trace, int* warm = nullptr);
 // small matrices: the same iteration as one workgroup in LDS (one launch); status_dev: steps taken or -1
 bool polar_small_fits(size_t M, size_t L);
 void launch_polar_small(double* A_dev, size_t M, size_t L, int* status_dev, hipStream_t s);

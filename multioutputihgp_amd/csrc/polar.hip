@@ -217,7 +217,7 @@ static void polar_dump_gram(const double* G, size_t L, hipStream_t s) {
 
 size_t polar_work_doubles(size_t M, size_t L) { return M * L + 2 * L * L + 8 + 4 * L + polar_deflate_work_doubles(M, L); }
 
-int polar_factor_device(double* X, size_t M, size_t L, double* work, hipStream_t s) {
+int polar_factor_device(double* X, size_t M, size_t L, double* work, hipStream_t s, int* deflate_warm) {
     double* G = work;                 // L*L
     double* W = G + L * L;            // L*L
     double* Xn = W + L * L;           // M*L
@@ -241,9 +241,10 @@ int polar_factor_device(double* X, size_t M, size_t L, double* work, hipStream_t
     polar_dump_gram(G, L, s);
     // ---- a few outlying singular values (the online learner's iterate: polar_deflate.hip) are taken out exactly before anything else:
     // worth an attempt whenever the input is not orthonormal to 1e-3 already (two tall-skinny passes over G decide whether it pays)
+    if (!(deflate_on && h[2] > 1e-3) && deflate_warm) *deflate_warm = 0;
     if (deflate_on && h[2] > 1e-3) {
         int pairs = 0;
-        if (polar_deflate(X, M, L, G, h[6], dwork, s, &pairs, polar_trace_level()) != 0) return -1;
+        if (polar_deflate(X, M, L, G, h[6], dwork, s, &pairs, polar_trace_level(), deflate_warm) != 0) return -1;
         if (pairs > 0) {
             if (gram_and_stats(false)) return -1;          // (the deflation has updated G along with X)
             bound = fmin(h[0], h[1]);

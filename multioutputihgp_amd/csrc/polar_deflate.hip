@@ -317,8 +317,13 @@ size_t polar_deflate_work_doubles(size_t M, size_t L) {
 
 // X (M x L, device) with Gram matrix G (L x L, device) = X^T X and frob2 = ||G - I||_F^2.  On success *n_pairs pairs were deflated: when > 0,
 // X and G are both updated in place (G <- W G W by three rank-NB terms, not by a new product).  Returns 0, or a HIP / launch error code.
-int polar_deflate(double* X, size_t M, size_t L, double* G, double frob2, double* work, hipStream_t s, int* n_pairs, int trace) {
+// *warm (in / out, may be NULL): non-zero on entry = `work` still holds the Ritz vectors of the previous successful call for the same (M, L) --
+// consecutive objective evaluations of a learner differ by one line-search step, and so do their outlying subspaces: the iteration starts from
+// them instead of the random block (one pass fewer).  Set on return according to whether Ritz vectors were left behind.
+int polar_deflate(double* X, size_t M, size_t L, double* G, double frob2, double* work, hipStream_t s, int* n_pairs, int trace, int* warm) {
     *n_pairs = 0;
+    const bool warm_start = warm && *warm;
+    if (warm) *warm = 0;
     if (L < 2 * NB || !(frob2 > 0.0)) return 0;
     const int nblk = (int)((L + GR - 1) / GR);
     double* V = work;                     // L x NB: current orthonormal basis
@@ -345,11 +350,16 @@ int polar_deflate(double* X, size_t M, size_t L, double* G, double frob2, double
         hipLaunchKernelGGL(jacobi32_kernel, dim3(1), dim3(256), 0, s, (const double*)T, theta, Q);
         hipLaunchKernelGGL(ts_rotate_kernel, dim3(rb8), dim3(256), 0, s, (const double*)B_, L, (const double*)Q, (const double*)theta, 1, tmp);
     };
-    // start block, orthonormalised twice (the first pass leaves O(cond eps) behind)
-    hipLaunchKernelGGL(init_block_kernel, dim3((unsigned)((L * NB + 255) / 256)), dim3(256), 0, s, Y, L);
-    orthonormalise(Y, V);
-    orthonormalise(V, Y);
-    MOIHGP_HIP_FATAL(hipMemcpyAsync(V, Y, sizeof(double) * L * NB, hipMemcpyDeviceToDevice, s));
+    if (warm_start) {
+        // the previous call's Ritz vectors: orthonormal to rounding (V Z with V orthonormal, Z orthogonal)
+        MOIHGP_HIP_FATAL(hipMemcpyAsync(V, Wm, sizeof(double) * L * NB, hipMemcpyDeviceToDevice, s));
+    } else {
+        // start block, orthonormalised twice (the first pass leaves O(cond eps) behind)
+        hipLaunchKernelGGL(init_block_kernel, dim3((unsigned)((L * NB + 255) / 256)), dim3(256), 0, s, Y, L);
+        orthonormalise(Y, V);
+        orthonormalise(V, Y);
+        MOIHGP_HIP_FATAL(hipMemcpyAsync(V, Y, sizeof(double) * L * NB, hipMemcpyDeviceToDevice, s));
+    }
     if (int rc = check_launch("polar_deflate (start block)")) return rc;
 
     double h_lam[NB], h_cst[2 * NB], h_d[NB];
@@ -384,15 +394,23 @@ int polar_deflate(double* X, size_t M, size_t L, double* G, double frob2, double
             if (fabs(h_d[i]) > 1e-13) worst = fmax(worst, crit);
             n_ok += accept[i] ? 1 : 0;
         }
-        if (trace) std::fprintf(stderr, "polar: deflation pass %d  |lambda|max %.4e  captured %.4f of ||E||_F^2  worst |d| res %.2e (tol %.1e)  converged pairs %d\n",
-                                it + 1, lmax, energy / frob2, worst, tolc, n_ok);
-        if (it >= 1 && energy < 0.9 * frob2) return 0;                   // E is not a few directions: nothing to gain here
+        if (trace) std::fprintf(stderr, "polar: deflation pass %d%s  |lambda|max %.4e  captured %.4f of ||E||_F^2  worst |d| res %.2e (tol %.1e)  converged pairs %d\n",
+                                it + 1, warm_start ? " (warm start)" : "", lmax, energy / frob2, worst, tolc, n_ok);
+        if ((it >= 1 || warm_start) && energy < 0.9 * frob2) {           // E is not a few directions: nothing to gain here
+            if (warm_start && it == 0) {                                  // (or the kept basis belongs to another matrix: once more from the random block)
+                int cold = 0;
+                const int rc = polar_deflate(X, M, L, G, frob2, work, s, n_pairs, trace, &cold);
+                if (warm) *warm = cold;
+                return rc;
+            }
+            return 0;
+        }
         if (worst <= tolc) break;                                        // every pair that matters has converged
         if (it + 1 == kMaxIter) break;
         // next basis: the columns of E W are nearly orthogonal with norms |lambda_i|: normalise, then orthonormalise
         hipLaunchKernelGGL(ts_rotate_kernel, dim3(rb8), dim3(256), 0, s, (const double*)YZ, L, (const double*)nullptr, (const double*)(cst + NB), 2, Y);
         orthonormalise(Y, V);
-        if (it == 0) {                                                   // (from the second Rayleigh-Ritz on the normalised columns are near-orthonormal: one pass)
+        if (it == 0 && !warm_start) {                                    // (from the second Rayleigh-Ritz on the normalised columns are near-orthonormal: one pass)
             orthonormalise(V, Y);
             MOIHGP_HIP_FATAL(hipMemcpyAsync(V, Y, sizeof(double) * L * NB, hipMemcpyDeviceToDevice, s));
         }
@@ -409,6 +427,7 @@ int polar_deflate(double* X, size_t M, size_t L, double* G, double frob2, double
     if (int rc = check_launch("polar_deflate (update)")) return rc;
     MOIHGP_HIP_FATAL(hipStreamSynchronize(s));                            // (h_d is on this frame's stack)
     *n_pairs = n_ok;
+    if (warm) *warm = 1;                                                  // Wm holds this matrix's Ritz vectors for the next call
     return 0;
 }
 

@@ -272,6 +272,50 @@ def test_stream_ragged_shapes_vs_oracle(env, dtype, L, T):
     assert torch.equal(nll2, nll) and torch.equal(x2, xT) and torch.equal(x3, xT) and torch.equal(yh3[:, :T], yhat[:, :T])
 
 
+@pytest.mark.parametrize("kern", ["Matern32", "Matern52"])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("L,T,nanf", [(513, 1, 0.0), (514, 15, 0.0), (520, 1024, 0.0), (517, 1025, 0.0), (600, 3000, 0.0), (515, 5007, 0.0),
+                                      (530, 2048, 0.02), (519, 777, 0.3), (1025, 4100, 0.001)])
+def test_many_latent_sweep_vs_oracle(env, kern, dtype, L, T, nanf):
+    """More than 512 latents take the one-wavefront-per-latent sweep whose stream is staged by LDS-DMA (filter_dma_kernel, csrc/recursion.hip):
+    a ring of 1 KB pieces with hand-counted waits, clamped pieces past the end of the stream, two forms of the ragged last segment (chunk-
+    aligned and not: fp32 chunks are 16 ticks, fp64 8), the missing-data segment path on top of the swizzled ring.  Against the oracle on
+    every latent: one tick, less than a chunk, exactly one segment, one tick more, many segments, dense and sparse gaps; nothing is written
+    past tick T of a row; both layouts."""
+    S = env["streams"]
+    rng = np.random.default_rng(17 * L + T)
+    prm = synth_params(L, rng)
+    bank = S.LatentBank(0.1, prm, kernel=KMAP[kern])
+    igps = env["cref"].ihgp_array(kern, 0.1, prm)
+    Ty = synth(L, T, rng, nanf)
+    x0 = 0.2 * rng.standard_normal((L, bank.d))
+    o = env["cref"].filter_stream(igps, Ty, x0=x0, nthreads=8)
+    tame = np.nan_to_num(np.abs(o["yhat"]), nan=0.0).max(axis=1) < 1e6            # (the literal DARE leaves a few draws unstable)
+    assert tame.sum() > L // 2
+    Tyd = to_dev(Ty, dtype)
+    sentinel = 12345.0
+    yh = torch.full((L, Tyd.shape[1] + 8), sentinel, dtype=dtype, device="cuda")   # wider than the stream: the row's own tail must survive
+    yhat, xT, nll = bank.filter(Tyd, T=T, x=torch.from_numpy(x0).to(dtype).cuda(), yhat=yh)
+    torch.cuda.synchronize()
+    tol = FP64_TIGHT if dtype == torch.float64 else FP32_TOL
+    got = yhat[:, :T].cpu().numpy()
+    assert rel_err_rows(np.nan_to_num(got[tame]), np.nan_to_num(o["yhat"][tame])) < tol
+    assert rel_err(xT.cpu().numpy()[tame], o["x"][tame]) < tol
+    assert rel_err(nll.cpu().numpy()[tame], o["nll_per_latent"][tame]) < tol
+    epv = 2 if dtype == torch.float64 else 4
+    assert bool((yh[:, (T + epv - 1) // epv * epv:] == sentinel).all()), "the sweep wrote past the padded end of a row"
+    # segment-major: ALWAYS the LDS-DMA sweep (series-major, Matern-5/2 at up to 1024 latents and 2 .. 8 segments takes the eight-wavefront team
+    # kernel of recursion_x.hip instead): against the oracle in its own right, and bit for bit where both layouts run the same kernel
+    yt, xb, nb = bank.filter_tiled(S.tile_stream(Tyd, T), T, x=torch.from_numpy(x0).to(dtype).cuda())
+    torch.cuda.synchronize()
+    got_t = S.untile_stream(yt, T)[:, :T].cpu().numpy()
+    assert rel_err_rows(np.nan_to_num(got_t[tame]), np.nan_to_num(o["yhat"][tame])) < tol
+    assert rel_err(xb.cpu().numpy()[tame], o["x"][tame]) < tol and rel_err(nb.cpu().numpy()[tame], o["nll_per_latent"][tame]) < tol
+    if kern == "Matern32" or L > 1024:
+        assert np.array_equal(got_t, got, equal_nan=True)
+        assert np.array_equal(xb.cpu().numpy(), xT.cpu().numpy(), equal_nan=True) and np.array_equal(nb.cpu().numpy(), nll.cpu().numpy(), equal_nan=True)
+
+
 def test_stream_all_missing_and_inf(env):
     rng = np.random.default_rng(4)
     L, T = 4, 1500
@@ -1567,8 +1611,9 @@ def test_segment_major_streams_equal_series_major(env, kern, dtype, L, T, nanf):
     yb_t, xb, nb = bank.filter_tiled(tiled, T, x=torch.zeros_like(x0), x_start=x0, nll_total=tot_b)
     yb = S.untile_stream(yb_t, T)
     torch.cuda.synchronize()
-    if L > 512:
-        # both layouts run the one-wavefront-per-latent kernel: the same operations in the same order
+    if L > 1024 or (L > 512 and kern == "Matern32"):
+        # both layouts run the one-wavefront-per-latent kernel: the same operations in the same order (Matern-5/2 at up to 1024 latents may take
+        # the eight-wavefront team kernel series-major)
         assert np.array_equal(ya[:, :T].cpu().numpy(), yb[:, :T].cpu().numpy(), equal_nan=True)
         assert np.array_equal(xa.cpu().numpy(), xb.cpu().numpy(), equal_nan=True) and np.array_equal(na.cpu().numpy(), nb.cpu().numpy(), equal_nan=True)
         assert np.array_equal(tot_a.cpu().numpy(), tot_b.cpu().numpy(), equal_nan=True)

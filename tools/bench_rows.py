@@ -12,7 +12,7 @@ import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
-from bench import synth_params, synth_stream, SEED
+from bench import synth_params, synth_stream, usable_cpus, SEED
 
 FP32_VEC_TF, FP64_VEC_TF = 157.3, 78.6          # MI355X_MICROARCH.md (fp64 vector: AMD public figure)
 FP32_MFMA_TF, FP64_MFMA_TF = 157.3, 78.6
@@ -60,7 +60,7 @@ def row_grad(a):
                 Ls = min(a.L, 1024)
                 igps = cref.ihgp_array("Matern52", 0.1, prm[:Ls])
                 Tyh = Ty[:Ls, :T].cpu().numpy()
-                nth = min(os.cpu_count() or 1, int(cref.lib().orc_max_threads()))
+                nth = max(1, min(usable_cpus(), int(cref.lib().orc_max_threads())))
                 t0 = time.perf_counter(); cref.grad_stream(igps, Tyh, want_yhat=False, nthreads=nth); tc = time.perf_counter() - t0
                 rec.update(cpu_steps_per_s=Ls * T / tc, cpu_threads=nth)
             out.append(rec)
@@ -115,7 +115,7 @@ def row_stacked(a):
                        frac_hbm=2 * es * L * T / (ms * 1e-3) / 1e9 / 8000.0)
             if dtype == torch.float64 and L >= 1024:
                 Ls = 512
-                nth = min(os.cpu_count() or 1, int(cref.lib(wide=True).orc_max_threads()))
+                nth = max(1, min(usable_cpus(), int(cref.lib(wide=True).orc_max_threads())))
                 igps = cref.ihgp_array(kern, 0.1, prm[:Ls])
                 Tyh = Ty[:Ls, :T].cpu().numpy()
                 t0 = time.perf_counter(); cref.filter_stream(igps, Tyh, nthreads=nth); tc = time.perf_counter() - t0
