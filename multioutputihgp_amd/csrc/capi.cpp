@@ -21,6 +21,11 @@
 namespace moihgp {
 
 static thread_local char g_last_error[512] = "";
+// option "filter_impute" left to itself: latents whose stream holds this many missing ticks or more are swept by imputation (gaps_x.hip).  One: the
+// second pass of recursion_x.hip costs a walk of one latent's stream however few latents take it (one wave per SIMD at d = 12), the imputation
+// costs per latent; measured (tools/filternan.py, 4096 x 10^4, d = 12 fp64) a threshold of 4 loses to both "always" and "never" between 10^-4
+// and 10^-3 missing, and "always" loses 15 % to "never" only below 2 gaps per latent
+constexpr int kGapAutoMin = 1;
 
 void set_last_error(const char* fmt, ...) {
     va_list ap;
@@ -83,6 +88,13 @@ struct moihgp_gp {
     bool win_has_nan = false;
     int polar_its = 0;         // Newton-Schulz steps of the last device polar factor (0: single-workgroup kernel / none yet)
     int polar_warm = 0;        // dpolar holds the outlying subspace of the previous polar factor (polar_deflate.hip warm start)
+    int opt_filter_impute = -1; // option "filter_impute": missing ticks of the stacked many-latent sweep by imputation (gaps_x.hip): 0 never, n >= 1: latents
+                                // whose stream holds n gaps or more, -1 = kGapAutoMin of them for d >= 8
+    void* dgap = nullptr;       // its compact bank (gap_bank_bytes), on first use
+    size_t gap_cap = 0;
+    unsigned long long cb_version = 1;        // bumped whenever the constant blocks are rebuilt
+    unsigned long long gap_imp_version = 0;   // cb_version the bank's impulse responses were swept for
+    unsigned long long gap_sig = 0;   // scalar type the bank's constant parts (at its head) were written for
     int opt_polar_warm = 0;    // option "polar_warm_start": use it (off by default: update() is then a function of its argument alone, bit for bit)
     double* dhp = nullptr;     // [L][gradx_hp_len(d)] HA AKHA^k rows of the stacked models' time-parallel gradient sweep (on first use)
     double* dxscratch = nullptr; // stacked kernels, few latents: per-slice NLL partials
@@ -119,7 +131,7 @@ struct moihgp_gp {
 
 static void gp_free(moihgp_gp* g) {
     if (!g) return;
-    void* ptrs[] = {g->dU, g->dS, g->dsqrtS, g->dinvsqrtS, g->dsigma, g->dparams, g->cb64, g->cb32, g->dx, g->dpart, g->dTy, g->dUty, g->dTyhat, g->dloss, g->dgrad, g->dscratch, g->dwork, g->dpolar, g->dfallback, g->dwin, g->dunstable, g->dxscratch, g->cbd64, g->dU32, g->dhp, g->dlink, g->dwinmiss, g->dtp64, g->dtp32, g->dxc64, g->dxc32, g->dlinkflags};
+    void* ptrs[] = {g->dU, g->dS, g->dsqrtS, g->dinvsqrtS, g->dsigma, g->dparams, g->cb64, g->cb32, g->dx, g->dpart, g->dTy, g->dUty, g->dTyhat, g->dloss, g->dgrad, g->dscratch, g->dwork, g->dpolar, g->dfallback, g->dwin, g->dunstable, g->dxscratch, g->cbd64, g->dU32, g->dhp, g->dlink, g->dwinmiss, g->dtp64, g->dtp32, g->dxc64, g->dxc32, g->dlinkflags, g->dgap};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (void* p : g->pinned) (void)hipHostUnregister(p);
@@ -186,6 +198,7 @@ static void upload_mixing(moihgp_gp* g) {
 static void run_ihgp_update(moihgp_gp* g) {
     order_after_sweeps(g);
     g->hp_valid = false;
+    g->cb_version++;
     MOIHGP_HIP_FATAL(hipMemcpyAsync(g->dparams, g->igp.data(), sizeof(double) * g->L * g->P, hipMemcpyHostToDevice, g->stream));
     if (kernel_stack(g->kernel)) {
         // the sensitivities cost nine more 100-iteration Lyapunov solves per latent at d = 12: only for handles that use them
@@ -742,6 +755,37 @@ static int filter_stream_io_impl(moihgp_gp* gp, int dtype, const void* Ty, size_
             gp->dlinkflags = dev_alloc<int>(gp->L);
             MOIHGP_HIP_FATAL(hipMemsetAsync(gp->dlinkflags, 0, gp->L * sizeof(int), (hipStream_t)stream));
         }
+        // many latents, a state too wide for per-chunk maps: latents whose stream holds missing ticks are swept by imputation (gaps_x.hip) between
+        // the first pass (which hands them over) and the second (which takes what the imputation could not)
+        const bool impute = !plain_x && gp->L >= 1024 && T > 0 && gp->opt_filter_split == 0 && (yhat || nll) &&
+                            (gp->opt_filter_impute >= 1 || (gp->opt_filter_impute == -1 && gp->d >= 8));
+        if (impute) {
+            const size_t need = gap_bank_bytes(gp->d, dtype, gp->L, ld, T);
+            if (gp->gap_cap < need) {
+                if (gp->dgap) { MOIHGP_HIP_FATAL(hipDeviceSynchronize()); MOIHGP_HIP_FATAL(hipFree(gp->dgap)); gp->dgap = nullptr; gp->gap_cap = 0; }
+                void* p = nullptr;
+                MOIHGP_HIP_FATAL(hipMalloc(&p, need));
+                gp->dgap = p; gp->gap_cap = need; gp->gap_sig = 0;
+            }
+            const GapBank bank = gap_bank_carve(gp->dgap, gp->d, dtype, gp->L, ld, T);
+            const unsigned long long sig = (unsigned long long)(dtype + 1);
+            if (gp->gap_sig != sig) {                                    // a fresh bank, or another scalar type: unit impulses and the zero state again
+                if (int rc = gap_bank_init(bank, gp->d, dtype, gp->L, (hipStream_t)stream)) return rc;
+                gp->gap_sig = sig; gp->gap_imp_version = 0;
+            }
+            if (gp->gap_imp_version != gp->cb_version) {                 // the filters' impulse responses: once per parameter update
+                if (int rc = launch_gap_impulse(bank, kid, dtype, gp->L, xb64, xb32, (hipStream_t)stream)) return rc;
+                gp->gap_imp_version = gp->cb_version;
+            }
+            const int min_gaps = gp->opt_filter_impute >= 1 ? gp->opt_filter_impute : kGapAutoMin;
+            if (int rc = launch_filter_stream_x(kid, dtype, Ty, T, ld, gp->L, xb64, xb32, x_in, x, yhat, nll, (hipStream_t)stream, e0, e1, gp->dxscratch, slen, -2, ld_out,
+                                                gp->dlinkflags, gp->dlink, nullptr, gp->opt_filter_maxlinks, gp->opt_filter_team, gp->dtp64, gp->dtp32)) return rc;
+            if (int rc = launch_gap_imputation(bank, kid, dtype, Ty, T, ld, gp->L, xb64, xb32, x_in, x, yhat, nll, ld_out, gp->dlinkflags, min_gaps, (hipStream_t)stream)) return rc;
+            if (int rc = launch_filter_stream_x(kid, dtype, Ty, T, ld, gp->L, xb64, xb32, x_in, x, yhat, nll, (hipStream_t)stream, nullptr, nullptr, gp->dxscratch, slen, -3, ld_out,
+                                                gp->dlinkflags, gp->dlink, nullptr, gp->opt_filter_maxlinks, gp->opt_filter_team, gp->dtp64, gp->dtp32)) return rc;
+            if (nll && nll_total) launch_nll_total(nll, gp->L, nll_total, (hipStream_t)stream);
+            return 0;
+        }
         int rc = launch_filter_stream_x(kid, dtype, Ty, T, ld, gp->L, xb64, xb32, x_in, x, yhat, nll, (hipStream_t)stream, e0, e1,
                                         gp->dxscratch, slen, gp->opt_filter_split /* test hook: 1 = off, n = slices */, ld_out, gp->L >= 1024 ? gp->dlinkflags : nullptr, gp->dlink, nll ? nll_total : nullptr,
                                         gp->opt_filter_maxlinks, gp->opt_filter_team, gp->dtp64, gp->dtp32);
@@ -1096,6 +1140,7 @@ int moihgp_set_option(moihgp_gp* gp, const char* name, long value) {
     if (!gp || !name) { set_last_error("set_option: null argument"); return 1; }
     const std::string n(name);
     if (n == "filter_split") { if (value < 0 || value > 64) { set_last_error("filter_split: 0 (automatic), 1 (off) or a slice count"); return 1; } gp->opt_filter_split = (int)value; return 0; }
+    if (n == "filter_impute") { if (value < -1 || value > 1000000) { set_last_error("filter_impute: -1 (automatic: state dimension >= 8), 0 (never), n >= 1 (stacked models: latents with n gaps or more)"); return 1; } gp->opt_filter_impute = (int)value; return 0; }
     if (n == "polar_warm_start") { if (value < 0 || value > 1) { set_last_error("polar_warm_start: 0 or 1"); return 1; } gp->opt_polar_warm = (int)value; gp->polar_warm = 0; return 0; }
     if (n == "filter_plain_x") { if (value < -1 || value > 1) { set_last_error("filter_plain_x: -1 (automatic), 0 (never), 1 (always: the stacked filter's kernels for Matern-3/2 and -5/2)"); return 1; } gp->opt_filter_plain_x = (int)value; return 0; }
     if (n == "filter_team") { if (value < -1 || value > 2) { set_last_error("filter_team: -1 (automatic), 0 (never), 1 (whenever the stream fits), 2 (the 32-tick-chunk form only)"); return 1; } gp->opt_filter_team = (int)value; return 0; }

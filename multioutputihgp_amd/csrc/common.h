@@ -161,6 +161,22 @@ int launch_gp_table_x(int kernel, const double* cb64, const double* cbd64, doubl
 int launch_grad_scan_x(int kernel, int dtype, const void* Ty, size_t Tpar, size_t ld, size_t L, const double* cb64, const double* cbd64,
                        void* x, void* dx, void* yhat, double* nll, double* grad, int* flags, double* hp, hipStream_t stream, int out_mode, int hp_build = 1);
 
+// gaps_x.hip: missing ticks of the stacked models' many-latent sweep by exact imputation (two gap-free sweeps of the latents that hold gaps
+// around a scalar recursion over their gaps).  GapBank: the compact bank those sweeps run on, carved out of one allocation of gap_bank_bytes().
+struct GapBank {
+    int* ctl = nullptr;                                         // [0] slots in use, [16 + c] slot c is live, [16 + L + c] the latent slot c holds
+    void* imp_in = nullptr; void* imp_out = nullptr;            // [L][1024]: unit impulses (constant: gap_bank_init) and the filters' responses to them
+    void* xz = nullptr;                                         // zeros [L][d]: the start state of the impulse sweep
+    void* stream_in = nullptr; void* stream_out = nullptr;      // [L][ld] of the stream's scalar type
+    void* x1 = nullptr;                                         // end states of the PRED sweeps [L][d] (unused)
+    int* glist = nullptr; int* cntp = nullptr;                  // the gaps' ticks per (slot, part of 2048 ticks), in order, and their number
+};
+size_t gap_bank_bytes(int d, int dtype, size_t L, size_t ld, size_t T);
+GapBank gap_bank_carve(void* base, int d, int dtype, size_t L, size_t ld, size_t T);
+int launch_gap_imputation(const GapBank& b, int kernel, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* cb64, const float* cb32, const void* xin, void* x,
+                          void* yhat, double* nll, size_t ldo, int* flags, int min_gaps, hipStream_t s);
+int gap_bank_init(const GapBank& b, int d, int dtype, size_t L, hipStream_t s);
+int launch_gap_impulse(const GapBank& b, int kernel, int dtype, size_t L, const double* cb64, const float* cb32, hipStream_t s);
 // recursion.hip: the same sweep over segment-major streams [ceil(T / SEG)][L][SEG], SEG = 4096 / sizeof(scalar) ticks (d = 2, 3)
 int launch_filter_stream_tiled(int d, int dtype, const void* Ty, size_t T, size_t L, const double* cb64, const float* cb32, const void* xin, void* x,
                                void* yhat, double* nll, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, int n_unstable, double* total, int variant = 0);

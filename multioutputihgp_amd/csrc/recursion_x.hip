@@ -93,7 +93,9 @@ __device__ inline void load_replay_const(P cu /* uniform view of the latent's bl
 
 // DPP form (fp64, d = 9 and 12): tick by tick, HA and K through slabs; the d = 12 instantiation sits at 256 registers exactly (two waves
 // per SIMD), which the grouped form below would overflow.
-template <typename T, int DB, int J, bool WRITE, bool NLL>
+// PRED (gaps_x.hip's first sweep): the tile receives the PREDICTED observation HA x (pre-step) instead of the filtered mean xnew(0, 0) -- as
+// y - v, which at a tick whose y is zero is HA x exactly
+template <typename T, int DB, int J, bool WRITE, bool NLL, bool PRED = false>
 __device__ inline void replay_dpp(const T (&a)[J * DB * DB], const T& ha, const T& kk, T* tile_lane, T* carry, int lane, int n, int head,
                               T (&xs)[DB * J], T (&xc)[DB * J], double& acc, unsigned& nobs) {
     constexpr int D = DB * J;
@@ -128,7 +130,7 @@ __device__ inline void replay_dpp(const T (&a)[J * DB * DB], const T& ha, const 
         static_for<D>([&](auto ii) { fmac_bc<decltype(ii)::value>(xn[decltype(ii)::value], kk, v); });   // ihgp.h:90 as A x + K (y - HA x)
 #pragma unroll
         for (int i = 0; i < D; i++) xs[i] = xn[i];
-        if (WRITE) tile_lane[k] = xn[0];                            // ihgp.h:91 `yhat = xnew(0, 0)`, literally
+        if (WRITE) tile_lane[k] = PRED ? (y - v) : xn[0];           // ihgp.h:91 `yhat = xnew(0, 0)`, literally
         if (k == klast) {                                           // wave-uniform
             if (lane == jl) {
                 if (NLL && counted) acc += part;
@@ -151,7 +153,7 @@ __device__ inline void replay_dpp(const T (&a)[J * DB * DB], const T& ha, const 
 // "is this the stream's last tick" test (five scalar instructions and a branch per tick: a lone wave issues one instruction of any kind
 // per four cycles, so they cost as much as vector ones); its carry-out is lane 63's final state.  The team kernel asks for it; the
 // many-latent kernel keeps the single loop (a second copy took part in its register allocation).
-template <typename T, int DB, int J, bool WRITE, bool NLL, bool FULLFAST = false, int CKR = kChunkX /* ticks per lane */>
+template <typename T, int DB, int J, bool WRITE, bool NLL, bool FULLFAST = false, int CKR = kChunkX /* ticks per lane */, bool PRED = false>
 __device__ inline void replay(const ReplayConst<T, DB, J>& rc, T* tile_lane, T* carry, int lane, int n, int head,
                               T (&xs)[DB * J], T (&xc)[DB * J], double& acc, unsigned& nobs) {
     using RC = ReplayConst<T, DB, J>;
@@ -159,7 +161,7 @@ __device__ inline void replay(const ReplayConst<T, DB, J>& rc, T* tile_lane, T* 
     constexpr int D = DB * J, EPV = 16 / sizeof(T), NG = CKR / EPV;
     if constexpr (!RC::PK && !RC::SOP) {
         static_assert(RC::PK || RC::SOP || CKR == kChunkX, "the slab form is built for kChunkX ticks per lane");
-        replay_dpp<T, DB, J, WRITE, NLL>(rc.a, rc.ha, rc.kk, tile_lane, carry, lane, n, head, xs, xc, acc, nobs);
+        replay_dpp<T, DB, J, WRITE, NLL, PRED>(rc.a, rc.ha, rc.kk, tile_lane, carry, lane, n, head, xs, xc, acc, nobs);
         return;
     }
     const int jl = (n - 1) / CKR, klast = (n - 1) % CKR;      // lane and tick of the last tick of the segment
@@ -208,7 +210,7 @@ __device__ inline void replay(const ReplayConst<T, DB, J>& rc, T* tile_lane, T* 
                     }
 #pragma unroll
                 for (int i = 0; i < RC::NPAIR * DB; i++) X[i] = XN[i];
-                o[e] = XN[0].x;                                        // ihgp.h:91 `yhat = xnew(0, 0)`, literally
+                o[e] = PRED ? (y[e] - v) : XN[0].x;                    // ihgp.h:91 `yhat = xnew(0, 0)`, literally
                 if (CHECK && k == klast) {                             // wave-uniform
                     if (lane == jl) {
                         if (NLL && counted) acc += (double)partf;
@@ -247,7 +249,7 @@ __device__ inline void replay(const ReplayConst<T, DB, J>& rc, T* tile_lane, T* 
                 for (int i = 0; i < D; i++) xn[i] = fma(rc.ks[i], v, xn[i]);                        // ihgp.h:90 as A x + K (y - HA x)
 #pragma unroll
                 for (int i = 0; i < D; i++) xs[i] = xn[i];
-                o[e] = xn[0];                                          // ihgp.h:91 `yhat = xnew(0, 0)`, literally
+                o[e] = PRED ? (y[e] - v) : xn[0];                      // ihgp.h:91 `yhat = xnew(0, 0)`, literally
                 if (CHECK && k == klast) {                             // wave-uniform
                     if (lane == jl) {
                         if (NLL && counted) acc += part;
@@ -379,7 +381,7 @@ constexpr int x_min_waves() {
 // The sweep of ONE wavefront over (a slice of) one latent's stream: the body of filter_x_kernel, and the fallback of the team kernel
 // below (one latent per workgroup), which hands a latent it cannot take to this code.  `tile` is the wave's padded LDS tile
 // (64 x (kChunkX + 16 bytes)), `carry` its D-entry carry-out slot.
-template <typename T, int DB, int J, bool WRITE, bool NLL, bool SPLIT, bool LINKS>
+template <typename T, int DB, int J, bool WRITE, bool NLL, bool SPLIT, bool LINKS, bool PRED = false>
 __device__ __forceinline__ void filter_x_body(const T* __restrict__ Ty, size_t Tlen, size_t ld, const T* __restrict__ cbT, const double* __restrict__ cb64,
                 const T* xin0 /* start state */, T* x /* end state; may be the same buffer */, T* __restrict__ yhat, double* __restrict__ nll,
                 int nslice, int segs_per_slice, double* __restrict__ nll_part, size_t ldo /* row stride of yhat */,
@@ -781,7 +783,7 @@ __device__ __forceinline__ void filter_x_body(const T* __restrict__ Ty, size_t T
 #pragma unroll
                 for (int i = 0; i < D; i++) xc[i] = read_lane(xs[i], 63);
             } else
-            replay<T, DB, J, WRITE, NLL>(rc, tile_lane, carry, lane, n, head, xs, xc, acc, nobs);
+            replay<T, DB, J, WRITE, NLL, false, kChunkX, PRED>(rc, tile_lane, carry, lane, n, head, xs, xc, acc, nobs);
         }
         // ---- stage out ----
         if (WRITE) {
@@ -814,11 +816,17 @@ __device__ __forceinline__ void filter_x_body(const T* __restrict__ Ty, size_t T
     }
 }
 
-template <typename T, int DB, int J, bool WRITE, bool NLL, int WPB, bool SPLIT, bool LINKS>
+template <typename T, int DB, int J, bool WRITE, bool NLL, int WPB, bool SPLIT, bool LINKS, bool PRED = false>
 __global__ void __launch_bounds__(64 * WPB, (x_min_waves<T, DB * J, SPLIT, LINKS>()))
 filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, const T* __restrict__ cbT, const double* __restrict__ cb64,
                 const T* xin0, T* x, T* __restrict__ yhat, double* __restrict__ nll, int nslice, int segs_per_slice, double* __restrict__ nll_part, size_t ldo,
-                int* __restrict__ link_flags, double* __restrict__ link_state) {
+                int* __restrict__ link_flags, double* __restrict__ link_state,
+                const int* __restrict__ active /* or NULL.  gaps_x.hip's compact banks: active[0] slots are in use; the stream of slot c is row c of Ty, its
+                                                  constants and start state those of latent m = active[16 + L + c] of the full arrays.  There nslice is the
+                                                  number of parts of the stream, nll_part the (int) gap counts per (slot, part), segs_per_slice the fewest gaps
+                                                  a slot is swept for.  With PRED its outputs (x, yhat) go to row c; without -- only if active[16 + c] != 0 --
+                                                  to row m of the caller's arrays (x, yhat, nll), the NLL without the gaps' terms, and flag m of
+                                                  (int*)link_state is cleared */) {
     constexpr int D = DB * J, STRIDE = kChunkX + 16 / (int)sizeof(T);
     __shared__ __attribute__((aligned(16))) T tiles[WPB][64 * STRIDE];
     __shared__ T carries[WPB][D];                                    // carry-out of a segment (written by the lane that holds its last tick)
@@ -827,8 +835,42 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
     const size_t l = SPLIT ? (size_t)blockIdx.x : (size_t)blockIdx.x * WPB + wave;   // SPLIT: grid = (latents, slices)
     const int slice = SPLIT ? (int)blockIdx.y : 0;
     if (l >= L) return;                                              // no workgroup barrier below
-    filter_x_body<T, DB, J, WRITE, NLL, SPLIT, LINKS>(Ty, Tlen, ld, cbT, cb64, xin0, x, yhat, nll, nslice, segs_per_slice, nll_part, ldo, link_flags, link_state,
+    int gaps = 0;                                                    // (scalar registers, all of it)
+    size_t m = l;
+    int* flags_out = nullptr;
+    if constexpr (!SPLIT && !LINKS) {
+        if (active) {
+            if (l >= (size_t)active[0]) return;
+            const int* cntp = reinterpret_cast<const int*>(nll_part) + l * (size_t)nslice;
+            for (int p0 = 0; p0 < nslice; p0 += 64) gaps += p0 + lane < nslice ? cntp[p0 + lane] : 0;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) gaps += __shfl_xor(gaps, o, 64);
+            gaps = __builtin_amdgcn_readfirstlane(gaps);
+            if (gaps < segs_per_slice) return;
+            if (!PRED && active[16 + l] == 0) return;                // the scalar recursion gave this one up
+            m = (size_t)active[16 + L + l];
+            const ptrdiff_t shift = (ptrdiff_t)m - (ptrdiff_t)l;
+            cbT += shift * XC<D>::SIZE;
+            cb64 += shift * XC<D>::SIZE;
+            xin0 += shift * D;
+            if (!PRED) {                                             // outputs straight into the caller's arrays
+                x += shift * D;
+                if (yhat) yhat += shift * (ptrdiff_t)ldo;
+                if (nll) nll += shift;
+                flags_out = reinterpret_cast<int*>(link_state);
+            }
+            nslice = 1; segs_per_slice = 0; nll_part = nullptr; link_state = nullptr;
+        }
+    }
+    filter_x_body<T, DB, J, WRITE, NLL, SPLIT, LINKS, PRED>(Ty, Tlen, ld, cbT, cb64, xin0, x, yhat, nll, nslice, segs_per_slice, nll_part, ldo, link_flags, link_state,
                                                       l, slice, lane, tiles[wave], carries[wave]);
+    if constexpr (!SPLIT && !LINKS && !PRED) {
+        if (flags_out && lane == 0) {
+            // the gaps were swept as observations that equal their predictions: v = 0, but counted (ihgp.h:204-209 does not); nothing observed: exactly 0
+            if (NLL) nll[l] = (size_t)gaps == Tlen ? 0.0 : nll[l] - 0.5 * (double)gaps * cb64[l * XC<D>::SIZE + XC<D>::LOGS];
+            flags_out[m] = 0;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -1483,7 +1525,10 @@ __global__ void __launch_bounds__(1024) sum_slices_total_kernel(const double* __
 template <typename T, int DB, int J, int WPB, bool SPLIT>
 int launch_x(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, const double* cb64, const void* xin, void* x, void* yhat, double* nll,
              hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, int nslice, int segs_per_slice, double* nll_part, size_t ldo,
-             int* link_flags = nullptr, double* link_state = nullptr, double* total = nullptr) {
+             int* link_flags = nullptr, double* link_state = nullptr, double* total = nullptr,
+             int pass_mode = 0 /* 0: first pass + second (LINKS) pass; 1: the first only; 2: the second only; 3: the first only, over a compact bank;
+                                    4: as 3, writing predicted observations HA x instead of filtered means (no NLL) */,
+             const int* active = nullptr) {
     dim3 block(64 * WPB), grid(SPLIT ? (unsigned)L : (unsigned)((L + WPB - 1) / WPB), SPLIT ? (unsigned)nslice : 1u);
     const T* ty = static_cast<const T*>(Ty);
     const T* xi = static_cast<const T*>(xin);
@@ -1493,14 +1538,24 @@ int launch_x(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, con
     // (link_flags: zero when the handle allocates them, set by the first pass, cleared again by the second as it takes a latent over)
 #define MOIHGP_X_LAUNCH(W_, N_)                                                                                                              \
     do {                                                                                                                                     \
-        hipExtLaunchKernelGGL((filter_x_kernel<T, DB, J, W_, N_, WPB, SPLIT, false>), grid, block, 0, stream, ev0, ev1, 0,                    \
-                              ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nslice, segs_per_slice, nll_part, ldo, link_flags, link_state);   \
+        if (pass_mode != 2)                                                                                                                  \
+            hipExtLaunchKernelGGL((filter_x_kernel<T, DB, J, W_, N_, WPB, SPLIT, false>), grid, block, 0, stream, ev0, ev1, 0,                \
+                                  ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nslice, segs_per_slice, nll_part, ldo, link_flags, link_state, active); \
         if constexpr (!SPLIT) {                                                                                                              \
-            if (link_flags)      /* second pass: the latents stopped at a segment with gaps (none: the grid exits at once) */                 \
+            if (link_flags && (pass_mode == 0 || pass_mode == 2))  /* second pass: the latents stopped at a segment with gaps (none: the grid exits at once) */ \
                 hipLaunchKernelGGL((filter_x_kernel<T, DB, J, W_, N_, WPB, SPLIT, true>), grid, block, 0, stream,                             \
-                                   ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nslice, segs_per_slice, nll_part, ldo, link_flags, link_state); \
+                                   ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nslice, segs_per_slice, nll_part, ldo, link_flags, link_state, (const int*)nullptr); \
         }                                                                                                                                    \
     } while (0)
+    if constexpr (!SPLIT) {
+        if (pass_mode == 4) {
+            hipLaunchKernelGGL((filter_x_kernel<T, DB, J, true, false, WPB, SPLIT, false, true>), grid, block, 0, stream,
+                               ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nslice, segs_per_slice, nll_part, ldo, link_flags, link_state, active);
+            hipError_t e4 = hipGetLastError();
+            if (e4 != hipSuccess) { set_last_error("filter_x_kernel launch: %s", hipGetErrorString(e4)); return 2; }
+            return 0;
+        }
+    }
     if (yhat && nll) MOIHGP_X_LAUNCH(true, true);
     else if (yhat) MOIHGP_X_LAUNCH(true, false);
     else if (nll) MOIHGP_X_LAUNCH(false, true);
@@ -1617,9 +1672,22 @@ int launch_xd(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, co
     if (L >= 1024) {
         // chunks with a gap per segment up to which the broken-link stages of the second pass beat the tick-by-tick walk (measured,
         // tools/filternan.py: a stage costs one scan + one replay, the second pass of the fp64 d = 12 kernel runs one wave per SIMD)
-        const int max_links = env_links >= 0 ? env_links : (DB * J <= kPairMaxDim ? 64 : ((sizeof(T) == 8 && DB * J > 9) ? 3 : 32));
+        // force_slices < -1 (gaps_x.hip: missing ticks by imputation around this sweep): -2 = the first pass alone, handing over EVERY latent that
+        // holds a gap; -3 = the second pass alone (what the imputation left flagged); -4 = the first pass over a compact bank of *link_flags latents
+        // (link_flags then points at that device-side count; its streams hold no gaps)
+        // (-5 = as -4, the sweep writing predicted observations HA x instead of filtered means; -6 = that sweep over the full bank)
+        // In the compact modes link_flags is the bank's control block, link_state the caller's flags (int*), scratch the gap counts per (slot, part)
+        // (int*), scratch_len the number of parts, env_links the fewest gaps a slot is swept for (filter_x_kernel).
+        const int pass_mode = force_slices == -2 ? 1 : force_slices == -3 ? 2 : force_slices == -4 ? 3 : (force_slices == -5 || force_slices == -6) ? 4 : 0;
+        if (pass_mode >= 3) {
+            const int* active = force_slices == -6 ? nullptr : link_flags;
+            return launch_x<T, DB, J, 4, false>(Ty, Tlen, ld, L, cbT, cb64, xin, x, yhat, nll, stream, ev0, ev1, (int)scratch_len, env_links, scratch, ldo,
+                                                nullptr, link_state, nullptr, pass_mode, active);
+        }
+        const int* active = nullptr;
+        const int max_links = pass_mode == 1 ? 64 : (env_links >= 0 ? env_links : (DB * J <= kPairMaxDim ? 64 : ((sizeof(T) == 8 && DB * J > 9) ? 3 : 32)));
         return launch_x<T, DB, J, 4, false>(Ty, Tlen, ld, L, cbT, cb64, xin, x, yhat, nll, stream, ev0, ev1, 1, max_links, nullptr, ldo,
-                                            (max_links > 0 && link_state) ? link_flags : nullptr, link_state, total);
+                                            (pass_mode < 3 && max_links > 0 && link_state) ? link_flags : nullptr, link_state, total, pass_mode, active);
     }
     const size_t nseg = (Tlen + SEG - 1) / SEG;
     // few latents, a stream of 2 .. kTeamWaves segments: one workgroup per latent, one wavefront per segment (filter_x_team_kernel), as long as

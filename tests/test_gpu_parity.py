@@ -4,6 +4,7 @@ BASELINE.json's full sizes.
 
 Tolerances (BASELINE.json north_star): 1e-6 relative for fp64, 1e-3 for fp32 on filtered means and NLL.
 The asserts below use tighter bars where the arithmetic allows, and say so."""
+import re
 import numpy as np
 import pytest
 import torch
@@ -980,6 +981,67 @@ def test_stacked_filter_gaps_as_broken_links(env, kern, dtype):
     torch.cuda.synchronize()
     assert rel_err_rows(torch.cat([ya[:, :cut], yb[:, :T - cut]], 1)[sub].cpu().numpy().astype(np.float64)[tame], o["yhat"][tame]) < tol * 10
     assert rel_err((na + nb)[sub].cpu().numpy()[tame], o["nll_per_latent"][tame]) < tol * 10
+
+
+@pytest.mark.parametrize("kern", ["Matern32x2", "Matern52x2", "Matern32x4", "Matern52x3", "Matern52x4"])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("nanf", [0.01, 0.05, 0.3])
+def test_stacked_gaps_by_imputation(env, kern, dtype, nanf, monkeypatch, capfd):
+    """Many latents, a stacked state: latents whose stream holds missing ticks are swept by EXACT IMPUTATION (csrc/gaps_x.hip; automatic from
+    d = 8 on, forced here for every d): a gap-free sweep with the gaps as zeros, the scalar triangular recursion w_p = HA x'_p + sum_q s_(p-q-1) w_q
+    over each latent's gaps, a second gap-free sweep with the gaps filled by their own predictions.  ihgp.h:83-87 / :204-209 semantics (x <- A x,
+    no likelihood term) against the oracle: dense random gaps (1 %, 5 %, 30 % of the ticks), gaps at both ends, runs of gaps, a series with no
+    observation at all and one with more gaps inside the filter's memory than the recursion's window holds (both left to the second pass),
+    gap-free latents in between, and the stream in two slabs that carry the state."""
+    J = int(kern[-1])
+    L, T = 1040, 4500
+    rng = np.random.default_rng(23 + J + int(100 * nanf))
+    prm = synth_params_stacked(L, J, rng)
+    bank = env["streams"].LatentBank(0.1, prm, kernel=kern)
+    bank.set_option("filter_impute", 1)
+    Ty = synth(L, T, rng)
+    Ty[rng.random((L, T)) < nanf] = np.nan
+    Ty[0:40] = synth(40, T, rng)                           # some latents without any gap
+    Ty[41, 0] = np.nan; Ty[42, T - 1] = np.nan; Ty[43, :5] = np.nan; Ty[44, T - 7:] = np.nan
+    Ty[45, 1000:1400] = np.nan                             # a long run
+    Ty[46, :] = np.nan                                     # nothing observed
+    Ty[47, ::2] = np.nan                                   # every other tick: more gaps inside the decay than the window holds
+    sub = np.concatenate([np.arange(36, 60), np.sort(rng.choice(np.arange(60, L), size=24, replace=False))])
+    o = env["cref"].filter_stream(env["cref"].ihgp_array(kern, 0.1, prm[sub]), np.ascontiguousarray(Ty[sub]), nthreads=8)
+    Tyd = to_dev(Ty, dtype)
+    monkeypatch.setenv("MOIHGP_GAP_TRACE", "1")
+    capfd.readouterr()
+    yhat, xT, nll = bank.filter(Tyd, T=T)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("MOIHGP_GAP_TRACE")
+    trace = re.search(r"gap imputation: (\d+) latents handed over, (\d+) solved, (\d+) gaps", capfd.readouterr().err)
+    assert trace, "the imputation path did not run"
+    handed, solved = int(trace.group(1)), int(trace.group(2))
+    assert handed >= ((L - 41) * 9) // 10 and solved >= (handed * 3) // 4, (handed, solved)             # (a filter without scan tables, or a slowly forgetting one, stays with the second pass)
+    tol = (FP64_TIGHT if dtype == torch.float64 else FP32_TOL) * 10
+    tame = np.nan_to_num(np.abs(o["yhat"]), nan=0.0).max(axis=1) < 1e6                 # literal-DARE unstable latents aside
+    assert tame.sum() > len(sub) // 2
+    yg = yhat[sub][:, :T].cpu().numpy().astype(np.float64)
+    assert rel_err_rows(yg[tame], o["yhat"][tame]) < tol
+    assert rel_err(xT[sub].cpu().numpy()[tame], o["x"][tame]) < tol
+    assert rel_err(nll[sub].cpu().numpy()[tame], o["nll_per_latent"][tame]) < tol and nll[46].item() == 0.0
+    # NLL-only and means-only sweeps, and the same stream in two slabs
+    _, x2, n2 = bank.filter(Tyd, T=T, want_yhat=False)
+    y3, x3, _ = bank.filter(Tyd, T=T, want_nll=False)
+    cut = 2048 + 32 * 5 + 8
+    ya, xa, na = bank.filter(Tyd[:, :cut].contiguous(), T=cut)
+    yb, xb, nb = bank.filter(Tyd[:, cut:].contiguous(), T=T - cut, x=xa.clone())
+    torch.cuda.synchronize()
+    assert rel_err(n2[sub].cpu().numpy()[tame], o["nll_per_latent"][tame]) < tol and rel_err(x3[sub].cpu().numpy()[tame], o["x"][tame]) < tol
+    assert rel_err_rows(y3[sub][:, :T].cpu().numpy().astype(np.float64)[tame], o["yhat"][tame]) < tol
+    assert rel_err_rows(torch.cat([ya[:, :cut], yb[:, :T - cut]], 1)[sub].cpu().numpy().astype(np.float64)[tame], o["yhat"][tame]) < tol
+    assert rel_err((na + nb)[sub].cpu().numpy()[tame], o["nll_per_latent"][tame]) < tol
+    # the second pass of recursion_x.hip on the same stream (imputation off): the two treatments of a gap agree
+    bank.set_option("filter_impute", 0)
+    y0, x0_, n0 = bank.filter(Tyd, T=T)
+    torch.cuda.synchronize()
+    assert rel_err_rows(y0[sub][:, :T].cpu().numpy().astype(np.float64)[tame], yg[tame]) < tol
+    assert rel_err(n0[sub].cpu().numpy()[tame], nll[sub].cpu().numpy()[tame]) < tol
 
 
 @pytest.mark.parametrize("kern,M,L", [("Matern32x2", 6, 3), ("Matern52x2", 8, 8), ("Matern52x4", 9, 4), ("Matern52x3", 150, 70)])

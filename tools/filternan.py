@@ -7,10 +7,13 @@ from bench import synth_params, synth_stream, SEED
 from multioutputihgp_amd.streams import LatentBank
 L, T = 4096, 10000
 dev = torch.device("cuda", 0)
+IMPUTE = os.environ.get("FILTERNAN_IMPUTE")           # -1 / 0 / 1: option "filter_impute" of the stacked models (unset: the library's default)
 for kern in (sys.argv[1:] or ["Matern52ss", "Matern52x2", "Matern52x4"]):
     bank = LatentBank(0.1, synth_params(L, 0, np.random.default_rng(SEED), kern), kernel=kern)
-    for dtype in (torch.float64, torch.float32):
-        for nan in (0.0, 0.0001, 0.01, 0.05):
+    if IMPUTE is not None and bank.stacked:
+        bank.set_option("filter_impute", int(IMPUTE))
+    for dtype in ((torch.float64, torch.float32) if "FILTERNAN_DTYPE" not in os.environ else (getattr(torch, os.environ["FILTERNAN_DTYPE"]),)):
+        for nan in ((0.0, 0.0001, 0.01, 0.05) if "FILTERNAN_FRACS" not in os.environ else [float(v) for v in os.environ["FILTERNAN_FRACS"].split(",")]):
             Ty = synth_stream(L, 0, T, dtype, dev, SEED + 1)
             if nan > 0:
                 Ty[torch.rand(Ty.shape, device=dev) < nan] = float("nan")
