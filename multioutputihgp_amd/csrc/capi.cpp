@@ -21,11 +21,6 @@
 namespace moihgp {
 
 static thread_local char g_last_error[512] = "";
-// option "filter_impute" left to itself: latents whose stream holds this many missing ticks or more are swept by imputation (gaps_x.hip).  One: the
-// second pass of recursion_x.hip costs a walk of one latent's stream however few latents take it (one wave per SIMD at d = 12), the imputation
-// costs per latent; measured (tools/filternan.py, 4096 x 10^4, d = 12 fp64) a threshold of 4 loses to both "always" and "never" between 10^-4
-// and 10^-3 missing, and "always" loses 15 % to "never" only below 2 gaps per latent
-constexpr int kGapAutoMin = 1;
 
 void set_last_error(const char* fmt, ...) {
     va_list ap;
@@ -88,8 +83,8 @@ struct moihgp_gp {
     bool win_has_nan = false;
     int polar_its = 0;         // Newton-Schulz steps of the last device polar factor (0: single-workgroup kernel / none yet)
     int polar_warm = 0;        // dpolar holds the outlying subspace of the previous polar factor (polar_deflate.hip warm start)
-    int opt_filter_impute = -1; // option "filter_impute": missing ticks of the stacked many-latent sweep by imputation (gaps_x.hip): 0 never, n >= 1: latents
-                                // whose stream holds n gaps or more, -1 = kGapAutoMin of them for d >= 8
+    int opt_filter_impute = -1; // option "filter_impute": missing ticks of the stacked many-latent sweep by imputation (filter_x_gaps_a / _b_kernel): -1 = for d >= 8,
+                                // 0 never, 1 always
     void* dgap = nullptr;       // its compact bank (gap_bank_bytes), on first use
     size_t gap_cap = 0;
     unsigned long long cb_version = 1;        // bumped whenever the constant blocks are rebuilt
@@ -755,19 +750,19 @@ static int filter_stream_io_impl(moihgp_gp* gp, int dtype, const void* Ty, size_
             gp->dlinkflags = dev_alloc<int>(gp->L);
             MOIHGP_HIP_FATAL(hipMemsetAsync(gp->dlinkflags, 0, gp->L * sizeof(int), (hipStream_t)stream));
         }
-        // many latents, a state too wide for per-chunk maps: latents whose stream holds missing ticks are swept by imputation (gaps_x.hip) between
-        // the first pass (which hands them over) and the second (which takes what the imputation could not)
+        // many latents, a state too wide for per-chunk maps: latents whose stream holds missing ticks are swept by imputation (recursion_x.hip:
+        // filter_x_gaps_a / _b_kernel) between the first pass, which hands them over, and the second, which takes what the imputation could not
         const bool impute = !plain_x && gp->L >= 1024 && T > 0 && gp->opt_filter_split == 0 && (yhat || nll) &&
-                            (gp->opt_filter_impute >= 1 || (gp->opt_filter_impute == -1 && gp->d >= 8));
+                            (gp->opt_filter_impute == 1 || (gp->opt_filter_impute == -1 && gp->d >= 8));
         if (impute) {
-            const size_t need = gap_bank_bytes(gp->d, dtype, gp->L, ld, T);
+            const size_t need = gap_bank_bytes(gp->d, dtype, gp->L, T);
             if (gp->gap_cap < need) {
                 if (gp->dgap) { MOIHGP_HIP_FATAL(hipDeviceSynchronize()); MOIHGP_HIP_FATAL(hipFree(gp->dgap)); gp->dgap = nullptr; gp->gap_cap = 0; }
                 void* p = nullptr;
                 MOIHGP_HIP_FATAL(hipMalloc(&p, need));
                 gp->dgap = p; gp->gap_cap = need; gp->gap_sig = 0;
             }
-            const GapBank bank = gap_bank_carve(gp->dgap, gp->d, dtype, gp->L, ld, T);
+            const GapBank bank = gap_bank_carve(gp->dgap, gp->d, dtype, gp->L, T);
             const unsigned long long sig = (unsigned long long)(dtype + 1);
             if (gp->gap_sig != sig) {                                    // a fresh bank, or another scalar type: unit impulses and the zero state again
                 if (int rc = gap_bank_init(bank, gp->d, dtype, gp->L, (hipStream_t)stream)) return rc;
@@ -777,13 +772,27 @@ static int filter_stream_io_impl(moihgp_gp* gp, int dtype, const void* Ty, size_
                 if (int rc = launch_gap_impulse(bank, kid, dtype, gp->L, xb64, xb32, (hipStream_t)stream)) return rc;
                 gp->gap_imp_version = gp->cb_version;
             }
-            const int min_gaps = gp->opt_filter_impute >= 1 ? gp->opt_filter_impute : kGapAutoMin;
             if (int rc = launch_filter_stream_x(kid, dtype, Ty, T, ld, gp->L, xb64, xb32, x_in, x, yhat, nll, (hipStream_t)stream, e0, e1, gp->dxscratch, slen, -2, ld_out,
                                                 gp->dlinkflags, gp->dlink, nullptr, gp->opt_filter_maxlinks, gp->opt_filter_team, gp->dtp64, gp->dtp32)) return rc;
-            if (int rc = launch_gap_imputation(bank, kid, dtype, Ty, T, ld, gp->L, xb64, xb32, x_in, x, yhat, nll, ld_out, gp->dlinkflags, min_gaps, (hipStream_t)stream)) return rc;
+            const GapArgs ga{bank.imp_out, bank.gpos, bank.gval, bank.gcap, bank.gstat};
+            const char* trace = getenv("MOIHGP_GAP_TRACE");               // diagnostics (the tests read it): synchronises the stream
+            const bool tracing = trace && trace[0] == '1';
+            if (tracing) MOIHGP_HIP_FATAL(hipMemsetAsync(bank.gstat, 0xFF, gp->L * sizeof(int), (hipStream_t)stream));
+            if (int rc = launch_filter_stream_x(kid, dtype, Ty, T, ld, gp->L, xb64, xb32, x_in, x, yhat, nll, (hipStream_t)stream, nullptr, nullptr,
+                                                reinterpret_cast<double*>(const_cast<GapArgs*>(&ga)), 0, -7, ld_out, gp->dlinkflags, gp->dlink, nullptr, -1, 0, nullptr, nullptr)) return rc;
+            // what the recursion could not take (a filter with a memory longer than its table): the second pass, as without imputation
             if (int rc = launch_filter_stream_x(kid, dtype, Ty, T, ld, gp->L, xb64, xb32, x_in, x, yhat, nll, (hipStream_t)stream, nullptr, nullptr, gp->dxscratch, slen, -3, ld_out,
                                                 gp->dlinkflags, gp->dlink, nullptr, gp->opt_filter_maxlinks, gp->opt_filter_team, gp->dtp64, gp->dtp32)) return rc;
             if (nll && nll_total) launch_nll_total(nll, gp->L, nll_total, (hipStream_t)stream);
+            if (tracing) {
+                std::vector<int> st(gp->L);
+                MOIHGP_HIP_FATAL(hipMemcpyAsync(st.data(), bank.gstat, gp->L * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+                MOIHGP_HIP_FATAL(hipStreamSynchronize((hipStream_t)stream));
+                long taken = 0, solved = 0, gaps = 0, why[5] = {0, 0, 0, 0, 0};
+                for (int v : st) if (v >= 0) { taken++; if (v & 1) { solved++; gaps += v >> 1; } else why[(v >> 1) < 5 ? (v >> 1) : 0]++; }
+                fprintf(stderr, "moihgp gap imputation: %ld latents handed over, %ld solved, %ld gaps filled (not solved: %ld table not finite, %ld response outlives the table, "
+                        "%ld ring overflow, %ld stream too long)\n", taken, solved, gaps, why[1], why[2], why[3], why[4]);
+            }
             return 0;
         }
         int rc = launch_filter_stream_x(kid, dtype, Ty, T, ld, gp->L, xb64, xb32, x_in, x, yhat, nll, (hipStream_t)stream, e0, e1,
@@ -1140,7 +1149,7 @@ int moihgp_set_option(moihgp_gp* gp, const char* name, long value) {
     if (!gp || !name) { set_last_error("set_option: null argument"); return 1; }
     const std::string n(name);
     if (n == "filter_split") { if (value < 0 || value > 64) { set_last_error("filter_split: 0 (automatic), 1 (off) or a slice count"); return 1; } gp->opt_filter_split = (int)value; return 0; }
-    if (n == "filter_impute") { if (value < -1 || value > 1000000) { set_last_error("filter_impute: -1 (automatic: state dimension >= 8), 0 (never), n >= 1 (stacked models: latents with n gaps or more)"); return 1; } gp->opt_filter_impute = (int)value; return 0; }
+    if (n == "filter_impute") { if (value < -1 || value > 1) { set_last_error("filter_impute: -1 (automatic: state dimension >= 8), 0 (never), 1 (always, stacked models)"); return 1; } gp->opt_filter_impute = (int)value; return 0; }
     if (n == "polar_warm_start") { if (value < 0 || value > 1) { set_last_error("polar_warm_start: 0 or 1"); return 1; } gp->opt_polar_warm = (int)value; gp->polar_warm = 0; return 0; }
     if (n == "filter_plain_x") { if (value < -1 || value > 1) { set_last_error("filter_plain_x: -1 (automatic), 0 (never), 1 (always: the stacked filter's kernels for Matern-3/2 and -5/2)"); return 1; } gp->opt_filter_plain_x = (int)value; return 0; }
     if (n == "filter_team") { if (value < -1 || value > 2) { set_last_error("filter_team: -1 (automatic), 0 (never), 1 (whenever the stream fits), 2 (the 32-tick-chunk form only)"); return 1; } gp->opt_filter_team = (int)value; return 0; }

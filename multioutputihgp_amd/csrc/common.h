@@ -161,20 +161,26 @@ int launch_gp_table_x(int kernel, const double* cb64, const double* cbd64, doubl
 int launch_grad_scan_x(int kernel, int dtype, const void* Ty, size_t Tpar, size_t ld, size_t L, const double* cb64, const double* cbd64,
                        void* x, void* dx, void* yhat, double* nll, double* grad, int* flags, double* hp, hipStream_t stream, int out_mode, int hp_build = 1);
 
-// gaps_x.hip: missing ticks of the stacked models' many-latent sweep by exact imputation (two gap-free sweeps of the latents that hold gaps
-// around a scalar recursion over their gaps).  GapBank: the compact bank those sweeps run on, carved out of one allocation of gap_bank_bytes().
-struct GapBank {
-    int* ctl = nullptr;                                         // [0] slots in use, [16 + c] slot c is live, [16 + L + c] the latent slot c holds
-    void* imp_in = nullptr; void* imp_out = nullptr;            // [L][1024]: unit impulses (constant: gap_bank_init) and the filters' responses to them
-    void* xz = nullptr;                                         // zeros [L][d]: the start state of the impulse sweep
-    void* stream_in = nullptr; void* stream_out = nullptr;      // [L][ld] of the stream's scalar type
-    void* x1 = nullptr;                                         // end states of the PRED sweeps [L][d] (unused)
-    int* glist = nullptr; int* cntp = nullptr;                  // the gaps' ticks per (slot, part of 2048 ticks), in order, and their number
+// Missing ticks of the stacked models' many-latent sweep by exact imputation (recursion_x.hip: filter_x_gaps_a / _b_kernel -- two gap-free sweeps of
+// a latent that holds gaps around a scalar recursion over its gaps).  gaps_x.hip: the scratch it works in and the filters' impulse
+// responses it needs.
+constexpr int kGapSMax = 1024;        // impulse-response table per latent (ticks); beyond it the response must be negligible
+struct GapArgs {                      // what launch_filter_stream_x(force_slices = -7) finds behind its `scratch` argument (host memory)
+    const void* imp;                  // [L][kGapSMax] impulse responses, the stream's scalar type
+    int* gpos; void* gval;            // [L][gcap] the gaps' ticks / their predictions, then fill values
+    size_t gcap;
+    int* gstat;                       // [L] per latent swept by imputation: 2 * gaps + 1 if solved, else 2 * the reason why not
 };
-size_t gap_bank_bytes(int d, int dtype, size_t L, size_t ld, size_t T);
-GapBank gap_bank_carve(void* base, int d, int dtype, size_t L, size_t ld, size_t T);
-int launch_gap_imputation(const GapBank& b, int kernel, int dtype, const void* Ty, size_t T, size_t ld, size_t L, const double* cb64, const float* cb32, const void* xin, void* x,
-                          void* yhat, double* nll, size_t ldo, int* flags, int min_gaps, hipStream_t s);
+struct GapBank {
+    void* imp_in = nullptr; void* imp_out = nullptr;            // [L][kGapSMax]: unit impulses (constant: gap_bank_init) and the filters' responses to them
+    void* xz = nullptr;                                         // zeros [L][d]: the start state of the impulse sweep
+    void* x1 = nullptr;                                         // its end states [L][d] (unused)
+    int* gpos = nullptr; void* gval = nullptr;                  // [L][gcap]
+    size_t gcap = 0;
+    int* gstat = nullptr;                                       // [L]
+};
+size_t gap_bank_bytes(int d, int dtype, size_t L, size_t T);
+GapBank gap_bank_carve(void* base, int d, int dtype, size_t L, size_t T);
 int gap_bank_init(const GapBank& b, int d, int dtype, size_t L, hipStream_t s);
 int launch_gap_impulse(const GapBank& b, int kernel, int dtype, size_t L, const double* cb64, const float* cb32, hipStream_t s);
 // recursion.hip: the same sweep over segment-major streams [ceil(T / SEG)][L][SEG], SEG = 4096 / sizeof(scalar) ticks (d = 2, 3)

@@ -381,13 +381,28 @@ constexpr int x_min_waves() {
 // The sweep of ONE wavefront over (a slice of) one latent's stream: the body of filter_x_kernel, and the fallback of the team kernel
 // below (one latent per workgroup), which hands a latent it cannot take to this code.  `tile` is the wave's padded LDS tile
 // (64 x (kChunkX + 16 bytes)), `carry` its D-entry carry-out slot.
-template <typename T, int DB, int J, bool WRITE, bool NLL, bool SPLIT, bool LINKS, bool PRED = false>
+// Missing ticks by exact imputation (the fused kernel below; the method is described there).  GAPS: 0 = none of it;
+//   1 = first sweep: resumes at the pass-1 hand-over, the gaps swept as zeros, the tile receives the PREDICTED observations HA x, of which those
+//       at the gaps are listed (tick, HA x') in gio->pos / gio->val, in tick order; nothing else is written (no means, no end state);
+//   2 = second sweep: resumes likewise, the gaps filled from gio->val (in the same order), and everything is written as usual;
+//   3 = the sweep writes predicted observations instead of filtered means (the filters' impulse responses).
+template <typename T>
+struct GapIO {
+    int* pos; T* val;            // this latent's lists
+    int* lds;                    // 128 ints of the wave's own LDS
+    const double* resume;        // the latent's hand-over record (kLinkState doubles)
+    int count;                   // gaps listed (out, GAPS = 1)
+    bool patch;                  // GAPS = 2: the lists hold the fill values
+};
+template <typename T, int DB, int J, bool WRITE, bool NLL, bool SPLIT, bool LINKS, int GAPS = 0>
 __device__ __forceinline__ void filter_x_body(const T* __restrict__ Ty, size_t Tlen, size_t ld, const T* __restrict__ cbT, const double* __restrict__ cb64,
                 const T* xin0 /* start state */, T* x /* end state; may be the same buffer */, T* __restrict__ yhat, double* __restrict__ nll,
                 int nslice, int segs_per_slice, double* __restrict__ nll_part, size_t ldo /* row stride of yhat */,
                 int* __restrict__ link_flags /* [L] or NULL */, double* __restrict__ link_state /* [L][kLinkState] */,
-                const size_t l, const int slice, const int lane, T* __restrict__ tile, T* __restrict__ carry) {
+                const size_t l, const int slice, const int lane, T* __restrict__ tile, T* __restrict__ carry, GapIO<T>* gio = nullptr) {
     constexpr int D = DB * J;
+    constexpr bool PRED = GAPS == 1 || GAPS == 3;
+    static_assert(GAPS == 0 || (!SPLIT && !LINKS), "the imputation sweeps are whole-stream, first-pass sweeps");
     using V = typename VecOf<T>::type;
     using Lay = XC<D>;
     constexpr int CK = kChunkX, EPV = 16 / sizeof(T), STRIDE = CK + EPV, SEG = 64 * CK;
@@ -410,6 +425,14 @@ __device__ __forceinline__ void filter_x_body(const T* __restrict__ Ty, size_t T
         t_resume = (size_t)st[D];
         if (NLL) { acc = st[16 + lane]; nobs = (unsigned)st[80 + lane]; }          // (per-lane partial sums, added up at the end)
     }
+    int gbase = 0;                                                   // gaps listed so far (scalar)
+    if constexpr (GAPS == 1 || GAPS == 2) {                          // resume where the first pass stopped this latent (its flag is the caller's business)
+        const double* st = gio->resume;
+#pragma unroll
+        for (int i = 0; i < D; i++) xc[i] = (T)st[i];
+        t_resume = (size_t)st[D];
+        if (NLL) { acc = st[16 + lane]; nobs = (unsigned)st[80 + lane]; }
+    }
     const bool scan_ok = __builtin_amdgcn_readfirstlane((int)(c[Lay::SCANOK] != T(0))) != 0;
     // The scan powers and the response table are streamed in at the start of every segment (L2-resident, coalesced, issued ahead
     // of the phases that use them) rather than held for the whole sweep: that leaves registers to fetch the NEXT segment of the
@@ -422,7 +445,7 @@ __device__ __forceinline__ void filter_x_body(const T* __restrict__ Ty, size_t T
     T ha = c[Lay::HA16 + (lane & 15)], kk = c[Lay::K16 + (lane & 15)];
     const int nlev = __builtin_amdgcn_readfirstlane((int)c[Lay::NLEV]);
     // the ticks this wave sweeps: [t_start, t_end), of which [t_begin, t_end) count (everything, unless SPLIT)
-    size_t t_begin = 0, t_end = Tlen, t_start = LINKS ? t_resume : 0;
+    size_t t_begin = 0, t_end = Tlen, t_start = (LINKS || GAPS == 1 || GAPS == 2) ? t_resume : 0;
     bool last = true;
     if (SPLIT) {
         const bool split_ok = scan_ok && nlev <= 5;                  // M^(2^nlev) is in the table and negligible
@@ -467,6 +490,55 @@ __device__ __forceinline__ void filter_x_body(const T* __restrict__ Ty, size_t T
     for (size_t t0 = t_start; t0 < t_end; t0 += SEG) {
         const int n = (int)(t_end - t0 < (size_t)SEG ? t_end - t0 : (size_t)SEG);
         const int head = SPLIT && t_begin > t0 ? (int)(t_begin - t0) : 0;      // warm-up ticks at the front of this segment
+        // The imputation sweeps stage the tile FIRST and deal with the gaps there, before the tables below fill the registers (at that point the
+        // d = 12 fp64 sweep sits at 256 registers exactly; the gap bookkeeping on top of it cost 50 more and a wave per SIMD).
+        int seg_gaps = 0;
+        if constexpr (GAPS == 1 || GAPS == 2) {
+#pragma unroll
+            for (int r = 0; r < CK / EPV; r++) {
+                const int e = (r * 64 + lane) * EPV;
+                T vals[EPV];
+                if (r < NPF) unpack<T>(pre[r < NPF ? r : 0], vals);
+                else if (e < n) unpack<T>(nt_load(reinterpret_cast<const V*>(row + t0 + e)), vals);
+#pragma unroll
+                for (int q = 0; q < EPV; q++) if (e + q >= n) vals[q] = T(0);        // beyond the stream: inert zeros
+                *reinterpret_cast<V*>(tile + (e / CK) * STRIDE + (e % CK)) = pack<T>(vals);
+            }
+            wave_lds_fence();
+            if (GAPS == 1 || gio->patch) {
+                // this lane's chunk: which of its ticks are missing; their places in the latent's lists (tick order = lane order, then k)
+                unsigned mask = 0;
+#pragma unroll
+                for (int kv = 0; kv < CK / EPV; kv++) {
+                    T yv[EPV];
+                    unpack<T>(*reinterpret_cast<const V*>(tile_lane + kv * EPV), yv);
+#pragma unroll
+                    for (int q = 0; q < EPV; q++) mask |= (yv[q] != yv[q]) ? (1u << (kv * EPV + q)) : 0u;
+                }
+                const int cnt = __builtin_popcount(mask);
+                int inc = cnt;                                       // inclusive scan over the lanes, in DPP
+                inc += __builtin_amdgcn_update_dpp(0, inc, DPP_ROW_SHR + 1, 0xF, 0xF, false);
+                inc += __builtin_amdgcn_update_dpp(0, inc, DPP_ROW_SHR + 2, 0xF, 0xF, false);
+                inc += __builtin_amdgcn_update_dpp(0, inc, DPP_ROW_SHR + 4, 0xF, 0xF, false);
+                inc += __builtin_amdgcn_update_dpp(0, inc, DPP_ROW_SHR + 8, 0xF, 0xF, false);
+                inc += __builtin_amdgcn_update_dpp(0, inc, DPP_ROW_BCAST15, 0xA, 0xF, false);
+                inc += __builtin_amdgcn_update_dpp(0, inc, 0x143 /* row_bcast:31 */, 0xC, 0xF, false);
+                seg_gaps = __builtin_amdgcn_readlane(inc, 63);
+                if (seg_gaps) {
+                    const int at = gbase + inc - cnt;
+                    if (GAPS == 1) { gio->lds[lane] = (int)mask; gio->lds[64 + lane] = at; }
+                    int j = 0;
+                    for (unsigned mm = mask; mm; mm &= mm - 1) {
+                        const int k = __builtin_ctz(mm);
+                        tile_lane[k] = GAPS == 1 ? T(0) : gio->val[at + j];
+                        j++;
+                    }
+                    wave_lds_fence();
+                }
+                if (GAPS == 2) gbase += seg_gaps;
+            }
+            __builtin_amdgcn_sched_barrier(0);                       // (none of the loads below before this is done)
+        }
         // ---- issue this segment's table traffic first: the response slabs (used once per segment, so streamed rather than
         // kept) and the diagonal blocks of A for the replay (scalar loads; the SGPRs are idle until then) ----
         const uptr<T> cu = launder(c);
@@ -480,15 +552,17 @@ __device__ __forceinline__ void filter_x_body(const T* __restrict__ Ty, size_t T
         ReplayConst<T, DB, J> rc;
         load_replay_const<T, DB, J>(cu, c, lane, rc);
         // ---- stage in: coalesced 16-byte loads, chunk-major into the padded tile ----
+        if constexpr (GAPS != 1 && GAPS != 2) {
 #pragma unroll
-        for (int r = 0; r < CK / EPV; r++) {
-            const int e = (r * 64 + lane) * EPV;
-            T vals[EPV];
-            if (r < NPF) unpack<T>(pre[r < NPF ? r : 0], vals);
-            else if (e < n) unpack<T>(nt_load(reinterpret_cast<const V*>(row + t0 + e)), vals);
+            for (int r = 0; r < CK / EPV; r++) {
+                const int e = (r * 64 + lane) * EPV;
+                T vals[EPV];
+                if (r < NPF) unpack<T>(pre[r < NPF ? r : 0], vals);
+                else if (e < n) unpack<T>(nt_load(reinterpret_cast<const V*>(row + t0 + e)), vals);
 #pragma unroll
-            for (int q = 0; q < EPV; q++) if (e + q >= n) vals[q] = T(0);        // beyond the stream: inert zeros
-            *reinterpret_cast<V*>(tile + (e / CK) * STRIDE + (e % CK)) = pack<T>(vals);
+                for (int q = 0; q < EPV; q++) if (e + q >= n) vals[q] = T(0);        // beyond the stream: inert zeros
+                *reinterpret_cast<V*>(tile + (e / CK) * STRIDE + (e % CK)) = pack<T>(vals);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);                           // (the prefetch registers are free from here on)
 #pragma unroll
@@ -785,8 +859,22 @@ __device__ __forceinline__ void filter_x_body(const T* __restrict__ Ty, size_t T
             } else
             replay<T, DB, J, WRITE, NLL, false, kChunkX, PRED>(rc, tile_lane, carry, lane, n, head, xs, xc, acc, nobs);
         }
+        if constexpr (GAPS == 1) {                                   // the predictions at the gaps, listed; nothing else leaves the tile
+            if (seg_gaps) {
+                wave_lds_fence();
+                const int at = gio->lds[64 + lane];
+                int j = 0;
+                for (unsigned mm = (unsigned)gio->lds[lane]; mm; mm &= mm - 1) {
+                    const int k = __builtin_ctz(mm);
+                    gio->pos[at + j] = (int)(t0 + (size_t)lane * CK + k);
+                    gio->val[at + j] = tile_lane[k];
+                    j++;
+                }
+                gbase += seg_gaps;
+            }
+        }
         // ---- stage out ----
-        if (WRITE) {
+        if (WRITE && GAPS != 1) {
             wave_lds_fence();
             int lo = lane;
             asm volatile("" : "+v"(lo));
@@ -801,7 +889,8 @@ __device__ __forceinline__ void filter_x_body(const T* __restrict__ Ty, size_t T
         }
         wave_lds_fence();
     }
-    if (lane == 0 && last) {
+    if constexpr (GAPS == 1) gio->count = gbase;
+    if (lane == 0 && last && GAPS != 1) {
 #pragma unroll
         for (int i = 0; i < D; i++) x[l * D + i] = xc[i];
     }
@@ -816,17 +905,11 @@ __device__ __forceinline__ void filter_x_body(const T* __restrict__ Ty, size_t T
     }
 }
 
-template <typename T, int DB, int J, bool WRITE, bool NLL, int WPB, bool SPLIT, bool LINKS, bool PRED = false>
+template <typename T, int DB, int J, bool WRITE, bool NLL, int WPB, bool SPLIT, bool LINKS, bool PREDOUT = false>
 __global__ void __launch_bounds__(64 * WPB, (x_min_waves<T, DB * J, SPLIT, LINKS>()))
 filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, const T* __restrict__ cbT, const double* __restrict__ cb64,
                 const T* xin0, T* x, T* __restrict__ yhat, double* __restrict__ nll, int nslice, int segs_per_slice, double* __restrict__ nll_part, size_t ldo,
-                int* __restrict__ link_flags, double* __restrict__ link_state,
-                const int* __restrict__ active /* or NULL.  gaps_x.hip's compact banks: active[0] slots are in use; the stream of slot c is row c of Ty, its
-                                                  constants and start state those of latent m = active[16 + L + c] of the full arrays.  There nslice is the
-                                                  number of parts of the stream, nll_part the (int) gap counts per (slot, part), segs_per_slice the fewest gaps
-                                                  a slot is swept for.  With PRED its outputs (x, yhat) go to row c; without -- only if active[16 + c] != 0 --
-                                                  to row m of the caller's arrays (x, yhat, nll), the NLL without the gaps' terms, and flag m of
-                                                  (int*)link_state is cleared */) {
+                int* __restrict__ link_flags, double* __restrict__ link_state) {
     constexpr int D = DB * J, STRIDE = kChunkX + 16 / (int)sizeof(T);
     __shared__ __attribute__((aligned(16))) T tiles[WPB][64 * STRIDE];
     __shared__ T carries[WPB][D];                                    // carry-out of a segment (written by the lane that holds its last tick)
@@ -835,41 +918,171 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
     const size_t l = SPLIT ? (size_t)blockIdx.x : (size_t)blockIdx.x * WPB + wave;   // SPLIT: grid = (latents, slices)
     const int slice = SPLIT ? (int)blockIdx.y : 0;
     if (l >= L) return;                                              // no workgroup barrier below
-    int gaps = 0;                                                    // (scalar registers, all of it)
-    size_t m = l;
-    int* flags_out = nullptr;
-    if constexpr (!SPLIT && !LINKS) {
-        if (active) {
-            if (l >= (size_t)active[0]) return;
-            const int* cntp = reinterpret_cast<const int*>(nll_part) + l * (size_t)nslice;
-            for (int p0 = 0; p0 < nslice; p0 += 64) gaps += p0 + lane < nslice ? cntp[p0 + lane] : 0;
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) gaps += __shfl_xor(gaps, o, 64);
-            gaps = __builtin_amdgcn_readfirstlane(gaps);
-            if (gaps < segs_per_slice) return;
-            if (!PRED && active[16 + l] == 0) return;                // the scalar recursion gave this one up
-            m = (size_t)active[16 + L + l];
-            const ptrdiff_t shift = (ptrdiff_t)m - (ptrdiff_t)l;
-            cbT += shift * XC<D>::SIZE;
-            cb64 += shift * XC<D>::SIZE;
-            xin0 += shift * D;
-            if (!PRED) {                                             // outputs straight into the caller's arrays
-                x += shift * D;
-                if (yhat) yhat += shift * (ptrdiff_t)ldo;
-                if (nll) nll += shift;
-                flags_out = reinterpret_cast<int*>(link_state);
-            }
-            nslice = 1; segs_per_slice = 0; nll_part = nullptr; link_state = nullptr;
-        }
+    filter_x_body<T, DB, J, WRITE, NLL, SPLIT, LINKS, PREDOUT ? 3 : 0>(Ty, Tlen, ld, cbT, cb64, xin0, x, yhat, nll, nslice, segs_per_slice, nll_part, ldo, link_flags,
+                                                                     link_state, l, slice, lane, tiles[wave], carries[wave]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// MISSING TICKS BY EXACT IMPUTATION (round 4): the latents the first pass handed over (a state too wide for per-chunk maps: d >= 8 by default).
+// Reference semantics: ihgp.h:83-87 -- a NaN observation advances the state by x <- A x (no correction), i.e. the innovation form
+// x' = A x + K v with v = 0 -- and ihgp.h:204-209 adds no likelihood term for it.
+//
+// Why.  The sweep above solves a segment of 64 x 32 ticks in parallel because every chunk moves the state by the same matrix AKHA^32.  A chunk
+// with a gap moves it by a matrix of its own; up to d = 6 that matrix fits a lane and the chunks' maps are scanned, beyond it does not, and the
+// second pass treats gaps as broken links of the scan (one scan + one replay per chunk with a gap) or walks the segment tick by tick: 12-16 x the
+// gap-free sweep once most chunks hold a gap (1 % of the ticks missing: 3.8 ms against 0.31 ms at d = 12, open since round 2).
+//
+// What.  A missing tick is an observation that happens to equal its own prediction: with y_p := w_p = HA x_p (the predicted observation at the
+// gap) the ordinary recursion gives v_p = 0 and x_(p+1) = A x_p -- the reference's branch.  The w_p are not known in advance, but they obey a
+// SCALAR triangular system.  Sweep the stream with the gaps set to zero (state x'); then e = x - x' moves by AKHA between gaps and is kicked
+// by K w_p at each gap, so
+//         w_p = HA x'_p + sum over gaps q < p of  s_(p-q-1) w_q,        s_k = HA AKHA^k K   (the filter's scalar impulse response),
+// where HA x'_p is what the first sweep leaves in its tile in place of the filtered mean (y - v: exactly HA x' where y' = 0; the filtered mean
+// xnew(0, 0) would not do -- for the stacked models H sums over the blocks), and the sum runs over the few gaps inside the decay of s.  Filling the
+// gaps with w_p and sweeping ONCE MORE gives the true filtered means, states and sum of v^2 (the gaps contribute v = 0 to it); only the count
+// of observed ticks needs correcting: nll -= n_gaps log(S) / 2.
+//   Two gap-free sweeps + a scalar recursion over the gaps, whatever their density -- and all of it per latent: one wavefront takes a flagged
+// latent through the first sweep and the recursion (filter_x_gaps_a_kernel: the lists of gaps live in the latent's scratch row, the recursion's
+// table in the wave's tile), one through the second sweep (filter_x_gaps_b_kernel); a bank without gaps leaves both at once.  (One kernel for
+// all three stages was tried: two inlined sweeps in one kernel cost 315 registers at d = 12 fp64 -- one wave per SIMD -- and ran 1.4 x slower.)  The impulse responses come from the same sweep run over a unit observation (gaps_x.hip, once per parameter
+// update).  A latent the recursion cannot take -- a response that has not decayed within kGapSMax ticks, more gaps inside its decay than the
+// window holds -- keeps its flag and takes the second pass (LINKS) as before.
+constexpr int kGapRing = 256;         // gaps inside the decay window the recursion keeps (LDS)
+
+// The scalar recursion over one latent's n gaps (ticks pos[], predictions val[], both in tick order): on success val[g] = w_g.  imp: the filter's
+// response to a unit observation at tick 0 from a zero state, as the GAPS = 3 sweep writes it: imp[k + 1] = s_k.  lds: the wave's tile.
+// 64 gaps at a time, one per lane, by forward substitution in column order: the finished w of the earlier gaps -- the last kGapRing of the blocks
+// before (newest first, until one lies outside the decay), then lane by lane inside the block -- are broadcast, and every later lane adds
+// s_(p-q-1) w_q to its own sum.  No reduction across lanes; about a dozen instructions per gap and broadcast.
+template <typename T>
+__device__ __forceinline__ int gap_solve_wave(const T* __restrict__ imp, const int* pos, T* val, const int n, const size_t Tlen, const int lane, unsigned char* lds) {
+    T* st = reinterpret_cast<T*>(lds);
+    int* ringp = reinterpret_cast<int*>(lds + kGapSMax * sizeof(T));
+    double* ringw = reinterpret_cast<double*>(lds + kGapSMax * sizeof(T) + kGapRing * sizeof(int));
+    constexpr int kZero = kGapSMax - 1;                                // (the table's last entry is zero)
+    double smax = 0.0;
+    bool bad = false;
+#pragma unroll 4
+    for (int k = lane; k < kGapSMax; k += 64) {
+        const T sv = k + 1 < kGapSMax ? imp[k + 1] : T(0);
+        st[k] = sv;
+        bad |= !(fabs((double)sv) < 1e300);
+        smax = fmax(smax, fabs((double)sv));
     }
-    filter_x_body<T, DB, J, WRITE, NLL, SPLIT, LINKS, PRED>(Ty, Tlen, ld, cbT, cb64, xin0, x, yhat, nll, nslice, segs_per_slice, nll_part, ldo, link_flags, link_state,
-                                                      l, slice, lane, tiles[wave], carries[wave]);
-    if constexpr (!SPLIT && !LINKS && !PRED) {
-        if (flags_out && lane == 0) {
-            // the gaps were swept as observations that equal their predictions: v = 0, but counted (ihgp.h:204-209 does not); nothing observed: exactly 0
-            if (NLL) nll[l] = (size_t)gaps == Tlen ? 0.0 : nll[l] - 0.5 * (double)gaps * cb64[l * XC<D>::SIZE + XC<D>::LOGS];
-            flags_out[m] = 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) smax = fmax(smax, __shfl_xor(smax, o));
+    const double tol = sizeof(T) == 8 ? 1e-17 : 1e-9;                  // (the sweep itself drops scan levels below 1e-20 / 1e-10)
+    int kd = 0;                                                        // one past the last k whose |s_k| still matters
+    for (int k = lane; k < kGapSMax; k += 64)
+        if (fabs((double)st[k]) > tol * smax) kd = k + 1;              // (each lane reads back what it wrote)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) kd = max(kd, __shfl_xor(kd, o));
+    const int kdec = __builtin_amdgcn_readfirstlane(kd);
+    // (the return value: 0 = solved, otherwise why not -- 1: a table that is not finite, 2: a response that outlives the table, 3: more gaps inside
+    // the decay than the ring holds, 4: a stream too long for 32-bit ticks)
+    int why = __builtin_amdgcn_ballot_w64(bad) != 0 ? 1 : kdec > kGapSMax - 64 ? 2 : Tlen >= (1u << 30) ? 4 : 0;
+    wave_lds_fence();
+    int nring = 0;                                                     // gaps solved so far; gap g sits in ring slot g % kGapRing
+    int posN = lane < n ? pos[lane] : 0;
+    T hvN = lane < n ? val[lane] : T(0);
+    for (int g0 = 0; g0 < n && why == 0; g0 += 64) {
+        const int p = posN;
+        double w = (double)hvN;
+        if (g0 + 64 < n) {                                             // the next 64, in flight during these
+            posN = g0 + 64 + lane < n ? pos[g0 + 64 + lane] : 0;
+            hvN = g0 + 64 + lane < n ? val[g0 + 64 + lane] : T(0);
         }
+        const int m = n - g0 < 64 ? n - g0 : 64;
+        const int pfirst = __builtin_amdgcn_readlane(p, 0);
+        if (nring >= kGapRing) {                                       // the ring is full: the gap it dropped last must be outside the decay
+            const int dropped = __builtin_amdgcn_readfirstlane(ringp[nring & (kGapRing - 1)]);
+            if (pfirst - dropped - 1 < kdec) { why = 3; break; }
+        }
+        const int nh = nring < kGapRing ? nring : kGapRing;
+        for (int h = 1; h <= nh; h++) {                                // the blocks before, newest gap first
+            const int slot = (nring - h) & (kGapRing - 1);
+            const int pq = __builtin_amdgcn_readfirstlane(ringp[slot]);
+            if (pfirst - pq - 1 >= kdec) break;
+            const double wq = ringw[slot];
+            const int k = p - pq - 1;                                  // (idle lanes: negative)
+            w = fma((double)st[(unsigned)k < (unsigned)kdec ? k : kZero], wq, w);
+        }
+#pragma unroll 4
+        for (int q = 0; q + 1 < m; q++) {                              // inside the block: lane q is final when its turn comes
+            const double wq = read_lane(w, q);
+            const int k = p - __builtin_amdgcn_readlane(p, q) - 1;     // (lanes up to q, idle lanes: negative)
+            w = fma((double)st[(unsigned)k < (unsigned)kdec ? k : kZero], wq, w);
+        }
+        if (lane < m) {
+            const int slot = (nring + lane) & (kGapRing - 1);
+            ringp[slot] = p;
+            ringw[slot] = w;
+            val[g0 + lane] = (T)w;
+        }
+        nring += m;
+        wave_lds_fence();
+    }
+    return why;
+}
+
+// Register caps of the two kernels below: what the plain sweep of the same model happens to fit (fp64: 256 = two waves per SIMD; fp32: three at
+// d = 12, four below) -- the gap bookkeeping costs 4 .. 16 registers more, and a few spilled values are cheaper than the wave they would cost.
+template <typename T, int D>
+constexpr int x_gaps_min_waves() { return sizeof(T) == 8 ? 2 : (D <= 9 ? 4 : 3); }
+
+// first sweep + recursion: the latents the first pass flagged (the flag stays: filter_x_gaps_b_kernel clears it)
+template <typename T, int DB, int J, int WPB>
+__global__ void __launch_bounds__(64 * WPB, (x_gaps_min_waves<T, DB * J>()))
+filter_x_gaps_a_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, const T* __restrict__ cbT, const double* __restrict__ cb64, const T* xin0,
+                       const int* __restrict__ flags, const double* __restrict__ link_state /* the first pass's hand-over records */,
+                       const T* __restrict__ imp /* [L][kGapSMax] impulse responses */, int* gpos, T* gval /* [L][gcap] scratch: the gaps' ticks and values */, size_t gcap,
+                       int* __restrict__ gstat /* [L] out: 2 * gaps + 1 if solved, else 2 * the reason why not */) {
+    constexpr int D = DB * J, STRIDE = kChunkX + 16 / (int)sizeof(T);
+    static_assert(sizeof(T) * 64 * STRIDE >= sizeof(T) * kGapSMax + (sizeof(int) + sizeof(double)) * kGapRing, "the recursion's table and ring borrow the wave's tile");
+    __shared__ __attribute__((aligned(16))) T tiles[WPB][64 * STRIDE];
+    __shared__ T carries[WPB][D];
+    __shared__ int glds[WPB][128];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t l = (size_t)blockIdx.x * WPB + wave;
+    if (l >= L || flags[l] == 0) return;                             // no workgroup barrier below
+    GapIO<T> gio;
+    gio.pos = gpos + l * gcap; gio.val = gval + l * gcap; gio.lds = glds[wave]; gio.resume = link_state + l * kLinkState; gio.count = 0; gio.patch = false;
+    filter_x_body<T, DB, J, true, false, false, false, 1>(Ty, Tlen, ld, cbT, cb64, xin0, nullptr, nullptr, nullptr, 1, 0, nullptr, 0, nullptr, nullptr,
+                                                          l, 0, lane, tiles[wave], carries[wave], &gio);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");               // the lists: written above, read below, by this wave
+    wave_lds_fence();
+    const int n_gaps = __builtin_amdgcn_readfirstlane(gio.count);
+    const int why = gap_solve_wave<T>(imp + l * kGapSMax, gio.pos, gio.val, n_gaps, Tlen, lane, reinterpret_cast<unsigned char*>(tiles[wave]));
+    if (lane == 0) gstat[l] = why == 0 ? 2 * n_gaps + 1 : 2 * why;
+}
+
+// second sweep: the gaps filled with their own predictions (a latent the recursion gave up keeps its flag: the second pass takes it)
+template <typename T, int DB, int J, bool WRITE, bool NLL, int WPB>
+__global__ void __launch_bounds__(64 * WPB, (x_gaps_min_waves<T, DB * J>()))
+filter_x_gaps_b_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, const T* __restrict__ cbT, const double* __restrict__ cb64,
+                       const T* xin0, T* x, T* __restrict__ yhat, double* __restrict__ nll, size_t ldo,
+                       int* __restrict__ flags /* cleared here */, const double* __restrict__ link_state,
+                       const int* __restrict__ gpos, const T* __restrict__ gval, size_t gcap, const int* __restrict__ gstat) {
+    constexpr int D = DB * J, STRIDE = kChunkX + 16 / (int)sizeof(T);
+    __shared__ __attribute__((aligned(16))) T tiles[WPB][64 * STRIDE];
+    __shared__ T carries[WPB][D];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t l = (size_t)blockIdx.x * WPB + wave;
+    if (l >= L || flags[l] == 0) return;                             // no workgroup barrier below
+    const int stat = gstat[l];
+    if (!(stat & 1)) return;
+    GapIO<T> gio;
+    gio.pos = const_cast<int*>(gpos) + l * gcap; gio.val = const_cast<T*>(gval) + l * gcap; gio.lds = nullptr; gio.resume = link_state + l * kLinkState;
+    gio.count = 0; gio.patch = true;
+    filter_x_body<T, DB, J, WRITE, NLL, false, false, 2>(Ty, Tlen, ld, cbT, cb64, xin0, x, yhat, nll, 1, 0, nullptr, ldo, nullptr, nullptr,
+                                                         l, 0, lane, tiles[wave], carries[wave], &gio);
+    if (lane == 0) {
+        // the gaps were swept as observations that equal their predictions: v = 0, but counted (ihgp.h:204-209 does not).  Nothing observed: exactly 0
+        const int n_gaps = stat >> 1;
+        if (NLL) nll[l] = (size_t)n_gaps == Tlen ? 0.0 : nll[l] - 0.5 * (double)n_gaps * cb64[l * XC<D>::SIZE + XC<D>::LOGS];
+        flags[l] = 0;
     }
 }
 
@@ -1526,9 +1739,10 @@ template <typename T, int DB, int J, int WPB, bool SPLIT>
 int launch_x(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, const double* cb64, const void* xin, void* x, void* yhat, double* nll,
              hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, int nslice, int segs_per_slice, double* nll_part, size_t ldo,
              int* link_flags = nullptr, double* link_state = nullptr, double* total = nullptr,
-             int pass_mode = 0 /* 0: first pass + second (LINKS) pass; 1: the first only; 2: the second only; 3: the first only, over a compact bank;
-                                    4: as 3, writing predicted observations HA x instead of filtered means (no NLL) */,
-             const int* active = nullptr) {
+             int pass_mode = 0 /* 0: first pass + second (LINKS) pass; 1: the first only; 2: the second only;
+                                    4: the first only, writing predicted observations HA x instead of filtered means (no NLL);
+                                    5: the imputation sweeps of the latents the first pass flagged (filter_x_gaps_a / _b_kernel) */,
+             const GapArgs* ga = nullptr) {
     dim3 block(64 * WPB), grid(SPLIT ? (unsigned)L : (unsigned)((L + WPB - 1) / WPB), SPLIT ? (unsigned)nslice : 1u);
     const T* ty = static_cast<const T*>(Ty);
     const T* xi = static_cast<const T*>(xin);
@@ -1540,20 +1754,36 @@ int launch_x(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, con
     do {                                                                                                                                     \
         if (pass_mode != 2)                                                                                                                  \
             hipExtLaunchKernelGGL((filter_x_kernel<T, DB, J, W_, N_, WPB, SPLIT, false>), grid, block, 0, stream, ev0, ev1, 0,                \
-                                  ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nslice, segs_per_slice, nll_part, ldo, link_flags, link_state, active); \
+                                  ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nslice, segs_per_slice, nll_part, ldo, link_flags, link_state); \
         if constexpr (!SPLIT) {                                                                                                              \
             if (link_flags && (pass_mode == 0 || pass_mode == 2))  /* second pass: the latents stopped at a segment with gaps (none: the grid exits at once) */ \
                 hipLaunchKernelGGL((filter_x_kernel<T, DB, J, W_, N_, WPB, SPLIT, true>), grid, block, 0, stream,                             \
-                                   ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nslice, segs_per_slice, nll_part, ldo, link_flags, link_state, (const int*)nullptr); \
+                                   ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nslice, segs_per_slice, nll_part, ldo, link_flags, link_state); \
         }                                                                                                                                    \
     } while (0)
     if constexpr (!SPLIT) {
         if (pass_mode == 4) {
             hipLaunchKernelGGL((filter_x_kernel<T, DB, J, true, false, WPB, SPLIT, false, true>), grid, block, 0, stream,
-                               ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nslice, segs_per_slice, nll_part, ldo, link_flags, link_state, active);
+                               ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, nslice, segs_per_slice, nll_part, ldo, link_flags, link_state);
             hipError_t e4 = hipGetLastError();
             if (e4 != hipSuccess) { set_last_error("filter_x_kernel launch: %s", hipGetErrorString(e4)); return 2; }
             return 0;
+        }
+        if constexpr (J >= 2) {
+            if (pass_mode == 5) {
+                hipLaunchKernelGGL((filter_x_gaps_a_kernel<T, DB, J, WPB>), grid, block, 0, stream, ty, Tlen, ld, L, cbT, cb64, xi, (const int*)link_flags,
+                                   (const double*)link_state, static_cast<const T*>(ga->imp), ga->gpos, static_cast<T*>(ga->gval), ga->gcap, ga->gstat);
+#define MOIHGP_X_GAPS(W_, N_) hipLaunchKernelGGL((filter_x_gaps_b_kernel<T, DB, J, W_, N_, WPB>), grid, block, 0, stream, ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, ldo, \
+                                                 link_flags, (const double*)link_state, (const int*)ga->gpos, static_cast<const T*>(ga->gval), ga->gcap, (const int*)ga->gstat)
+                if (yhat && nll) MOIHGP_X_GAPS(true, true);
+                else if (yhat) MOIHGP_X_GAPS(true, false);
+                else if (nll) MOIHGP_X_GAPS(false, true);
+                else { set_last_error("the imputation sweep needs an output"); return 1; }
+#undef MOIHGP_X_GAPS
+                hipError_t e5 = hipGetLastError();
+                if (e5 != hipSuccess) { set_last_error("filter_x_gaps kernels launch: %s", hipGetErrorString(e5)); return 2; }
+                return 0;
+            }
         }
     }
     if (yhat && nll) MOIHGP_X_LAUNCH(true, true);
@@ -1672,22 +1902,16 @@ int launch_xd(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, co
     if (L >= 1024) {
         // chunks with a gap per segment up to which the broken-link stages of the second pass beat the tick-by-tick walk (measured,
         // tools/filternan.py: a stage costs one scan + one replay, the second pass of the fp64 d = 12 kernel runs one wave per SIMD)
-        // force_slices < -1 (gaps_x.hip: missing ticks by imputation around this sweep): -2 = the first pass alone, handing over EVERY latent that
-        // holds a gap; -3 = the second pass alone (what the imputation left flagged); -4 = the first pass over a compact bank of *link_flags latents
-        // (link_flags then points at that device-side count; its streams hold no gaps)
-        // (-5 = as -4, the sweep writing predicted observations HA x instead of filtered means; -6 = that sweep over the full bank)
-        // In the compact modes link_flags is the bank's control block, link_state the caller's flags (int*), scratch the gap counts per (slot, part)
-        // (int*), scratch_len the number of parts, env_links the fewest gaps a slot is swept for (filter_x_kernel).
-        const int pass_mode = force_slices == -2 ? 1 : force_slices == -3 ? 2 : force_slices == -4 ? 3 : (force_slices == -5 || force_slices == -6) ? 4 : 0;
-        if (pass_mode >= 3) {
-            const int* active = force_slices == -6 ? nullptr : link_flags;
-            return launch_x<T, DB, J, 4, false>(Ty, Tlen, ld, L, cbT, cb64, xin, x, yhat, nll, stream, ev0, ev1, (int)scratch_len, env_links, scratch, ldo,
-                                                nullptr, link_state, nullptr, pass_mode, active);
-        }
-        const int* active = nullptr;
+        // force_slices < -1 (missing ticks by imputation, filter_x_gaps_a / _b_kernel): -2 = the first pass alone, handing over EVERY latent that holds a
+        // gap; -3 = the second pass alone; -6 = the first pass alone, writing predicted observations HA x instead of filtered means (the filters'
+        // impulse responses); -7 = the imputation sweep of the latents the first pass flagged (scratch then points at a host-side GapArgs)
+        const int pass_mode = force_slices == -2 ? 1 : force_slices == -3 ? 2 : force_slices == -6 ? 4 : force_slices == -7 ? 5 : 0;
+        if (pass_mode >= 4)
+            return launch_x<T, DB, J, 4, false>(Ty, Tlen, ld, L, cbT, cb64, xin, x, yhat, nll, stream, ev0, ev1, 1, 0, nullptr, ldo,
+                                                pass_mode == 5 ? link_flags : nullptr, link_state, nullptr, pass_mode, reinterpret_cast<const GapArgs*>(scratch));
         const int max_links = pass_mode == 1 ? 64 : (env_links >= 0 ? env_links : (DB * J <= kPairMaxDim ? 64 : ((sizeof(T) == 8 && DB * J > 9) ? 3 : 32)));
         return launch_x<T, DB, J, 4, false>(Ty, Tlen, ld, L, cbT, cb64, xin, x, yhat, nll, stream, ev0, ev1, 1, max_links, nullptr, ldo,
-                                            (pass_mode < 3 && max_links > 0 && link_state) ? link_flags : nullptr, link_state, total, pass_mode, active);
+                                            (max_links > 0 && link_state) ? link_flags : nullptr, link_state, total, pass_mode);
     }
     const size_t nseg = (Tlen + SEG - 1) / SEG;
     // few latents, a stream of 2 .. kTeamWaves segments: one workgroup per latent, one wavefront per segment (filter_x_team_kernel), as long as
