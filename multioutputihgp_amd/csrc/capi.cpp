@@ -67,8 +67,11 @@ struct moihgp_gp {
     float* cb32 = nullptr;
     // per-tick staging
     double *dx = nullptr, *dy = nullptr, *ddx = nullptr;       // one device block [x | y | dx]
-    int* dunstable = nullptr;                                  // device int[2]: latents flagged unstable (fp64, fp32 blocks)
-    int n_unstable[2] = {0, 0};
+    int* dunstable = nullptr;                                  // device int[3]: latents flagged unstable (fp64, fp32 blocks); [2]: fp32 only, swept in fp64
+    int n_unstable[3] = {0, 0, 0};
+    int* drescue_idx = nullptr;                                // stacked models, 1024 latents and more: the latents counted in n_unstable[2]
+    void* drescue = nullptr; size_t rescue_cap = 0;            // their compact fp64 bank (filter_stream, fp32 streams)
+    void* drescue_const = nullptr; size_t rescue_const_cap = 0; // ... its constant blocks and team-kernel powers (per update)
     double* dpart = nullptr;                                   // [32][L] chunk partials of the per-tick projection
     double *dTy = nullptr, *dUty = nullptr, *dTyhat = nullptr, *dloss = nullptr, *dgrad = nullptr, *dscratch = nullptr;
     double* dwork = nullptr;   // L*L + L, lazily (missing-output projection)
@@ -126,7 +129,7 @@ struct moihgp_gp {
 
 static void gp_free(moihgp_gp* g) {
     if (!g) return;
-    void* ptrs[] = {g->dU, g->dS, g->dsqrtS, g->dinvsqrtS, g->dsigma, g->dparams, g->cb64, g->cb32, g->dx, g->dpart, g->dTy, g->dUty, g->dTyhat, g->dloss, g->dgrad, g->dscratch, g->dwork, g->dpolar, g->dfallback, g->dwin, g->dunstable, g->dxscratch, g->cbd64, g->dU32, g->dhp, g->dlink, g->dwinmiss, g->dtp64, g->dtp32, g->dxc64, g->dxc32, g->dlinkflags, g->dgap};
+    void* ptrs[] = {g->dU, g->dS, g->dsqrtS, g->dinvsqrtS, g->dsigma, g->dparams, g->cb64, g->cb32, g->dx, g->dpart, g->dTy, g->dUty, g->dTyhat, g->dloss, g->dgrad, g->dscratch, g->dwork, g->dpolar, g->dfallback, g->dwin, g->dunstable, g->dxscratch, g->cbd64, g->dU32, g->dhp, g->dlink, g->dwinmiss, g->dtp64, g->dtp32, g->dxc64, g->dxc32, g->dlinkflags, g->dgap, g->drescue_idx, g->drescue, g->drescue_const};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (void* p : g->pinned) (void)hipHostUnregister(p);
@@ -197,7 +200,8 @@ static void run_ihgp_update(moihgp_gp* g) {
     MOIHGP_HIP_FATAL(hipMemcpyAsync(g->dparams, g->igp.data(), sizeof(double) * g->L * g->P, hipMemcpyHostToDevice, g->stream));
     if (kernel_stack(g->kernel)) {
         // the sensitivities cost nine more 100-iteration Lyapunov solves per latent at d = 12: only for handles that use them
-        launch_stack_update(g->kernel, g->dt, g->dparams, g->L, g->cb64, g->cb32, g->sens_wanted ? g->cbd64 : nullptr, g->dunstable, g->stream);
+        if (g->L >= 1024 && !g->drescue_idx) g->drescue_idx = dev_alloc<int>(g->L);
+        launch_stack_update(g->kernel, g->dt, g->dparams, g->L, g->cb64, g->cb32, g->sens_wanted ? g->cbd64 : nullptr, g->dunstable, g->drescue_idx, g->stream);
         g->sens_valid = g->sens_wanted;
         // the time-parallel gradient sweep's per-latent tables follow the sensitivity blocks: rebuilt HERE, on the handle's stream (which this
         // function synchronises), so that hp_valid never claims a table nobody built and sweeps on any caller stream find it complete
@@ -220,8 +224,25 @@ static void run_ihgp_update(moihgp_gp* g) {
             launch_team_powers(g->kernel | (1 << 4), g->dxc64, g->L, g->dtp64, g->dtp32, g->stream);
         }
     }
-    MOIHGP_HIP_FATAL(hipMemcpyAsync(g->n_unstable, g->dunstable, 2 * sizeof(int), hipMemcpyDeviceToHost, g->stream));
+    MOIHGP_HIP_FATAL(hipMemcpyAsync(g->n_unstable, g->dunstable, 3 * sizeof(int), hipMemcpyDeviceToHost, g->stream));
     MOIHGP_HIP_FATAL(hipStreamSynchronize(g->stream));
+    if (kernel_stack(g->kernel) && g->drescue_idx && g->n_unstable[2] > 0) {
+        // fp32 sweeps of this bank take n_unstable[2] latents in fp64 on the side (filter_stream_impl): their constant blocks and the few-latents team
+        // kernel's scan powers, compact, once per update
+        const size_t n = (size_t)g->n_unstable[2], xcs = (size_t)xc_size(g->d), tpe = team_powers_elems(g->d);
+        const size_t need = n * (xcs + tpe) * sizeof(double) + n * tpe * sizeof(float);
+        if (g->rescue_const_cap < need) {
+            if (g->drescue_const) { MOIHGP_HIP_FATAL(hipDeviceSynchronize()); MOIHGP_HIP_FATAL(hipFree(g->drescue_const)); g->drescue_const = nullptr; g->rescue_const_cap = 0; }
+            MOIHGP_HIP_FATAL(hipMalloc(&g->drescue_const, need));
+            g->rescue_const_cap = need;
+        }
+        double* cbc = static_cast<double*>(g->drescue_const);
+        double* tpd = cbc + n * xcs;
+        float* tpf = reinterpret_cast<float*>(tpd + n * tpe);
+        launch_rescue_gather(nullptr, 0, 0, g->drescue_idx, n, g->cb64, (int)xcs, nullptr, g->d, nullptr, cbc, nullptr, g->stream);
+        launch_team_powers(g->kernel, cbc, n, tpd, tpf, g->stream);
+        MOIHGP_HIP_FATAL(hipStreamSynchronize(g->stream));
+    }
 }
 
 static void ensure_sensitivities(moihgp_gp* g) {
@@ -281,7 +302,8 @@ static moihgp_gp* gp_create(int kernel, double dt, size_t M, size_t L, bool late
     g->cb32 = dev_alloc<float>(L * cbs);
     if (kstack) g->cbd64 = dev_alloc<double>(L * (size_t)xd_size(g->d, g->P));
     g->dfallback = dev_alloc<int>(2 * L + 1);
-    g->dunstable = dev_alloc<int>(2);
+    g->dunstable = dev_alloc<int>(3);
+    MOIHGP_HIP_FATAL(hipMemset(g->dunstable, 0, 3 * sizeof(int)));
     g->igp.resize(L * g->P);
     for (size_t l = 0; l < L; l++) {
         if (params_LP) for (int p = 0; p < g->P; p++) g->igp[l * g->P + p] = params_LP[l * g->P + p];
@@ -750,6 +772,40 @@ static int filter_stream_io_impl(moihgp_gp* gp, int dtype, const void* Ty, size_
             gp->dlinkflags = dev_alloc<int>(gp->L);
             MOIHGP_HIP_FATAL(hipMemsetAsync(gp->dlinkflags, 0, gp->L * sizeof(int), (hipStream_t)stream));
         }
+        // fp32 streams, many latents: the latents whose fp32 scan tables are unusable while the fp64 ones are fine (a mildly unstable filter; listed at
+        // update(), skipped by the many-latent kernel) are swept in fp64 on the handle's own stream, beside the sweep -- tick by tick in the fp32
+        // kernel one of them holds the whole launch (4096 x 10^4 Matern32x2: 7 such latents, 302 us against 80)
+        const size_t n_res = (!plain_x && dtype == MOIHGP_F32 && gp->L >= 1024 && T > 0) ? (size_t)gp->n_unstable[2] : 0;
+        if (n_res) {
+            const size_t xcs = (size_t)xc_size(gp->d), dd = (size_t)gp->d;
+            const size_t tpe = team_powers_elems(gp->d);
+            const size_t need = (2 * n_res * ld + 2 * n_res * dd + n_res + n_res * 16) * sizeof(double);
+            if (gp->rescue_cap < need) {
+                if (gp->drescue) { MOIHGP_HIP_FATAL(hipDeviceSynchronize()); MOIHGP_HIP_FATAL(hipFree(gp->drescue)); gp->drescue = nullptr; gp->rescue_cap = 0; }
+                MOIHGP_HIP_FATAL(hipMalloc(&gp->drescue, need));
+                gp->rescue_cap = need;
+            }
+            double* rin = static_cast<double*>(gp->drescue);
+            double* rout = rin + n_res * ld;
+            double* xi = rout + n_res * ld;
+            double* xo = xi + n_res * dd;
+            double* nc = xo + n_res * dd;
+            double* sc = nc + n_res;
+            double* cbc = static_cast<double*>(gp->drescue_const);        // (run_ihgp_update)
+            double* tpd = cbc + n_res * xcs;                              // the few-latents team kernel's scan powers: segments side by side, a fifth of the latency
+            float* tpf = reinterpret_cast<float*>(tpd + n_res * tpe);
+            if (const char* tr = getenv("MOIHGP_GAP_TRACE"); tr && tr[0] == '1') fprintf(stderr, "moihgp side sweep: %zu latents of the fp32 bank in fp64\n", n_res);
+            wait_for_caller(gp, (hipStream_t)stream);                    // (behind the caller's queue so far: the stream and the start states are there)
+            launch_rescue_gather(static_cast<const float*>(Ty), T, ld, gp->drescue_idx, n_res, nullptr, (int)xcs, static_cast<const float*>(x_in), gp->d, rin, nullptr, xi, gp->stream);
+            if (int rc = launch_filter_stream_x(kid, MOIHGP_F64, rin, T, ld, n_res, cbc, nullptr, xi, xo, yhat ? rout : nullptr, nll ? nc : nullptr, gp->stream, nullptr, nullptr,
+                                                sc, n_res * 16, 0, ld, nullptr, nullptr, nullptr, gp->opt_filter_maxlinks, -1, tpd, tpf)) return rc;
+            launch_rescue_scatter(gp->drescue_idx, n_res, rout, T, ld, xo, gp->d, nc, static_cast<float*>(yhat), ld_out, static_cast<float*>(x), nll, gp->stream);
+        }
+        auto rescued = [&]() {                                          // the caller's stream waits for the side sweep; the total over all latents
+            if (!n_res) return;
+            caller_waits(gp, (hipStream_t)stream);
+            if (nll && nll_total) launch_nll_total(nll, gp->L, nll_total, (hipStream_t)stream);
+        };
         // many latents, a state too wide for per-chunk maps: latents whose stream holds missing ticks are swept by imputation (recursion_x.hip:
         // filter_x_gaps_a / _b_kernel) between the first pass, which hands them over, and the second, which takes what the imputation could not
         const bool impute = !plain_x && gp->L >= 1024 && T > 0 && gp->opt_filter_split == 0 && (yhat || nll) &&
@@ -783,7 +839,8 @@ static int filter_stream_io_impl(moihgp_gp* gp, int dtype, const void* Ty, size_
             // what the recursion could not take (a filter with a memory longer than its table): the second pass, as without imputation
             if (int rc = launch_filter_stream_x(kid, dtype, Ty, T, ld, gp->L, xb64, xb32, x_in, x, yhat, nll, (hipStream_t)stream, nullptr, nullptr, gp->dxscratch, slen, -3, ld_out,
                                                 gp->dlinkflags, gp->dlink, nullptr, gp->opt_filter_maxlinks, gp->opt_filter_team, gp->dtp64, gp->dtp32)) return rc;
-            if (nll && nll_total) launch_nll_total(nll, gp->L, nll_total, (hipStream_t)stream);
+            if (n_res) rescued();
+            else if (nll && nll_total) launch_nll_total(nll, gp->L, nll_total, (hipStream_t)stream);
             if (tracing) {
                 std::vector<int> st(gp->L);
                 MOIHGP_HIP_FATAL(hipMemcpyAsync(st.data(), bank.gstat, gp->L * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
@@ -796,8 +853,9 @@ static int filter_stream_io_impl(moihgp_gp* gp, int dtype, const void* Ty, size_
             return 0;
         }
         int rc = launch_filter_stream_x(kid, dtype, Ty, T, ld, gp->L, xb64, xb32, x_in, x, yhat, nll, (hipStream_t)stream, e0, e1,
-                                        gp->dxscratch, slen, gp->opt_filter_split /* test hook: 1 = off, n = slices */, ld_out, gp->L >= 1024 ? gp->dlinkflags : nullptr, gp->dlink, nll ? nll_total : nullptr,
-                                        gp->opt_filter_maxlinks, gp->opt_filter_team, gp->dtp64, gp->dtp32);
+                                        gp->dxscratch, slen, gp->opt_filter_split /* test hook: 1 = off, n = slices */, ld_out, gp->L >= 1024 ? gp->dlinkflags : nullptr, gp->dlink,
+                                        (nll && !n_res) ? nll_total : nullptr, gp->opt_filter_maxlinks, gp->opt_filter_team, gp->dtp64, gp->dtp32);
+        if (rc == 0) rescued();
         return rc;
     }
     // few latents, streams of 2 .. 8 segments: one workgroup per latent, eight wavefronts (the stacked filter's team kernel, recursion_x.hip)

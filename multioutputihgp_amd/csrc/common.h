@@ -125,7 +125,14 @@ void launch_ihgp_update(int kernel, int d, double dt, const double* params_dev, 
 // stationary_x.hip / recursion_x.hip: the same two stages for stacked models (state dim d in {4, 6, 8, 9, 12}).
 // params_dev [n][2J+1] = (magnitude_j, lengthscale_j) x J, noise.
 void launch_stack_update(int kernel, double dt, const double* params_dev, size_t n, double* cb64, float* cb32,
-                         double* cbd64 /* [n] sensitivity blocks XD, or NULL to skip them */, int* n_unstable, hipStream_t stream);
+                         double* cbd64 /* [n] sensitivity blocks XD, or NULL to skip them */, int* n_unstable /* int[3] */,
+                         int* rescue_idx /* int[n] or NULL: see stack_update_kernel */, hipStream_t stream);
+// gaps_x.hip: the latents listed in idx (n of them: fp32 tables unusable, fp64 ones fine) of an fp32 bank, swept in fp64: rows and start states
+// (Ty != NULL: per sweep) or constant blocks (Ty == NULL: per update) out into a compact fp64 bank, results back
+void launch_rescue_gather(const float* Ty, size_t T, size_t ld, const int* idx, size_t n, const double* cb64, int xcs, const float* xin, int d,
+                          double* rows, double* cbc, double* xc, hipStream_t s);
+void launch_rescue_scatter(const int* idx, size_t n, const double* rows, size_t T, size_t ld, const double* xc, int d, const double* nllc,
+                           float* yhat, size_t ldo, float* x, double* nll, hipStream_t s);
 // stationary_x.hip: the reference's own models (d = 2, 3) in the stacked layout, for the few-latents team kernel: [n][xc_size(d)] from the CB blocks
 void launch_xc_from_cb(int d, const double* cb64, size_t n, double* xc64, float* xc32, hipStream_t stream);
 // stack_dispatch.hip: the team kernel for those models, if the stream and the bank suit it (returns -1 if not: the caller carries on)

@@ -15,7 +15,42 @@ __global__ void __launch_bounds__(256) gap_impulse_kernel(T* __restrict__ imp_in
 
 size_t up256(size_t v) { return (v + 255) / 256 * 256; }
 
+// ---- fp32 banks: latents whose fp32 scan tables are unusable (a mildly unstable filter: its largest table entry leaves 1e18) while the fp64 ones
+// are fine -- swept in fp64 on the side (capi.cpp) instead of tick by tick in the fp32 kernel, where one of them holds the whole launch (4096 x
+// 10^4 Matern32x2: 7 such latents, 302 us against 80) ----
+__global__ void __launch_bounds__(256) rescue_gather_kernel(const float* __restrict__ Ty, size_t T, size_t ld, const int* __restrict__ idx, const double* __restrict__ cb64, int xcs,
+                                                            const float* __restrict__ xin, int d, double* __restrict__ rows, double* __restrict__ cbc, double* __restrict__ xc) {
+    const size_t c = blockIdx.x, l = (size_t)idx[c];
+    if (Ty) {                                                           // per sweep: the stream rows and start states
+        for (size_t t = (size_t)blockIdx.y * 256 + threadIdx.x; t < T; t += (size_t)gridDim.y * 256) rows[c * ld + t] = (double)Ty[l * ld + t];
+        if (blockIdx.y == 0 && (int)threadIdx.x < d) xc[c * d + threadIdx.x] = (double)xin[l * d + threadIdx.x];
+    } else if (blockIdx.y == 0) {                                       // per update: the constant blocks
+        for (int e = threadIdx.x; e < xcs; e += 256) cbc[c * xcs + e] = cb64[l * xcs + e];
+    }
+}
+__global__ void __launch_bounds__(256) rescue_scatter_kernel(const int* __restrict__ idx, const double* __restrict__ rows, size_t T, size_t ld, const double* __restrict__ xc, int d,
+                                                             const double* __restrict__ nllc, float* __restrict__ yhat, size_t ldo, float* __restrict__ x, double* __restrict__ nll) {
+    const size_t c = blockIdx.x, l = (size_t)idx[c];
+    if (yhat)
+        for (size_t t = (size_t)blockIdx.y * 256 + threadIdx.x; t < T; t += (size_t)gridDim.y * 256) yhat[l * ldo + t] = (float)rows[c * ld + t];
+    if (blockIdx.y == 0) {
+        if ((int)threadIdx.x < d) x[l * d + threadIdx.x] = (float)xc[c * d + threadIdx.x];
+        if (threadIdx.x == 0 && nll) nll[l] = nllc[c];
+    }
+}
+
 }  // namespace
+
+void launch_rescue_gather(const float* Ty, size_t T, size_t ld, const int* idx, size_t n, const double* cb64, int xcs, const float* xin, int d,
+                          double* rows, double* cbc, double* xc, hipStream_t s) {
+    const unsigned parts = Ty ? (unsigned)((T + 4095) / 4096 ? (T + 4095) / 4096 : 1) : 1u;
+    hipLaunchKernelGGL(rescue_gather_kernel, dim3((unsigned)n, parts), dim3(256), 0, s, Ty, T, ld, idx, cb64, xcs, xin, d, rows, cbc, xc);
+}
+void launch_rescue_scatter(const int* idx, size_t n, const double* rows, size_t T, size_t ld, const double* xc, int d, const double* nllc,
+                           float* yhat, size_t ldo, float* x, double* nll, hipStream_t s) {
+    const unsigned parts = (unsigned)((T + 4095) / 4096 ? (T + 4095) / 4096 : 1);
+    hipLaunchKernelGGL(rescue_scatter_kernel, dim3((unsigned)n, parts), dim3(256), 0, s, idx, rows, T, ld, xc, d, nllc, yhat, ldo, x, nll);
+}
 
 size_t gap_bank_bytes(int d, int dtype, size_t L, size_t T) {
     const size_t es = dtype == 0 ? 8 : 4;

@@ -433,7 +433,12 @@ __device__ __forceinline__ void filter_x_body(const T* __restrict__ Ty, size_t T
         t_resume = (size_t)st[D];
         if (NLL) { acc = st[16 + lane]; nobs = (unsigned)st[80 + lane]; }
     }
-    const bool scan_ok = __builtin_amdgcn_readfirstlane((int)(c[Lay::SCANOK] != T(0))) != 0;
+    const bool scan_ok = __builtin_amdgcn_readfirstlane((int)(c[Lay::SCANOK] > T(0))) != 0;
+    // SCANOK < 0 (fp32 blocks of a bank of 1024 latents and more, stationary_x.hip): tables unusable in fp32, fine in fp64 -- the caller sweeps this
+    // latent in fp64 on the side (capi.cpp), the many-latent kernel leaves it alone
+    if constexpr (sizeof(T) == 4 && !SPLIT && !LINKS && (GAPS == 0 || GAPS == 3)) {
+        if (__builtin_amdgcn_readfirstlane((int)(c[Lay::SCANOK] < T(0))) != 0) return;
+    }
     // The scan powers and the response table are streamed in at the start of every segment (L2-resident, coalesced, issued ahead
     // of the phases that use them) rather than held for the whole sweep: that leaves registers to fetch the NEXT segment of the
     // stream during the replay, so a wave does not sit waiting for HBM at a segment boundary.  fp64 with 12 states has room for
@@ -1128,7 +1133,7 @@ filter_x_team_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L,
     if (l >= L) return;
     const T* __restrict__ c = cbT + l * Lay::SIZE;
     static_assert(Lay::SP == Lay::G + Lay::GN, "the team kernel copies G and SP as one range");
-    const bool scan_ok = __builtin_amdgcn_readfirstlane((int)(c[Lay::SCANOK] != T(0))) != 0;
+    const bool scan_ok = __builtin_amdgcn_readfirstlane((int)(c[Lay::SCANOK] > T(0))) != 0;
     const int nlev = __builtin_amdgcn_readfirstlane((int)c[Lay::NLEV]);
     const bool team_ok = scan_ok && nlev <= 5;                                         // uniform over the workgroup
     T* tile = tiles + (size_t)wave * 64 * STRIDE;
@@ -1490,7 +1495,7 @@ filter_x_teamc_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L
     if (lane == 0) done[wave] = 0;
     __syncthreads();
     MOIHGP_STAMP(1);
-    const bool scan_ok = __builtin_amdgcn_readfirstlane((int)(c[Lay::SCANOK] != T(0) && tp[7 * Lay::LS + 2] != T(0))) != 0;   // response table and powers tame
+    const bool scan_ok = __builtin_amdgcn_readfirstlane((int)(c[Lay::SCANOK] > T(0) && tp[7 * Lay::LS + 2] != T(0))) != 0;   // response table and powers tame
     const int nlev = __builtin_amdgcn_readfirstlane((int)tp[7 * Lay::LS]);              // levels of the scan that matter
     const bool decays = __builtin_amdgcn_readfirstlane((int)(tp[7 * Lay::LS + 1] != T(0))) != 0;    // M^64 negligible: segments chain through e0 alone
     const T* pw = tab + GNC;                                                           // pw + lv * LS: M^(2^lv)

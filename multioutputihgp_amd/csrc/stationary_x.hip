@@ -109,7 +109,9 @@ __device__ inline void wmv(const double* A, const double* x, double* y, int lane
 template <int DB, int J>
 __global__ void __launch_bounds__(64) stack_update_kernel(double dt, const double* __restrict__ params, size_t n,
                                                           double* __restrict__ cb64, float* __restrict__ cb32,
-                                                          double* __restrict__ cbd64, int* __restrict__ n_unstable) {
+                                                          double* __restrict__ cbd64, int* __restrict__ n_unstable,
+                                                          int* __restrict__ rescue_idx /* or NULL: latents whose fp32 tables are unusable but whose fp64 ones are (listed,
+                                                                                          counted in n_unstable[2], their fp32 SCANOK = -1: capi.cpp sweeps them in fp64) */) {
     constexpr int D = DB * J, NN = D * D, P = 2 * J + 1, BB = DB * DB;
     using L = XC<D>;
     __shared__ double sA[NN], sAT[NN], sQ[NN], sP[NN], sT1[NN], sT2[NN], sAKHA[NN], sH[D], sV1[D], sV2[D], sV3[D], sK[D], sHA[D];
@@ -269,9 +271,11 @@ __global__ void __launch_bounds__(64) stack_update_kernel(double dt, const doubl
         o64[L::NLEV] = (double)nlev64;
         o32[L::NLEV] = (float)nlev32;
         o64[L::SCANOK] = ok ? 1.0 : 0.0;
-        o32[L::SCANOK] = ok32 ? 1.0f : 0.0f;
+        const bool rescue = rescue_idx && ok && !ok32;
+        o32[L::SCANOK] = ok32 ? 1.0f : (rescue ? -1.0f : 0.0f);
         if (!ok) atomicAdd(&n_unstable[0], 1);
         if (!ok32) atomicAdd(&n_unstable[1], 1);
+        if (rescue) rescue_idx[atomicAdd(&n_unstable[2], 1)] = (int)l;
     }
     if (!cbd64) return;
 
@@ -439,8 +443,8 @@ __global__ void __launch_bounds__(64) xc_from_cb_kernel(const double* __restrict
 }
 
 template <int DB, int J>
-void launch_t(double dt, const double* params, size_t n, double* cb64, float* cb32, double* cbd64, int* n_unstable, hipStream_t s) {
-    hipLaunchKernelGGL((stack_update_kernel<DB, J>), dim3((unsigned)n), dim3(64), 0, s, dt, params, n, cb64, cb32, cbd64, n_unstable);
+void launch_t(double dt, const double* params, size_t n, double* cb64, float* cb32, double* cbd64, int* n_unstable, int* rescue_idx, hipStream_t s) {
+    hipLaunchKernelGGL((stack_update_kernel<DB, J>), dim3((unsigned)n), dim3(64), 0, s, dt, params, n, cb64, cb32, cbd64, n_unstable, rescue_idx);
 }
 
 }  // namespace
@@ -453,18 +457,18 @@ void launch_xc_from_cb(int d, const double* cb64, size_t n, double* xc64, float*
 }
 
 void launch_stack_update(int kernel, double dt, const double* params_dev, size_t n, double* cb64, float* cb32, double* cbd64,
-                         int* n_unstable, hipStream_t stream) {
+                         int* n_unstable /* int[3] */, int* rescue_idx /* int[n] or NULL */, hipStream_t stream) {
     if (n == 0) return;
-    MOIHGP_HIP_FATAL(hipMemsetAsync(n_unstable, 0, 2 * sizeof(int), stream));
+    MOIHGP_HIP_FATAL(hipMemsetAsync(n_unstable, 0, 3 * sizeof(int), stream));
     const int base = kernel_base(kernel), J = kernel_stack(kernel);
     if (base == 0) {
-        if (J == 2) launch_t<2, 2>(dt, params_dev, n, cb64, cb32, cbd64, n_unstable, stream);
-        else if (J == 3) launch_t<2, 3>(dt, params_dev, n, cb64, cb32, cbd64, n_unstable, stream);
-        else launch_t<2, 4>(dt, params_dev, n, cb64, cb32, cbd64, n_unstable, stream);
+        if (J == 2) launch_t<2, 2>(dt, params_dev, n, cb64, cb32, cbd64, n_unstable, rescue_idx, stream);
+        else if (J == 3) launch_t<2, 3>(dt, params_dev, n, cb64, cb32, cbd64, n_unstable, rescue_idx, stream);
+        else launch_t<2, 4>(dt, params_dev, n, cb64, cb32, cbd64, n_unstable, rescue_idx, stream);
     } else {
-        if (J == 2) launch_t<3, 2>(dt, params_dev, n, cb64, cb32, cbd64, n_unstable, stream);
-        else if (J == 3) launch_t<3, 3>(dt, params_dev, n, cb64, cb32, cbd64, n_unstable, stream);
-        else launch_t<3, 4>(dt, params_dev, n, cb64, cb32, cbd64, n_unstable, stream);
+        if (J == 2) launch_t<3, 2>(dt, params_dev, n, cb64, cb32, cbd64, n_unstable, rescue_idx, stream);
+        else if (J == 3) launch_t<3, 3>(dt, params_dev, n, cb64, cb32, cbd64, n_unstable, rescue_idx, stream);
+        else launch_t<3, 4>(dt, params_dev, n, cb64, cb32, cbd64, n_unstable, rescue_idx, stream);
     }
     MOIHGP_HIP_FATAL(hipGetLastError());
 }

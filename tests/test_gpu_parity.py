@@ -1044,6 +1044,44 @@ def test_stacked_gaps_by_imputation(env, kern, dtype, nanf, monkeypatch, capfd):
     assert rel_err(n0[sub].cpu().numpy()[tame], nll[sub].cpu().numpy()[tame]) < tol
 
 
+def test_fp32_bank_sweeps_unscannable_latents_in_fp64(env, monkeypatch, capfd):
+    """Many latents, fp32 streams: a mildly unstable latent (the literal DARE of dare.h:23 returns such gains: rho(AKHA) of 1.04 .. 1.4) has scan tables
+    that leave the fp32 range but not the fp64 one.  Tick by tick in the fp32 kernel one of them holds the whole launch (BASELINE-sized Matern32x2
+    bank: 7 of 4096, 302 us against 80); they are listed at update(), left alone by the many-latent kernel and swept in fp64 beside it
+    (csrc/capi.cpp).  Their rows against the oracle while the values fit fp32, the other latents as before, with and without gaps in the stream."""
+    from bench import synth_params, SEED
+    kern, L = "Matern32x2", 4096
+    prm = synth_params(L, 0, np.random.default_rng(SEED), kern)
+    igps = env["cref"].ihgp_array(kern, 0.1, prm)
+    rho = np.array([max(abs(np.linalg.eigvals(g.mat("AKHA")))) for g in igps])
+    wild = np.flatnonzero((rho > 1.045) & (rho < 1.3))           # rho^1024 beyond 1e18 (fp32 tables unusable), below 1e150 (fp64 ones fine)
+    assert len(wild) >= 1, ("the synthetic bank holds no mildly unstable latent", np.sort(rho)[-10:])
+    T = int(min(1400, 60.0 / np.log(rho[wild].max())))           # while rho^T fits fp32 with room to spare
+    rng = np.random.default_rng(5)
+    Ty = synth(L, T, rng)
+    Ty[wild[0], [7, T // 3, T // 3 + 1, T - 1]] = np.nan          # the side sweep takes gaps the way the fp64 kernels do
+    sub = np.concatenate([wild, np.sort(rng.choice(np.flatnonzero(rho < 0.999), size=24, replace=False))])
+    o = env["cref"].filter_stream(env["cref"].ihgp_array(kern, 0.1, prm[sub]), np.ascontiguousarray(Ty[sub]), nthreads=8)
+    bank = env["streams"].LatentBank(0.1, prm, kernel=kern)
+    monkeypatch.setenv("MOIHGP_GAP_TRACE", "1")
+    capfd.readouterr()
+    yhat, xT, nll = bank.filter(to_dev(Ty, torch.float32), T=T)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("MOIHGP_GAP_TRACE")
+    trace = re.search(r"side sweep: (\d+) latents", capfd.readouterr().err)
+    assert trace and int(trace.group(1)) >= len(wild), "the fp64 side sweep did not run"
+    yg = yhat[sub][:, :T].cpu().numpy().astype(np.float64)
+    assert np.all(np.isfinite(o["yhat"])) and np.all(np.isfinite(yg))
+    assert rel_err_rows(yg, o["yhat"]) < FP32_TOL
+    assert rel_err(xT[sub].cpu().numpy(), o["x"]) < FP32_TOL
+    a, b = nll[sub].cpu().numpy(), o["nll_per_latent"]
+    assert np.all(np.abs(a - b) <= FP32_TOL * np.abs(b))
+    # NLL-only sweep, and the running total over all latents
+    _, x2, n2 = bank.filter(to_dev(Ty, torch.float32), T=T, want_yhat=False)
+    torch.cuda.synchronize()
+    assert np.all(np.abs(n2[sub].cpu().numpy() - b) <= FP32_TOL * np.abs(b)) and rel_err(x2[sub].cpu().numpy(), o["x"]) < FP32_TOL
+
+
 @pytest.mark.parametrize("kern,M,L", [("Matern32x2", 6, 3), ("Matern52x2", 8, 8), ("Matern52x4", 9, 4), ("Matern52x3", 150, 70)])
 def test_stacked_full_objects_vs_oracle(env, kern, M, L):
     """BASELINE.json's d = 6 / d = 12 configurations behind the whole MOIHGP surface: a stacked StateSpace in the template slot of
