@@ -180,7 +180,7 @@ int moihgp_release_stream(moihgp_gp* gp, void* stream);
  *   "filter_impute"   stacked models, 1024 latents and more: latents whose stream holds missing ticks are swept twice without gaps around a scalar
  *                     recursion over their gaps (exact imputation, csrc/recursion_x.hip: filter_x_gaps_a / _b_kernel) instead of by the second
  *                     pass's broken links / tick-by-tick walk, which keeps the latents whose filter remembers more than 1024 ticks:
- *                     -1 = automatic (state dimension >= 8), 0 = never, 1 = always.  (env MOIHGP_GAP_TRACE=1: one line per sweep on stderr with the
+ *                     -1 = automatic (state dimension >= 8; below it if no latent's filter is that slow), 0 = never, 1 = always.  (env MOIHGP_GAP_TRACE=1: one line per sweep on stderr with the
  *                     number of latents taken, solved and not, and why not; synchronises the stream)
  *   "polar_warm_start" 0 (default) / 1: update() starts the deflation of outlying singular values (csrc/polar_deflate.hip) from the subspace the
  *                     previous update() of this handle found -- consecutive objective evaluations of a learner differ by one line-search step,

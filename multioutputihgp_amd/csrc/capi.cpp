@@ -67,8 +67,8 @@ struct moihgp_gp {
     float* cb32 = nullptr;
     // per-tick staging
     double *dx = nullptr, *dy = nullptr, *ddx = nullptr;       // one device block [x | y | dx]
-    int* dunstable = nullptr;                                  // device int[3]: latents flagged unstable (fp64, fp32 blocks); [2]: fp32 only, swept in fp64
-    int n_unstable[3] = {0, 0, 0};
+    int* dunstable = nullptr;                                  // device int[4]: latents flagged unstable (fp64, fp32 blocks); [2]: fp32 only, swept in fp64;
+    int n_unstable[4] = {0, 0, 0, 0};                          // [3]: stacked models, filters that remember more than ~1000 ticks
     int* drescue_idx = nullptr;                                // stacked models, 1024 latents and more: the latents counted in n_unstable[2]
     void* drescue = nullptr; size_t rescue_cap = 0;            // their compact fp64 bank (filter_stream, fp32 streams)
     void* drescue_const = nullptr; size_t rescue_const_cap = 0; // ... its constant blocks and team-kernel powers (per update)
@@ -224,7 +224,7 @@ static void run_ihgp_update(moihgp_gp* g) {
             launch_team_powers(g->kernel | (1 << 4), g->dxc64, g->L, g->dtp64, g->dtp32, g->stream);
         }
     }
-    MOIHGP_HIP_FATAL(hipMemcpyAsync(g->n_unstable, g->dunstable, 3 * sizeof(int), hipMemcpyDeviceToHost, g->stream));
+    MOIHGP_HIP_FATAL(hipMemcpyAsync(g->n_unstable, g->dunstable, 4 * sizeof(int), hipMemcpyDeviceToHost, g->stream));
     MOIHGP_HIP_FATAL(hipStreamSynchronize(g->stream));
     if (kernel_stack(g->kernel) && g->drescue_idx && g->n_unstable[2] > 0) {
         // fp32 sweeps of this bank take n_unstable[2] latents in fp64 on the side (filter_stream_impl): their constant blocks and the few-latents team
@@ -302,8 +302,8 @@ static moihgp_gp* gp_create(int kernel, double dt, size_t M, size_t L, bool late
     g->cb32 = dev_alloc<float>(L * cbs);
     if (kstack) g->cbd64 = dev_alloc<double>(L * (size_t)xd_size(g->d, g->P));
     g->dfallback = dev_alloc<int>(2 * L + 1);
-    g->dunstable = dev_alloc<int>(3);
-    MOIHGP_HIP_FATAL(hipMemset(g->dunstable, 0, 3 * sizeof(int)));
+    g->dunstable = dev_alloc<int>(4);
+    MOIHGP_HIP_FATAL(hipMemset(g->dunstable, 0, 4 * sizeof(int)));
     g->igp.resize(L * g->P);
     for (size_t l = 0; l < L; l++) {
         if (params_LP) for (int p = 0; p < g->P; p++) g->igp[l * g->P + p] = params_LP[l * g->P + p];
@@ -807,9 +807,12 @@ static int filter_stream_io_impl(moihgp_gp* gp, int dtype, const void* Ty, size_
             if (nll && nll_total) launch_nll_total(nll, gp->L, nll_total, (hipStream_t)stream);
         };
         // many latents, a state too wide for per-chunk maps: latents whose stream holds missing ticks are swept by imputation (recursion_x.hip:
-        // filter_x_gaps_a / _b_kernel) between the first pass, which hands them over, and the second, which takes what the imputation could not
+        // filter_x_gaps_a / _b_kernel) between the first pass, which hands them over, and the second, which takes what the imputation could not.
+        // Left to itself: at d >= 8 always (the second pass alone is 4-6 x slower there), below it -- where the second pass scans the chunks' own
+        // maps -- only for a bank without slow filters, whose latents would take both (measured, tools/filternan.py, 4096 x 10^4 at 1 % missing:
+        // 2 x Matern-5/2 0.81 -> 0.45 ms; 2 x Matern-3/2 at the bench's draw, 13 % of them slow, 0.37 -> 0.63)
         const bool impute = !plain_x && gp->L >= 1024 && T > 0 && gp->opt_filter_split == 0 && (yhat || nll) &&
-                            (gp->opt_filter_impute == 1 || (gp->opt_filter_impute == -1 && gp->d >= 8));
+                            (gp->opt_filter_impute == 1 || (gp->opt_filter_impute == -1 && (gp->d >= 8 || gp->n_unstable[3] == 0)));
         if (impute) {
             const size_t need = gap_bank_bytes(gp->d, dtype, gp->L, T);
             if (gp->gap_cap < need) {

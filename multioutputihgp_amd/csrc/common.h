@@ -125,7 +125,7 @@ void launch_ihgp_update(int kernel, int d, double dt, const double* params_dev, 
 // stationary_x.hip / recursion_x.hip: the same two stages for stacked models (state dim d in {4, 6, 8, 9, 12}).
 // params_dev [n][2J+1] = (magnitude_j, lengthscale_j) x J, noise.
 void launch_stack_update(int kernel, double dt, const double* params_dev, size_t n, double* cb64, float* cb32,
-                         double* cbd64 /* [n] sensitivity blocks XD, or NULL to skip them */, int* n_unstable /* int[3] */,
+                         double* cbd64 /* [n] sensitivity blocks XD, or NULL to skip them */, int* n_unstable /* int[4]: unusable tables fp64 / fp32, fp32 only (listed in rescue_idx), slow filters */,
                          int* rescue_idx /* int[n] or NULL: see stack_update_kernel */, hipStream_t stream);
 // gaps_x.hip: the latents listed in idx (n of them: fp32 tables unusable, fp64 ones fine) of an fp32 bank, swept in fp64: rows and start states
 // (Ty != NULL: per sweep) or constant blocks (Ty == NULL: per update) out into a compact fp64 bank, results back

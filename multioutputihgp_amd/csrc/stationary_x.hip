@@ -276,6 +276,7 @@ __global__ void __launch_bounds__(64) stack_update_kernel(double dt, const doubl
         if (!ok) atomicAdd(&n_unstable[0], 1);
         if (!ok32) atomicAdd(&n_unstable[1], 1);
         if (rescue) rescue_idx[atomicAdd(&n_unstable[2], 1)] = (int)l;
+        if (nlev64 > 5) atomicAdd(&n_unstable[3], 1);                  // a filter that remembers more than ~1000 ticks (capi.cpp: imputation of missing ticks)
     }
     if (!cbd64) return;
 
@@ -457,9 +458,9 @@ void launch_xc_from_cb(int d, const double* cb64, size_t n, double* xc64, float*
 }
 
 void launch_stack_update(int kernel, double dt, const double* params_dev, size_t n, double* cb64, float* cb32, double* cbd64,
-                         int* n_unstable /* int[3] */, int* rescue_idx /* int[n] or NULL */, hipStream_t stream) {
+                         int* n_unstable /* int[4] */, int* rescue_idx /* int[n] or NULL */, hipStream_t stream) {
     if (n == 0) return;
-    MOIHGP_HIP_FATAL(hipMemsetAsync(n_unstable, 0, 3 * sizeof(int), stream));
+    MOIHGP_HIP_FATAL(hipMemsetAsync(n_unstable, 0, 4 * sizeof(int), stream));
     const int base = kernel_base(kernel), J = kernel_stack(kernel);
     if (base == 0) {
         if (J == 2) launch_t<2, 2>(dt, params_dev, n, cb64, cb32, cbd64, n_unstable, rescue_idx, stream);
