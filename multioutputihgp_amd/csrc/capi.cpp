@@ -833,7 +833,7 @@ static int filter_stream_io_impl(moihgp_gp* gp, int dtype, const void* Ty, size_
             }
             if (int rc = launch_filter_stream_x(kid, dtype, Ty, T, ld, gp->L, xb64, xb32, x_in, x, yhat, nll, (hipStream_t)stream, e0, e1, gp->dxscratch, slen, -2, ld_out,
                                                 gp->dlinkflags, gp->dlink, nullptr, gp->opt_filter_maxlinks, gp->opt_filter_team, gp->dtp64, gp->dtp32)) return rc;
-            const GapArgs ga{bank.imp_out, bank.gpos, bank.gval, bank.gcap, bank.gstat};
+            const GapArgs ga{bank.imp_out, bank.gpos, bank.gval, bank.gw, bank.gcap, bank.gstat};
             const char* trace = getenv("MOIHGP_GAP_TRACE");               // diagnostics (the tests read it): synchronises the stream
             const bool tracing = trace && trace[0] == '1';
             if (tracing) MOIHGP_HIP_FATAL(hipMemsetAsync(bank.gstat, 0xFF, gp->L * sizeof(int), (hipStream_t)stream));
@@ -848,10 +848,13 @@ static int filter_stream_io_impl(moihgp_gp* gp, int dtype, const void* Ty, size_
                 std::vector<int> st(gp->L);
                 MOIHGP_HIP_FATAL(hipMemcpyAsync(st.data(), bank.gstat, gp->L * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
                 MOIHGP_HIP_FATAL(hipStreamSynchronize((hipStream_t)stream));
-                long taken = 0, solved = 0, gaps = 0, why[5] = {0, 0, 0, 0, 0};
-                for (int v : st) if (v >= 0) { taken++; if (v & 1) { solved++; gaps += v >> 1; } else why[(v >> 1) < 5 ? (v >> 1) : 0]++; }
-                fprintf(stderr, "moihgp gap imputation: %ld latents handed over, %ld solved, %ld gaps filled (not solved: %ld table not finite, %ld response outlives the table, "
-                        "%ld ring overflow, %ld stream too long)\n", taken, solved, gaps, why[1], why[2], why[3], why[4]);
+                long taken = 0, solved = 0, gaps = 0, states = 0, why[6] = {0, 0, 0, 0, 0, 0};
+                for (int v : st) if (v >= 0) {
+                    taken++;
+                    if (v & 1) { solved++; gaps += (v & 0x3FFFFFFF) >> 1; states += (v >> 30) & 1; } else why[(v >> 1) < 6 ? (v >> 1) : 0]++;
+                }
+                fprintf(stderr, "moihgp gap imputation: %ld latents handed over, %ld solved, %ld gaps filled (%ld of the latents by the state form: memory beyond the table or "
+                        "the ring; not solved: %ld response not finite or growing, %ld fill value not finite, %ld stream too long)\n", taken, solved, gaps, states, why[1], why[5], why[4]);
             }
             return 0;
         }

@@ -174,15 +174,15 @@ int launch_grad_scan_x(int kernel, int dtype, const void* Ty, size_t Tpar, size_
 constexpr int kGapSMax = 1024;        // impulse-response table per latent (ticks); beyond it the response must be negligible
 struct GapArgs {                      // what launch_filter_stream_x(force_slices = -7) finds behind its `scratch` argument (host memory)
     const void* imp;                  // [L][kGapSMax] impulse responses, the stream's scalar type
-    int* gpos; void* gval;            // [L][gcap] the gaps' ticks / their predictions, then fill values
+    int* gpos; void* gval; void* gw;  // [L][gcap] the gaps' ticks / their predictions / their fill values
     size_t gcap;
-    int* gstat;                       // [L] per latent swept by imputation: 2 * gaps + 1 if solved, else 2 * the reason why not
+    int* gstat;                       // [L] per latent swept by imputation: 2 * gaps + 1 if solved (bit 30: by the state form), else 2 * the reason why not
 };
 struct GapBank {
     void* imp_in = nullptr; void* imp_out = nullptr;            // [L][kGapSMax]: unit impulses (constant: gap_bank_init) and the filters' responses to them
     void* xz = nullptr;                                         // zeros [L][d]: the start state of the impulse sweep
     void* x1 = nullptr;                                         // its end states [L][d] (unused)
-    int* gpos = nullptr; void* gval = nullptr;                  // [L][gcap]
+    int* gpos = nullptr; void* gval = nullptr; void* gw = nullptr;   // [L][gcap]
     size_t gcap = 0;
     int* gstat = nullptr;                                       // [L]
 };

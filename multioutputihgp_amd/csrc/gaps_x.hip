@@ -55,7 +55,7 @@ void launch_rescue_scatter(const int* idx, size_t n, const double* rows, size_t 
 size_t gap_bank_bytes(int d, int dtype, size_t L, size_t T) {
     const size_t es = dtype == 0 ? 8 : 4;
     const size_t gcap = (T + 63) / 64 * 64;
-    return 2 * up256(L * (size_t)kGapSMax * es) + 2 * up256(L * (size_t)d * es) + up256(L * sizeof(int)) + up256(L * gcap * sizeof(int)) + up256(L * gcap * es);
+    return 2 * up256(L * (size_t)kGapSMax * es) + 2 * up256(L * (size_t)d * es) + up256(L * sizeof(int)) + up256(L * gcap * sizeof(int)) + 2 * up256(L * gcap * es);
 }
 
 GapBank gap_bank_carve(void* base, int d, int dtype, size_t L, size_t T) {
@@ -69,7 +69,8 @@ GapBank gap_bank_carve(void* base, int d, int dtype, size_t L, size_t T) {
     b.x1 = p; p += up256(L * (size_t)d * es);
     b.gstat = reinterpret_cast<int*>(p); p += up256(L * sizeof(int));
     b.gpos = reinterpret_cast<int*>(p); p += up256(L * b.gcap * sizeof(int));
-    b.gval = p;
+    b.gval = p; p += up256(L * b.gcap * es);
+    b.gw = p;
     return b;
 }
 

@@ -71,8 +71,22 @@ __global__ void __launch_bounds__(256)
 gemm_mfma_kernel(size_t Mi, size_t Nj, size_t Kk, const TA* __restrict__ A, size_t lda, const TB* __restrict__ B, size_t ldb,
                  TC* __restrict__ C, size_t ldc, const double* __restrict__ rs, int rs_mode, const double* __restrict__ ks, int ks_mode,
                  unsigned tiles_m, unsigned tiles_n) {
-    __shared__ TC As[BK][LDT];
-    __shared__ TC Bs[BK][LDT];
+    // fp32: rows k with bit 3 set keep their columns XOR 32 -- the k-contiguous operands write rows e and 8 + e from the two threads that share a
+    // column, which are 8 x 144 words = a multiple of the 64 banks apart (25 % of the LDS cycles were such conflicts, profiles/r04/gemm_variants.log);
+    // reads take 16 consecutive columns of one row and do not notice: unproject 70.6 -> 71.7 % of the fp32 MFMA peak, project unchanged (74.4 %).
+    // MOIHGP_GEMM_DB=1 (tried, off): two LDS buffers and one barrier per k-tile, the next tile's stash beside this tile's MFMAs -- 74 KB per
+    // workgroup, two workgroups per compute unit instead of four: 71.1 / 67.5 %, the four resident workgroups already hide each other's barriers.
+#ifndef MOIHGP_GEMM_DB
+#define MOIHGP_GEMM_DB 0
+#endif
+#ifndef MOIHGP_GEMM_SWZ
+#define MOIHGP_GEMM_SWZ 1
+#endif
+    constexpr int NBUF = (sizeof(TC) == 4 && MOIHGP_GEMM_DB) ? 2 : 1;
+    constexpr bool SWZ = sizeof(TC) == 4 && MOIHGP_GEMM_SWZ;           // (fp64 rows are 288 words: its reads are laid out for that, its writes conflict two ways still)
+    __shared__ TC As[NBUF][BK][LDT];
+    __shared__ TC Bs[NBUF][BK][LDT];
+    auto swz = [](int k) { return SWZ ? (k & 8) << 2 : 0; };
     // ---- XCD-aware tile order: workgroups b, b+8, b+16.. share an XCD; give each XCD a contiguous run of tiles ----
     const unsigned nwg = SYM ? tiles_m * (tiles_m + 1) / 2 : tiles_m * tiles_n;
     unsigned bid = blockIdx.x;
@@ -183,48 +197,66 @@ gemm_mfma_kernel(size_t Mi, size_t Nj, size_t Kk, const TA* __restrict__ A, size
             }
         }
     };
-    auto stash = [&]() {
+    auto stash = [&](int buf) {
 #pragma unroll
         for (int h = 0; h < KH; h++) {
             if (A_ICONTIG) {
-                const int kk = 16 * h + (tid >> 4), ii = (tid & 15) * 8;
+                const int kk = 16 * h + (tid >> 4), ii = ((tid & 15) * 8) ^ swz(kk);
 #pragma unroll
-                for (int e = 0; e < 8; e++) As[kk][ii + e] = ra[h][e];
+                for (int e = 0; e < 8; e++) As[buf][kk][ii + e] = ra[h][e];
             } else {
                 const int ii = tid >> 1, kk = 16 * h + (tid & 1) * 8;
 #pragma unroll
-                for (int e = 0; e < 8; e++) As[kk + e][ii] = ra[h][e];
+                for (int e = 0; e < 8; e++) As[buf][kk + e][ii ^ swz(kk)] = ra[h][e];       // (kk is a multiple of 8: one swizzle for its eight rows)
             }
             if (B_KCONTIG) {
                 const int jj = tid >> 1, kk = 16 * h + (tid & 1) * 8;
 #pragma unroll
-                for (int e = 0; e < 8; e++) Bs[kk + e][jj] = rb[h][e];
+                for (int e = 0; e < 8; e++) Bs[buf][kk + e][jj ^ swz(kk)] = rb[h][e];
             } else {
-                const int kk = 16 * h + (tid >> 4), jj = (tid & 15) * 8;
+                const int kk = 16 * h + (tid >> 4), jj = ((tid & 15) * 8) ^ swz(kk);
 #pragma unroll
-                for (int e = 0; e < 8; e++) Bs[kk][jj + e] = rb[h][e];
+                for (int e = 0; e < 8; e++) Bs[buf][kk][jj + e] = rb[h][e];
             }
         }
     };
-
-    fetch(0);
-    for (size_t k0 = 0; k0 < Kk; k0 += BK) {
-        __syncthreads();                 // previous tile fully consumed
-        stash();
-        __syncthreads();
-        if (k0 + BK < Kk) fetch(k0 + BK);   // in flight during the MFMAs below
+    auto multiply = [&](int buf) {
 #pragma unroll
         for (int s = 0; s < BK / 4; s++) {
             TC af[4], bf[4];
             const int kr = s * 4 + (lane >> 4), c = lane & 15;
+            const int sw = swz(s * 4);                                 // (compile-time: the lane's part of kr is below bit 3)
 #pragma unroll
-            for (int a = 0; a < 4; a++) af[a] = As[kr][wm * 64 + a * 16 + c];
+            for (int a = 0; a < 4; a++) af[a] = As[buf][kr][wm * 64 + ((a * 16) ^ sw) + c];
 #pragma unroll
-            for (int b = 0; b < 4; b++) bf[b] = Bs[kr][wn * 64 + b * 16 + c];
+            for (int b = 0; b < 4; b++) bf[b] = Bs[buf][kr][wn * 64 + ((b * 16) ^ sw) + c];
 #pragma unroll
             for (int a = 0; a < 4; a++)
 #pragma unroll
                 for (int b = 0; b < 4; b++) acc[a][b] = Acc<TC>::mfma(af[a], bf[b], acc[a][b]);
+        }
+    };
+
+    fetch(0);
+    if constexpr (NBUF == 2) {
+        stash(0);
+        __syncthreads();
+        if (BK < Kk) fetch(BK);
+        int cur = 0;
+        for (size_t k0 = 0; k0 < Kk; k0 += BK) {
+            multiply(cur);
+            if (k0 + BK < Kk) stash(cur ^ 1);        // the tile fetched during the previous multiply
+            __syncthreads();                         // the next tile is complete; this one is fully consumed
+            if (k0 + 2 * BK < Kk) fetch(k0 + 2 * BK);
+            cur ^= 1;
+        }
+    } else {
+        for (size_t k0 = 0; k0 < Kk; k0 += BK) {
+            __syncthreads();                 // previous tile fully consumed
+            stash(0);
+            __syncthreads();
+            if (k0 + BK < Kk) fetch(k0 + BK);   // in flight during the MFMAs below
+            multiply(0);
         }
     }
 

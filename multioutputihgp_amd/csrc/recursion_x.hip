@@ -950,17 +950,18 @@ filter_x_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, cons
 // latent through the first sweep and the recursion (filter_x_gaps_a_kernel: the lists of gaps live in the latent's scratch row, the recursion's
 // table in the wave's tile), one through the second sweep (filter_x_gaps_b_kernel); a bank without gaps leaves both at once.  (One kernel for
 // all three stages was tried: two inlined sweeps in one kernel cost 315 registers at d = 12 fp64 -- one wave per SIMD -- and ran 1.4 x slower.)  The impulse responses come from the same sweep run over a unit observation (gaps_x.hip, once per parameter
-// update).  A latent the recursion cannot take -- a response that has not decayed within kGapSMax ticks, more gaps inside its decay than the
-// window holds -- keeps its flag and takes the second pass (LINKS) as before.
+// update).  A latent the table form cannot take -- a response that has not decayed within kGapSMax ticks, more gaps inside its decay than the
+// ring holds -- is solved by the state form of the same system (gap_solve_states); only a latent whose response is not finite or GROWS (rho(AKHA) > 1: the
+// zero-filled sweep then departs from the true one exponentially and the sum x' + e cancels) keeps its flag and takes the second pass (LINKS) as before.
 constexpr int kGapRing = 256;         // gaps inside the decay window the recursion keeps (LDS)
 
-// The scalar recursion over one latent's n gaps (ticks pos[], predictions val[], both in tick order): on success val[g] = w_g.  imp: the filter's
+// The scalar recursion over one latent's n gaps (ticks pos[], predictions val[], both in tick order): on success wout[g] = w_g.  imp: the filter's
 // response to a unit observation at tick 0 from a zero state, as the GAPS = 3 sweep writes it: imp[k + 1] = s_k.  lds: the wave's tile.
 // 64 gaps at a time, one per lane, by forward substitution in column order: the finished w of the earlier gaps -- the last kGapRing of the blocks
 // before (newest first, until one lies outside the decay), then lane by lane inside the block -- are broadcast, and every later lane adds
 // s_(p-q-1) w_q to its own sum.  No reduction across lanes; about a dozen instructions per gap and broadcast.
 template <typename T>
-__device__ __forceinline__ int gap_solve_wave(const T* __restrict__ imp, const int* pos, T* val, const int n, const size_t Tlen, const int lane, unsigned char* lds) {
+__device__ __forceinline__ int gap_solve_wave(const T* __restrict__ imp, const int* pos, const T* val, T* wout, const int n, const size_t Tlen, const int lane, unsigned char* lds) {
     T* st = reinterpret_cast<T*>(lds);
     int* ringp = reinterpret_cast<int*>(lds + kGapSMax * sizeof(T));
     double* ringw = reinterpret_cast<double*>(lds + kGapSMax * sizeof(T) + kGapRing * sizeof(int));
@@ -983,9 +984,18 @@ __device__ __forceinline__ int gap_solve_wave(const T* __restrict__ imp, const i
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) kd = max(kd, __shfl_xor(kd, o));
     const int kdec = __builtin_amdgcn_readfirstlane(kd);
-    // (the return value: 0 = solved, otherwise why not -- 1: a table that is not finite, 2: a response that outlives the table, 3: more gaps inside
-    // the decay than the ring holds, 4: a stream too long for 32-bit ticks)
-    int why = __builtin_amdgcn_ballot_w64(bad) != 0 ? 1 : kdec > kGapSMax - 64 ? 2 : Tlen >= (1u << 30) ? 4 : 0;
+    // A response that GROWS (rho(AKHA) > 1: the literal DARE returns such gains) rules imputation out altogether: the sweep with zeros at the gaps
+    // then departs from the true one like rho^t, and x = x' + e cancels that many digits.  Growth over the table: its last quarter against its
+    // first, extrapolated to the length of the stream; beyond 1e4 (fp64; 1e2 in fp32) the latent is left to the second pass.
+    double head = 0.0, tail = 0.0;
+    for (int k = lane; k < kGapSMax / 4; k += 64) { head = fmax(head, fabs((double)st[k])); tail = fmax(tail, fabs((double)st[3 * kGapSMax / 4 + k])); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { head = fmax(head, __shfl_xor(head, o)); tail = fmax(tail, __shfl_xor(tail, o)); }
+    const bool grows = tail > head && log(tail / head) * ((double)Tlen / (0.75 * kGapSMax)) > (sizeof(T) == 8 ? 9.2 : 4.6);
+    // (the return value: 0 = solved, otherwise why not -- 1: a table that is not finite or grows, 2: a response that outlives the table, 3: more gaps
+    // inside the decay than the ring holds, 4: a stream too long for 32-bit ticks, 5: a fill value that is not finite)
+    int why = (__builtin_amdgcn_ballot_w64(bad) != 0 || __builtin_amdgcn_readfirstlane((int)grows)) ? 1 : kdec > kGapSMax - 64 ? 2 : Tlen >= (1u << 30) ? 4 : 0;
+    bool wild = false;
     wave_lds_fence();
     int nring = 0;                                                     // gaps solved so far; gap g sits in ring slot g % kGapRing
     int posN = lane < n ? pos[lane] : 0;
@@ -1022,12 +1032,93 @@ __device__ __forceinline__ int gap_solve_wave(const T* __restrict__ imp, const i
             const int slot = (nring + lane) & (kGapRing - 1);
             ringp[slot] = p;
             ringw[slot] = w;
-            val[g0 + lane] = (T)w;
+            wout[g0 + lane] = (T)w;
+            wild |= !(fabs(w) < (sizeof(T) == 8 ? 1e300 : 1e37));
         }
         nring += m;
         wave_lds_fence();
     }
+    if (why == 0 && __builtin_amdgcn_ballot_w64(wild) != 0) why = 5;
     return why;
+}
+
+__device__ inline double wave_sum_dpp(double v) {                      // all in DPP; the total comes back uniform
+    v += dpp0<DPP_ROW_SHR + 1, 0xF>(v);
+    v += dpp0<DPP_ROW_SHR + 2, 0xF>(v);
+    v += dpp0<DPP_ROW_SHR + 4, 0xF>(v);
+    v += dpp0<DPP_ROW_SHR + 8, 0xF>(v);
+    v += dpp0<DPP_ROW_BCAST15, 0xA>(v);
+    v += dpp0<0x143 /* row_bcast:31 */, 0xC>(v);
+    return read_lane(v, 63);
+}
+
+// The same system without the table, for the latents the table form cannot take (a filter that remembers more than kGapSMax ticks, more gaps inside
+// its memory than the ring holds): the error state e = x - x' itself, D numbers carried from gap to gap --
+//     w_p = HA x'_p + HA e_p ;   e <- AKHA e + K w_p  through the gap ;   e <- AKHA^g e  across the g observed ticks to the next one
+// with AKHA^g from binary powers: AKHA^(1, 2, 4, 8, 16) formed here (LDS), AKHA^(32 .. 1024) the latent's own scan levels (fp64 block).  Any
+// memory length, any density, and exact -- but a few D x D matrix-vector products on D lanes per gap (~230 instructions where the table form
+// takes a dozen).  All of it in fp64.
+template <typename T, int D>
+__device__ __forceinline__ bool gap_solve_states(const double* __restrict__ c64, const int* pos, const T* val, T* wout, const int n, const int lane, unsigned char* lds) {
+    using Lay = XC<D>;
+    constexpr int NN = D * D;
+    double* pw = reinterpret_cast<double*>(lds);                       // [5][D * D], row-major
+    for (int e = lane; e < NN; e += 64) pw[e] = c64[Lay::AKHA + e];
+    wave_lds_fence();
+    for (int lv = 1; lv < 5; lv++) {
+        const double* src = pw + (lv - 1) * NN;
+        for (int e = lane; e < NN; e += 64) {
+            const int i = e / D, j = e % D;
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; k++) acc = fma(src[i * D + k], src[k * D + j], acc);
+            pw[lv * NN + e] = acc;
+        }
+        wave_lds_fence();
+    }
+    const int li = lane < D ? lane : 0;                                // (idle lanes shadow lane 0; nobody reads them)
+    const double ha = c64[Lay::HA + li], kk = c64[Lay::K + li];
+    double err = 0.0;                                                  // lane i < D: entry i of e
+    auto advance = [&](const double* m) {                              // e <- m e (m row-major, LDS or global)
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < D; j++) acc = fma(m[li * D + j], read_lane(err, j), acc);
+        err = acc;
+    };
+    int tprev = -1;
+    bool wild = false;
+    int posN = lane < n ? pos[lane] : 0;
+    T hvN = lane < n ? val[lane] : T(0);
+    for (int g0 = 0; g0 < n; g0 += 64) {
+        const int p = posN;
+        const double hv = (double)hvN;
+        if (g0 + 64 < n) {
+            posN = g0 + 64 + lane < n ? pos[g0 + 64 + lane] : 0;
+            hvN = g0 + 64 + lane < n ? val[g0 + 64 + lane] : T(0);
+        }
+        const int m = n - g0 < 64 ? n - g0 : 64;
+        double wv = 0.0;
+        for (int q = 0; q < m; q++) {
+            const int tp = __builtin_amdgcn_readlane(p, q);
+            if (tprev >= 0) {                                          // across the observed ticks since the last gap
+                int g = tp - tprev - 1;
+#pragma unroll
+                for (int b = 0; b < 5; b++) if (g & (1 << b)) advance(pw + b * NN);
+                g >>= 5;
+#pragma unroll
+                for (int lv = 0; lv < 6; lv++) if (g & (1 << lv)) advance(c64 + Lay::SP + lv * Lay::LS);
+                for (g >>= 6; g > 0; g--) { advance(c64 + Lay::SP + 5 * Lay::LS); advance(c64 + Lay::SP + 5 * Lay::LS); }       // 2048 ticks at a time
+            }
+            const double w = read_lane(hv, q) + wave_sum_dpp(lane < D ? ha * err : 0.0);
+            advance(pw);                                               // through the gap: e <- AKHA e + K w
+            err = fma(kk, w, err);
+            wv = lane == q ? w : wv;
+            tprev = tp;
+        }
+        if (lane < m) wout[g0 + lane] = (T)wv;
+        wild |= !(fabs(wv) < (sizeof(T) == 8 ? 1e300 : 1e37));
+    }
+    return __builtin_amdgcn_ballot_w64(wild) == 0;                     // every fill value finite
 }
 
 // Register caps of the two kernels below: what the plain sweep of the same model happens to fit (fp64: 256 = two waves per SIMD; fp32: three at
@@ -1040,10 +1131,12 @@ template <typename T, int DB, int J, int WPB>
 __global__ void __launch_bounds__(64 * WPB, (x_gaps_min_waves<T, DB * J>()))
 filter_x_gaps_a_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, const T* __restrict__ cbT, const double* __restrict__ cb64, const T* xin0,
                        const int* __restrict__ flags, const double* __restrict__ link_state /* the first pass's hand-over records */,
-                       const T* __restrict__ imp /* [L][kGapSMax] impulse responses */, int* gpos, T* gval /* [L][gcap] scratch: the gaps' ticks and values */, size_t gcap,
-                       int* __restrict__ gstat /* [L] out: 2 * gaps + 1 if solved, else 2 * the reason why not */) {
+                       const T* __restrict__ imp /* [L][kGapSMax] impulse responses */, int* gpos, T* gval /* [L][gcap] scratch: the gaps' ticks and predictions */,
+                       T* gw /* [L][gcap] out: their fill values */, size_t gcap,
+                       int* __restrict__ gstat /* [L] out: 2 * gaps + 1 if solved (bit 30: by the state form), else 2 * the reason why not */) {
     constexpr int D = DB * J, STRIDE = kChunkX + 16 / (int)sizeof(T);
     static_assert(sizeof(T) * 64 * STRIDE >= sizeof(T) * kGapSMax + (sizeof(int) + sizeof(double)) * kGapRing, "the recursion's table and ring borrow the wave's tile");
+    static_assert(sizeof(T) * 64 * STRIDE >= sizeof(double) * 5 * D * D, "so do the state form's powers");
     __shared__ __attribute__((aligned(16))) T tiles[WPB][64 * STRIDE];
     __shared__ T carries[WPB][D];
     __shared__ int glds[WPB][128];
@@ -1058,8 +1151,15 @@ filter_x_gaps_a_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t 
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");               // the lists: written above, read below, by this wave
     wave_lds_fence();
     const int n_gaps = __builtin_amdgcn_readfirstlane(gio.count);
-    const int why = gap_solve_wave<T>(imp + l * kGapSMax, gio.pos, gio.val, n_gaps, Tlen, lane, reinterpret_cast<unsigned char*>(tiles[wave]));
-    if (lane == 0) gstat[l] = why == 0 ? 2 * n_gaps + 1 : 2 * why;
+    unsigned char* lds = reinterpret_cast<unsigned char*>(tiles[wave]);
+    int why = gap_solve_wave<T>(imp + l * kGapSMax, gio.pos, gio.val, gw + l * gcap, n_gaps, Tlen, lane, lds);
+    int form = 0;
+    if (why == 2 || why == 3) {                                      // a long memory, or many gaps inside it: the state form
+        wave_lds_fence();
+        why = gap_solve_states<T, D>(cb64 + l * XC<D>::SIZE, gio.pos, gio.val, gw + l * gcap, n_gaps, lane, lds) ? 0 : 5;
+        form = 1 << 30;
+    }
+    if (lane == 0) gstat[l] = why == 0 ? (2 * n_gaps + 1) | form : 2 * why;
 }
 
 // second sweep: the gaps filled with their own predictions (a latent the recursion gave up keeps its flag: the second pass takes it)
@@ -1068,7 +1168,7 @@ __global__ void __launch_bounds__(64 * WPB, (x_gaps_min_waves<T, DB * J>()))
 filter_x_gaps_b_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t L, const T* __restrict__ cbT, const double* __restrict__ cb64,
                        const T* xin0, T* x, T* __restrict__ yhat, double* __restrict__ nll, size_t ldo,
                        int* __restrict__ flags /* cleared here */, const double* __restrict__ link_state,
-                       const int* __restrict__ gpos, const T* __restrict__ gval, size_t gcap, const int* __restrict__ gstat) {
+                       const int* __restrict__ gpos, const T* __restrict__ gw, size_t gcap, const int* __restrict__ gstat) {
     constexpr int D = DB * J, STRIDE = kChunkX + 16 / (int)sizeof(T);
     __shared__ __attribute__((aligned(16))) T tiles[WPB][64 * STRIDE];
     __shared__ T carries[WPB][D];
@@ -1079,13 +1179,13 @@ filter_x_gaps_b_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t 
     const int stat = gstat[l];
     if (!(stat & 1)) return;
     GapIO<T> gio;
-    gio.pos = const_cast<int*>(gpos) + l * gcap; gio.val = const_cast<T*>(gval) + l * gcap; gio.lds = nullptr; gio.resume = link_state + l * kLinkState;
+    gio.pos = const_cast<int*>(gpos) + l * gcap; gio.val = const_cast<T*>(gw) + l * gcap; gio.lds = nullptr; gio.resume = link_state + l * kLinkState;
     gio.count = 0; gio.patch = true;
     filter_x_body<T, DB, J, WRITE, NLL, false, false, 2>(Ty, Tlen, ld, cbT, cb64, xin0, x, yhat, nll, 1, 0, nullptr, ldo, nullptr, nullptr,
                                                          l, 0, lane, tiles[wave], carries[wave], &gio);
     if (lane == 0) {
         // the gaps were swept as observations that equal their predictions: v = 0, but counted (ihgp.h:204-209 does not).  Nothing observed: exactly 0
-        const int n_gaps = stat >> 1;
+        const int n_gaps = (stat & 0x3FFFFFFF) >> 1;
         if (NLL) nll[l] = (size_t)n_gaps == Tlen ? 0.0 : nll[l] - 0.5 * (double)n_gaps * cb64[l * XC<D>::SIZE + XC<D>::LOGS];
         flags[l] = 0;
     }
@@ -1777,9 +1877,9 @@ int launch_x(const void* Ty, size_t Tlen, size_t ld, size_t L, const T* cbT, con
         if constexpr (J >= 2) {
             if (pass_mode == 5) {
                 hipLaunchKernelGGL((filter_x_gaps_a_kernel<T, DB, J, WPB>), grid, block, 0, stream, ty, Tlen, ld, L, cbT, cb64, xi, (const int*)link_flags,
-                                   (const double*)link_state, static_cast<const T*>(ga->imp), ga->gpos, static_cast<T*>(ga->gval), ga->gcap, ga->gstat);
+                                   (const double*)link_state, static_cast<const T*>(ga->imp), ga->gpos, static_cast<T*>(ga->gval), static_cast<T*>(ga->gw), ga->gcap, ga->gstat);
 #define MOIHGP_X_GAPS(W_, N_) hipLaunchKernelGGL((filter_x_gaps_b_kernel<T, DB, J, W_, N_, WPB>), grid, block, 0, stream, ty, Tlen, ld, L, cbT, cb64, xi, xs, yh, nll, ldo, \
-                                                 link_flags, (const double*)link_state, (const int*)ga->gpos, static_cast<const T*>(ga->gval), ga->gcap, (const int*)ga->gstat)
+                                                 link_flags, (const double*)link_state, (const int*)ga->gpos, static_cast<const T*>(ga->gw), ga->gcap, (const int*)ga->gstat)
                 if (yhat && nll) MOIHGP_X_GAPS(true, true);
                 else if (yhat) MOIHGP_X_GAPS(true, false);
                 else if (nll) MOIHGP_X_GAPS(false, true);
