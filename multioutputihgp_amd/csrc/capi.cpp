@@ -813,7 +813,10 @@ static int filter_stream_io_impl(moihgp_gp* gp, int dtype, const void* Ty, size_
         // 2 x Matern-5/2 0.81 -> 0.45 ms; 2 x Matern-3/2 at the bench's draw, 13 % of them slow, 0.37 -> 0.63)
         const bool impute = !plain_x && gp->L >= 1024 && T > 0 && gp->opt_filter_split == 0 && (yhat || nll) &&
                             (gp->opt_filter_impute == 1 || (gp->opt_filter_impute == -1 && (gp->d >= 8 || gp->n_unstable[3] == 0)));
-        if (impute) {
+        // (its scratch is 12 or 20 bytes per tick and latent -- the lists of gaps, sized for the worst case: beyond 16 GB (MOIHGP_GAP_BANK_GB) the stream
+        // is too long for one call's worth of it and the second pass alone takes the gaps, as before round 4; slabs of a long stream stay below)
+        static const size_t gap_bank_limit = []() { const char* e = getenv("MOIHGP_GAP_BANK_GB"); const double gb = e ? atof(e) : 16.0; return (size_t)(gb * 1073741824.0); }();
+        if (impute && gap_bank_bytes(gp->d, dtype, gp->L, T) <= gap_bank_limit) {
             const size_t need = gap_bank_bytes(gp->d, dtype, gp->L, T);
             if (gp->gap_cap < need) {
                 if (gp->dgap) { MOIHGP_HIP_FATAL(hipDeviceSynchronize()); MOIHGP_HIP_FATAL(hipFree(gp->dgap)); gp->dgap = nullptr; gp->gap_cap = 0; }
