@@ -88,7 +88,7 @@ struct moihgp_gp {
     int polar_warm = 0;        // dpolar holds the outlying subspace of the previous polar factor (polar_deflate.hip warm start)
     int opt_filter_impute = -1; // option "filter_impute": missing ticks of the stacked many-latent sweep by imputation (filter_x_gaps_a / _b_kernel): -1 = for d >= 8,
                                 // 0 never, 1 always
-    void* dgap = nullptr;       // its compact bank (gap_bank_bytes), on first use
+    void* dgap = nullptr;       // its scratch: impulse responses and the lists of gaps (gap_bank_bytes), on first use
     size_t gap_cap = 0;
     unsigned long long cb_version = 1;        // bumped whenever the constant blocks are rebuilt
     unsigned long long gap_imp_version = 0;   // cb_version the bank's impulse responses were swept for

@@ -93,7 +93,7 @@ __device__ inline void load_replay_const(P cu /* uniform view of the latent's bl
 
 // DPP form (fp64, d = 9 and 12): tick by tick, HA and K through slabs; the d = 12 instantiation sits at 256 registers exactly (two waves
 // per SIMD), which the grouped form below would overflow.
-// PRED (gaps_x.hip's first sweep): the tile receives the PREDICTED observation HA x (pre-step) instead of the filtered mean xnew(0, 0) -- as
+// PRED (the imputation's first sweep and the filters' impulse responses: GAPS = 1 / 3 of filter_x_body): the tile receives the PREDICTED observation HA x (pre-step) instead of the filtered mean xnew(0, 0) -- as
 // y - v, which at a tick whose y is zero is HA x exactly
 template <typename T, int DB, int J, bool WRITE, bool NLL, bool PRED = false>
 __device__ inline void replay_dpp(const T (&a)[J * DB * DB], const T& ha, const T& kk, T* tile_lane, T* carry, int lane, int n, int head,
@@ -1022,7 +1022,6 @@ __device__ __forceinline__ int gap_solve_wave(const T* __restrict__ imp, const i
             const int k = p - pq - 1;                                  // (idle lanes: negative)
             w = fma((double)st[(unsigned)k < (unsigned)kdec ? k : kZero], wq, w);
         }
-#pragma unroll 4
         for (int q = 0; q + 1 < m; q++) {                              // inside the block: lane q is final when its turn comes
             const double wq = read_lane(w, q);
             const int k = p - __builtin_amdgcn_readlane(p, q) - 1;     // (lanes up to q, idle lanes: negative)

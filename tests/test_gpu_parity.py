@@ -1044,6 +1044,45 @@ def test_stacked_gaps_by_imputation(env, kern, dtype, nanf, monkeypatch, capfd):
     assert rel_err(n0[sub].cpu().numpy()[tame], nll[sub].cpu().numpy()[tame]) < tol
 
 
+@pytest.mark.parametrize("T", [1, 2, 31, 32, 33, 64, 2047, 2048, 2049, 4113])
+@pytest.mark.parametrize("kern,dtype", [("Matern52x4", torch.float64), ("Matern52x3", torch.float32), ("Matern32x4", torch.float64)])
+def test_imputation_at_awkward_lengths(env, kern, dtype, T):
+    """The imputation sweeps at stream lengths around the chunk (32 ticks) and segment (2048) boundaries, down to a single tick: 10 % of the ticks
+    missing, a gap at the first and at the last tick, one series without any observation, one that is all gaps but its last tick; the stream
+    continued from a carried state; against the oracle and against the second pass alone (filter_impute = 0)."""
+    J = int(kern[-1])
+    L = 1024
+    rng = np.random.default_rng(7 * T + J)
+    prm = synth_params_stacked(L, J, rng)
+    bank = env["streams"].LatentBank(0.1, prm, kernel=kern)
+    bank.set_option("filter_impute", 1)
+    Ty = synth(L, T, rng)
+    Ty[rng.random((L, T)) < 0.1] = np.nan
+    Ty[0, :] = synth(1, T, rng)[0]                        # a gap-free latent
+    Ty[1, 0] = np.nan; Ty[2, T - 1] = np.nan
+    Ty[3, :] = np.nan
+    Ty[4, :T - 1] = np.nan; Ty[4, T - 1] = 0.3
+    sub = np.concatenate([np.arange(8), np.sort(rng.choice(np.arange(8, L), size=24, replace=False))])
+    igps = env["cref"].ihgp_array(kern, 0.1, prm[sub])
+    x0 = 0.1 * rng.standard_normal((L, bank.d))
+    o = env["cref"].filter_stream(igps, np.ascontiguousarray(Ty[sub]), x0=np.ascontiguousarray(x0[sub]), nthreads=4)
+    xs = torch.from_numpy(x0).to(device="cuda", dtype=dtype)
+    yhat, xT, nll = bank.filter(to_dev(Ty, dtype), T=T, x_start=xs)
+    torch.cuda.synchronize()
+    tol = (FP64_TIGHT if dtype == torch.float64 else FP32_TOL) * 10
+    tame = np.nan_to_num(np.abs(o["yhat"]), nan=0.0).max(axis=1) < 1e6
+    yg = yhat[sub][:, :T].cpu().numpy().astype(np.float64)
+    assert rel_err_rows(yg[tame], o["yhat"][tame]) < tol
+    assert rel_err(xT[sub].cpu().numpy()[tame], o["x"][tame]) < tol
+    a, b = nll[sub].cpu().numpy()[tame], o["nll_per_latent"][tame]
+    assert np.all(np.abs(a - b) <= tol * np.maximum(np.abs(b), 1.0)) and nll[3].item() == 0.0
+    bank.set_option("filter_impute", 0)
+    y0, x0_, n0 = bank.filter(to_dev(Ty, dtype), T=T, x_start=xs)
+    torch.cuda.synchronize()
+    assert rel_err_rows(y0[sub][:, :T].cpu().numpy().astype(np.float64)[tame], yg[tame]) < tol
+    assert rel_err(x0_[sub].cpu().numpy()[tame], xT[sub].cpu().numpy()[tame]) < tol
+
+
 def test_fp32_bank_sweeps_unscannable_latents_in_fp64(env, monkeypatch, capfd):
     """Many latents, fp32 streams: a mildly unstable latent (the literal DARE of dare.h:23 returns such gains: rho(AKHA) of 1.04 .. 1.4) has scan tables
     that leave the fp32 range but not the fp64 one.  Tick by tick in the fp32 kernel one of them holds the whole launch (BASELINE-sized Matern32x2
