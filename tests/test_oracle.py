@@ -407,3 +407,49 @@ def test_fair_cpu_baseline_equals_the_literal_sweep(kern, dtype, layout):
     assert np.abs(ya[tame] - yb[tame]).max() <= tol * np.abs(ya[tame]).max()
     assert np.abs(a["x"][tame] - b["x"][tame]).max() <= tol * max(np.abs(a["x"][tame]).max(), 1e-3)
     assert np.abs(a["nll_per_latent"][tame] - b["nll_per_latent"][tame]).max() <= tol * np.abs(a["nll_per_latent"][tame]).max()
+
+
+@pytest.mark.parametrize("kern,frac", [("Matern52x4", 0.05), ("Matern52x3", 0.3), ("Matern52x2", 0.01), ("Matern32x2", 0.1)])
+def test_missing_ticks_equal_observations_at_their_own_predictions(kern, frac):
+    """The identity behind the GPU's imputation sweeps (csrc/recursion_x.hip filter_x_gaps_a / _b_kernel), checked on the CPU with the oracle alone:
+    a missing tick (ihgp.h:83-87: x <- A x, no likelihood term) is an observation equal to its own prediction w_p = HA x_p, and the w_p follow from a
+    sweep with the gaps set to ZERO by the scalar recursion  w_p = HA x'_p + sum_{gaps q < p} s_(p-q-1) w_q,  s_k = HA AKHA^k K.  Filling the gaps
+    with w and sweeping again reproduces the literal sweep's filtered means and end state, and its NLL once the gaps' log-terms are taken out."""
+    J = int(kern[-1]); d = (2 if kern.startswith("Matern32") else 3) * J
+    rng = np.random.default_rng(11 + d)
+    L, T = 6, 700
+    cols = []
+    for _ in range(J):
+        cols += [rng.uniform(0.5, 2, L), rng.uniform(0.5, 2, L)]
+    prm = np.column_stack(cols + [rng.uniform(0.05, 0.2, L)])
+    igps = cref.ihgp_array(kern, 0.1, prm)
+    t = np.arange(T)
+    Ty = np.sin(0.05 * t[None, :] * (1 + np.arange(L)[:, None] % 7)) + 0.1 * rng.standard_normal((L, T))
+    miss = rng.random((L, T)) < frac
+    miss[0, 0] = miss[1, T - 1] = True
+    Tn = Ty.copy(); Tn[miss] = np.nan
+    lit = cref.filter_stream(igps, Tn)                                  # the reference's treatment of the gaps
+    Tz = Ty.copy(); Tz[miss] = 0.0
+    filled = Tz.copy()
+    for l in range(L):
+        AKHA, K, HA = igps[l].mat("AKHA"), igps[l].mat("K"), igps[l].mat("HA")
+        if max(abs(np.linalg.eigvals(AKHA))) >= 0.999:
+            filled[l] = np.nan                                          # (an unstable draw of the literal DARE: imputation does not apply, see DESIGN 3.7)
+            continue
+        s = np.empty(T); u = K.copy()
+        for k in range(T):
+            s[k] = HA @ u; u = AKHA @ u
+        x = np.zeros(d); hx = np.empty(T)                               # zero-filled sweep: predicted observations HA x'
+        for k in range(T):
+            hx[k] = HA @ x; x = AKHA @ x + K * Tz[l, k]
+        gaps = np.flatnonzero(miss[l]); w = np.empty(len(gaps))
+        for i, p in enumerate(gaps):
+            w[i] = hx[p] + sum(s[p - q - 1] * w[j] for j, q in enumerate(gaps[:i]))
+        filled[l, gaps] = w
+    ok = ~np.isnan(filled).any(axis=1)
+    assert ok.sum() >= L - 2
+    again = cref.filter_stream(cref.ihgp_array(kern, 0.1, prm[ok]), np.ascontiguousarray(filled[ok]))
+    assert rel_err(again["yhat"], lit["yhat"][ok]) < 1e-10 and rel_err(again["x"], lit["x"][ok]) < 1e-10
+    logS = np.array([np.log(g.mat("S")) for g, k in zip(igps, ok) if k])
+    n_gaps = miss[ok].sum(axis=1)
+    assert rel_err(again["nll_per_latent"] - 0.5 * n_gaps * logS, lit["nll_per_latent"][ok]) < 1e-10
