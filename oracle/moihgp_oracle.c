@@ -811,7 +811,7 @@ double orc_filter_stream_f32(const orc_ihgp* g, size_t L, size_t T, const float*
 #define ORC_DEF_FAST(N, REAL, FB, SUF)                                                                                            \
 static void fast_block_##N##SUF(const orc_ihgp* g, size_t nb, size_t T, const REAL* Ty, size_t ld, int layout, size_t l0,         \
                                 REAL* x, REAL* yhat, double* nllp) {                                                             \
-    REAL A[N * N][FB], K[N][FB], HA[N][FB], xs[N][FB], yb[FT][FB], ob[FT][FB], part[FB];                                          \
+    REAL A[N * N][FB], K[N][FB], HA[N][FB], xs[N][FB], yb[FT][FB], ob[FT][FB], part[FB], pcnt[FB];                                \
     double Sinv[FB], logS[FB], acc[FB], cnt[FB];                                                                                  \
     for (size_t b = 0; b < FB; b++) {                                                                                             \
         const orc_ihgp* gl = &g[b < nb ? b : 0];                                                                                  \
@@ -821,7 +821,13 @@ static void fast_block_##N##SUF(const orc_ihgp* g, size_t nb, size_t T, const RE
     }                                                                                                                             \
     for (size_t t0 = 0; t0 < T; t0 += FT) {                                                                                       \
         const size_t tt = T - t0 < FT ? T - t0 : FT;                                                                              \
-        if (layout == 0) {                                                                                                        \
+        if (layout == 0 && nb == FB) {          /* a full block: tick-major copy, the FB strided loads of a tick as one gather */  \
+            const REAL* r0 = Ty + l0 * ld + t0;                                                                                   \
+            for (size_t t = 0; t < tt; t++) {                                                                                     \
+                _Pragma("omp simd")                                                                                               \
+                for (size_t b = 0; b < FB; b++) yb[t][b] = r0[b * ld + t];                                                        \
+            }                                                                                                                     \
+        } else if (layout == 0) {                                                                                                 \
             for (size_t b = 0; b < FB; b++) {                                                                                     \
                 if (b < nb) { const REAL* r = Ty + (l0 + b) * ld + t0; for (size_t t = 0; t < tt; t++) yb[t][b] = r[t]; }         \
                 else for (size_t t = 0; t < tt; t++) yb[t][b] = (REAL)NAN;                                                        \
@@ -829,7 +835,7 @@ static void fast_block_##N##SUF(const orc_ihgp* g, size_t nb, size_t T, const RE
         } else {                                                                                                                  \
             for (size_t t = 0; t < tt; t++) { const REAL* r = Ty + (t0 + t) * ld + l0; for (size_t b = 0; b < FB; b++) yb[t][b] = b < nb ? r[b] : (REAL)NAN; } \
         }                                                                                                                         \
-        for (size_t b = 0; b < FB; b++) part[b] = (REAL)0;                                                                        \
+        for (size_t b = 0; b < FB; b++) { part[b] = (REAL)0; pcnt[b] = (REAL)0; }     /* (one scalar type inside the simd loop) */ \
         for (size_t t = 0; t < tt; t++) {                                                                                         \
             _Pragma("omp simd")                                                                                                   \
             for (size_t b = 0; b < FB; b++) {                                                                                     \
@@ -839,15 +845,22 @@ static void fast_block_##N##SUF(const orc_ihgp* g, size_t nb, size_t T, const RE
                 for (int i = 0; i < N; i++) hx += HA[i][b] * xs[i][b];                                                            \
                 const REAL v = obs ? y - hx : (REAL)0;                                                                            \
                 part[b] += v * v;                                                                                                 \
-                cnt[b] += obs ? 1.0 : 0.0;                                                                                        \
+                pcnt[b] += obs ? (REAL)1 : (REAL)0;                                                                               \
                 for (int i = 0; i < N; i++) { REAL s_ = K[i][b] * v; for (int k = 0; k < N; k++) s_ += A[i * N + k][b] * xs[k][b]; xn[i] = s_; } \
                 for (int i = 0; i < N; i++) xs[i][b] = xn[i];                                                                     \
                 ob[t][b] = xn[0];                                                                                                 \
             }                                                                                                                     \
         }                                                                                                                         \
-        for (size_t b = 0; b < FB; b++) acc[b] += (double)part[b];                                                                \
+        for (size_t b = 0; b < FB; b++) { acc[b] += (double)part[b]; cnt[b] += (double)pcnt[b]; }                                 \
         if (yhat) {                                                                                                               \
-            if (layout == 0) { for (size_t b = 0; b < nb; b++) { REAL* r = yhat + (l0 + b) * ld + t0; for (size_t t = 0; t < tt; t++) r[t] = ob[t][b]; } } \
+            if (layout == 0 && nb == FB) {                                                                                        \
+                REAL* r0 = yhat + l0 * ld + t0;                                                                                   \
+                for (size_t t = 0; t < tt; t++) {                                                                                 \
+                    _Pragma("omp simd")                                                                                           \
+                    for (size_t b = 0; b < FB; b++) r0[b * ld + t] = ob[t][b];                                                    \
+                }                                                                                                                 \
+            }                                                                                                                     \
+            else if (layout == 0) { for (size_t b = 0; b < nb; b++) { REAL* r = yhat + (l0 + b) * ld + t0; for (size_t t = 0; t < tt; t++) r[t] = ob[t][b]; } } \
             else { for (size_t t = 0; t < tt; t++) { REAL* r = yhat + (t0 + t) * ld + l0; for (size_t b = 0; b < nb; b++) r[b] = ob[t][b]; } } \
         }                                                                                                                         \
     }                                                                                                                             \
