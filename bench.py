@@ -130,9 +130,13 @@ def cpu_baseline(prm, Ty_host, T, nll_gpu_sum, yhat_gpu_sub, sub, kernel="Matern
             t_best = min(t_best, time.perf_counter() - t0)
             reps += 1
         return t_best, reps
-    t_best, reps = best_of(lambda: cref.filter_stream_fast(igps, Ty_host, x0=None, want_yhat=True, nthreads=nthreads, native=native), 10.0)
+    Ty_host = np.ascontiguousarray(Ty_host)
+    yh_buf = np.zeros_like(Ty_host)      # the outputs land in ONE buffer, touched before the clock starts (round 4: a fresh 164 MB array per pass cost
+                                         # 15-20 ms of page faults -- five times the sweep itself on 16 threads, and all of the reported time)
+    t_best, reps = best_of(lambda: cref.filter_stream_fast(igps, Ty_host, x0=None, want_yhat=True, nthreads=nthreads, native=native, yhat_out=yh_buf), 10.0)
     v_opt = L * T / t_best
-    t_gen, reps_gen = best_of(lambda: cref.filter_stream(igps, Ty_host, x0=None, want_yhat=True, nthreads=nthreads, native=native), 6.0)
+    t_gen, reps_gen = best_of(lambda: cref.filter_stream(igps, Ty_host, x0=None, want_yhat=True, nthreads=nthreads, native=native, yhat_out=yh_buf), 6.0)
+    del yh_buf
     ghz = cpu_ghz()
     # (i) reference-shaped: single thread, one call per (tick, latent), heap temporaries (fp64 like the reference)
     import ctypes as C

@@ -302,8 +302,9 @@ class GP:
         self._L.orc_gp_set_literal_ugrad(self._h, int(bool(flag)))
 
 
-def filter_stream(igps, Ty, ld=None, layout=0, x0=None, want_yhat=True, nthreads=1, native=False):
-    """Ty: [L][T] (layout 0) or [T][L] (layout 1) float64 or float32."""
+def filter_stream(igps, Ty, ld=None, layout=0, x0=None, want_yhat=True, nthreads=1, native=False, yhat_out=None):
+    """Ty: [L][T] (layout 0) or [T][L] (layout 1) float64 or float32.  yhat_out: a buffer like Ty to write the means into (timing loops: a fresh
+    164 MB array per call costs more in page faults than the sweep itself on 16 threads)."""
     Lb = lib(native, isinstance(igps[0], OrcIHGPX))
     f32 = Ty.dtype == np.float32
     Ty = np.ascontiguousarray(Ty)
@@ -315,7 +316,8 @@ def filter_stream(igps, Ty, ld=None, layout=0, x0=None, want_yhat=True, nthreads
     d = igps[0].d
     dt = np.float32 if f32 else np.float64
     x = np.zeros((L, d), dtype=dt) if x0 is None else np.array(x0, dtype=dt).reshape(L, d).copy()
-    yhat = np.zeros_like(Ty) if want_yhat else None
+    yhat = (np.zeros_like(Ty) if yhat_out is None else yhat_out) if want_yhat else None
+    assert yhat is None or (yhat.dtype == Ty.dtype and yhat.shape == Ty.shape and yhat.flags["C_CONTIGUOUS"])
     nll_l = np.zeros(L)
     if f32:
         nll = Lb.orc_filter_stream_f32(igps, L, T, _ptr(Ty, _fp), ld, layout, _ptr(x, _fp), _ptr(yhat, _fp), _ptr(nll_l), nthreads)
@@ -324,7 +326,7 @@ def filter_stream(igps, Ty, ld=None, layout=0, x0=None, want_yhat=True, nthreads
     return dict(yhat=yhat, x=x, nll=float(nll), nll_per_latent=nll_l)
 
 
-def filter_stream_fast(igps, Ty, ld=None, layout=0, x0=None, want_yhat=True, nthreads=1, native=False):
+def filter_stream_fast(igps, Ty, ld=None, layout=0, x0=None, want_yhat=True, nthreads=1, native=False, yhat_out=None):
     """The fair-optimised CPU baseline (orc_filter_stream_fast: d-specialised, SIMD across latents); same contract as filter_stream."""
     Lb = lib(native, isinstance(igps[0], OrcIHGPX))
     f32 = Ty.dtype == np.float32
@@ -334,7 +336,8 @@ def filter_stream_fast(igps, Ty, ld=None, layout=0, x0=None, want_yhat=True, nth
     d = igps[0].d
     dt = np.float32 if f32 else np.float64
     x = np.zeros((L, d), dtype=dt) if x0 is None else np.array(x0, dtype=dt).reshape(L, d).copy()
-    yhat = np.zeros_like(Ty) if want_yhat else None
+    yhat = (np.zeros_like(Ty) if yhat_out is None else yhat_out) if want_yhat else None
+    assert yhat is None or (yhat.dtype == Ty.dtype and yhat.shape == Ty.shape and yhat.flags["C_CONTIGUOUS"])
     nll_l = np.zeros(L)
     nll = Lb.orc_filter_stream_fast(igps, L, T, Ty.ctypes.data, ld, layout, x.ctypes.data, yhat.ctypes.data if want_yhat else None, _ptr(nll_l), nthreads, int(f32))
     return dict(yhat=yhat, x=x, nll=float(nll), nll_per_latent=nll_l)

@@ -808,6 +808,13 @@ double orc_filter_stream_f32(const orc_ihgp* g, size_t L, size_t T, const float*
 #define FB64 8
 #define FB32 16
 #define FT 64
+/* Series-major streams reach the tick-major tile either row by row (scalar copies: FT contiguous loads per latent) or tick by tick (one
+ * gather / scatter instruction per tick).  Measured with the vectorised tick loop: Xeon (AVX-512, 2.1 GHz) 2.7 ns per step and thread with
+ * gathers against 3.9 without; the GPU boxes' EPYC -- whose gathers and scatters are microcoded -- the other way round (bench.py cpu_baseline).
+ * Off unless asked (make native FASTFLAGS=-DORC_FAST_GATHER=1). */
+#ifndef ORC_FAST_GATHER
+#define ORC_FAST_GATHER 0
+#endif
 
 #define ORC_DEF_FAST(N, REAL, FB, SUF, UINT)                                                                                            \
 static void fast_block_##N##SUF(const orc_ihgp* g, size_t nb, size_t T, const REAL* Ty, size_t ld, int layout, size_t l0,         \
@@ -822,7 +829,7 @@ static void fast_block_##N##SUF(const orc_ihgp* g, size_t nb, size_t T, const RE
     }                                                                                                                             \
     for (size_t t0 = 0; t0 < T; t0 += FT) {                                                                                       \
         const size_t tt = T - t0 < FT ? T - t0 : FT;                                                                              \
-        if (layout == 0 && nb == FB) {          /* a full block: tick-major copy, the FB strided loads of a tick as one gather */  \
+        if (ORC_FAST_GATHER && layout == 0 && nb == FB) {   /* a full block: the FB strided loads of a tick as one gather */      \
             const REAL* r0 = Ty + l0 * ld + t0;                                                                                   \
             for (size_t t = 0; t < tt; t++) {                                                                                     \
                 _Pragma("omp simd")                                                                                               \
@@ -858,7 +865,7 @@ static void fast_block_##N##SUF(const orc_ihgp* g, size_t nb, size_t T, const RE
         }                                                                                                                         \
         for (size_t b = 0; b < FB; b++) { acc[b] += (double)part[b]; cnt[b] += (double)pcnt[b]; }                                 \
         if (yhat) {                                                                                                               \
-            if (layout == 0 && nb == FB) {                                                                                        \
+            if (ORC_FAST_GATHER && layout == 0 && nb == FB) {                                                                     \
                 REAL* r0 = yhat + l0 * ld + t0;                                                                                   \
                 for (size_t t = 0; t < tt; t++) {                                                                                 \
                     _Pragma("omp simd")                                                                                           \
