@@ -809,11 +809,11 @@ double orc_filter_stream_f32(const orc_ihgp* g, size_t L, size_t T, const float*
 #define FB32 16
 #define FT 64
 /* Series-major streams reach the tick-major tile either row by row (scalar copies: FT contiguous loads per latent) or tick by tick (one
- * gather / scatter instruction per tick).  Measured with the vectorised tick loop: Xeon (AVX-512, 2.1 GHz) 2.7 ns per step and thread with
- * gathers against 3.9 without; the GPU boxes' EPYC -- whose gathers and scatters are microcoded -- the other way round (bench.py cpu_baseline).
- * Off unless asked (make native FASTFLAGS=-DORC_FAST_GATHER=1). */
+ * gather / scatter per tick).  Measured with the vectorised tick loop on 16 threads of the GPU boxes' EPYC 9575F (bench.py cpu_baseline, C3
+ * shape): 18.8e9 steps/s with gathers (4.3 cycles per step and thread), 14.2e9 without; a 2.1 GHz AVX-512 Xeon: 2.7 against 3.3 ns per step
+ * and thread.  On unless asked otherwise (make native FASTFLAGS=-DORC_FAST_GATHER=0). */
 #ifndef ORC_FAST_GATHER
-#define ORC_FAST_GATHER 0
+#define ORC_FAST_GATHER 1
 #endif
 
 #define ORC_DEF_FAST(N, REAL, FB, SUF, UINT)                                                                                            \
