@@ -1120,6 +1120,42 @@ __device__ __forceinline__ bool gap_solve_states(const double* __restrict__ c64,
     return __builtin_amdgcn_ballot_w64(wild) == 0;                     // every fill value finite
 }
 
+// Is imputation safe for this latent over a stream of Tlen ticks?  Not if its filter is unstable (rho(AKHA) > 1: the literal DARE of dare.h:23 returns
+// such gains for part of the parameter box): the sweep with zeros at the gaps then departs from the true one like rho^t and x = x' + e cancels
+// that many digits -- 1e11 of them for rho = 1.0026 over 16384 ticks (tools/fuzz_campaign.py, seed 401: a latent whose growing mode is so
+// weakly observed that its impulse response still DECAYS over the 1024 ticks of the table, which is why the table alone is not asked).  Growth is
+// read off AKHA^4096 (the latent's scan level AKHA^1024, squared twice here): max|AKHA^4096|^(Tlen / 4096) bounds what a rounding error can
+// grow to; beyond 1e4 (fp64 streams) / 1e2 (fp32) the latent is left to the second pass.  lds: D * D doubles x 2.
+template <typename T, int D>
+__device__ __forceinline__ bool gap_filter_grows(const double* __restrict__ c64, const size_t Tlen, const int lane, unsigned char* lds) {
+    using Lay = XC<D>;
+    constexpr int NN = D * D;
+    double* a = reinterpret_cast<double*>(lds);
+    double* b = a + NN;
+    for (int e = lane; e < NN; e += 64) a[e] = c64[Lay::SP + 5 * Lay::LS + e];      // AKHA^1024
+    wave_lds_fence();
+    for (int sq = 0; sq < 2; sq++) {
+        const double* src = sq ? b : a;
+        double* dst = sq ? a : b;
+        for (int e = lane; e < NN; e += 64) {
+            const int i = e / D, j = e % D;
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; k++) acc = fma(src[i * D + k], src[k * D + j], acc);
+            dst[e] = acc;
+        }
+        wave_lds_fence();
+    }
+    double big = 0.0;                                                   // (NaN: treated as growing)
+    bool nan = false;
+    for (int e = lane; e < NN; e += 64) { const double v = fabs(a[e]); big = fmax(big, v); nan |= !(v == v); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) big = fmax(big, __shfl_xor(big, o));
+    const bool grows = __builtin_amdgcn_ballot_w64(nan) != 0 || (big > 1.0 && log(big) * ((double)Tlen / 4096.0) > (sizeof(T) == 8 ? 9.2 : 4.6));
+    wave_lds_fence();
+    return __builtin_amdgcn_readfirstlane((int)grows) != 0;
+}
+
 // Register caps of the two kernels below: what the plain sweep of the same model happens to fit (fp64: 256 = two waves per SIMD; fp32: three at
 // d = 12, four below) -- the gap bookkeeping costs 4 .. 16 registers more, and a few spilled values are cheaper than the wave they would cost.
 template <typename T, int D>
@@ -1143,6 +1179,11 @@ filter_x_gaps_a_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t l = (size_t)blockIdx.x * WPB + wave;
     if (l >= L || flags[l] == 0) return;                             // no workgroup barrier below
+    unsigned char* lds = reinterpret_cast<unsigned char*>(tiles[wave]);
+    if (gap_filter_grows<T, D>(cb64 + l * XC<D>::SIZE, Tlen, lane, lds)) {      // an unstable filter: not for imputation (its flag stays: second pass)
+        if (lane == 0) gstat[l] = 2 * 1;
+        return;
+    }
     GapIO<T> gio;
     gio.pos = gpos + l * gcap; gio.val = gval + l * gcap; gio.lds = glds[wave]; gio.resume = link_state + l * kLinkState; gio.count = 0; gio.patch = false;
     filter_x_body<T, DB, J, true, false, false, false, 1>(Ty, Tlen, ld, cbT, cb64, xin0, nullptr, nullptr, nullptr, 1, 0, nullptr, 0, nullptr, nullptr,
@@ -1150,7 +1191,6 @@ filter_x_gaps_a_kernel(const T* __restrict__ Ty, size_t Tlen, size_t ld, size_t 
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");               // the lists: written above, read below, by this wave
     wave_lds_fence();
     const int n_gaps = __builtin_amdgcn_readfirstlane(gio.count);
-    unsigned char* lds = reinterpret_cast<unsigned char*>(tiles[wave]);
     int why = gap_solve_wave<T>(imp + l * kGapSMax, gio.pos, gio.val, gw + l * gcap, n_gaps, Tlen, lane, lds);
     int form = 0;
     if (why == 2 || why == 3) {                                      // a long memory, or many gaps inside it: the state form
