@@ -1504,6 +1504,11 @@ def test_filter_fuzz_vs_oracle(env, kern, L, T, nanf, dt_, seed):
     yg = yhat[:, :T].cpu().numpy()
     scale = max(np.abs(yo[tame]).max(), 1e-300)
     assert np.abs(yg[tame] - yo[tame]).max() / scale < tol * 10, (kern, L, T, nanf, dt_)
+    # ... and row by row among the latents that stay calm: one unstable latent at 1e16 sets a global scale behind which a wrong ordinary latent hides
+    # (round 4: an imputed latent with an error of 8e11 passed the line above; only its NLL gave it away)
+    calm = np.nan_to_num(np.abs(yo), nan=0.0, posinf=np.inf).max(axis=1) < 1e3
+    if calm.any():
+        assert rel_err_rows(yg[calm].astype(np.float64), yo[calm]) < tol * 10, (kern, L, T, nanf, dt_)
     xscale = max(np.abs(o["x"][tame]).max(), 1e-6 * np.abs(x0).max())         # (an all-missing stream decays the state to ~0)
     assert np.abs(xT.cpu().numpy()[tame] - o["x"][tame]).max() / xscale < tol * 10
     # (the kernel sums v^2 per chunk in the stream's precision: a trajectory beyond ~1e18 squares out of fp32's range, where the
