@@ -1124,8 +1124,10 @@ __device__ __forceinline__ bool gap_solve_states(const double* __restrict__ c64,
 // such gains for part of the parameter box): the sweep with zeros at the gaps then departs from the true one like rho^t and x = x' + e cancels
 // that many digits -- 1e11 of them for rho = 1.0026 over 16384 ticks (tools/fuzz_campaign.py, seed 401: a latent whose growing mode is so
 // weakly observed that its impulse response still DECAYS over the 1024 ticks of the table, which is why the table alone is not asked).  Growth is
-// read off AKHA^4096 (the latent's scan level AKHA^1024, squared twice here): max|AKHA^4096|^(Tlen / 4096) bounds what a rounding error can
-// grow to; beyond 1e4 (fp64 streams) / 1e2 (fp32) the latent is left to the second pass.  lds: D * D doubles x 2.
+// read off the matrix: n2 = max|AKHA^2048|, n4 = max|AKHA^4096| (the latent's scan level AKHA^1024, squared twice here).  What a rounding error
+// can grow to over the stream is bounded by n4 up to 4096 ticks and, where the powers still grow (n4 > n2: by then only a growing mode is
+// left), by n4 (n4 / n2)^((Tlen - 4096) / 2048) beyond; more than 1e4 (fp64 streams) / 1e2 (fp32) and the latent is left to the second pass.
+// lds: D * D doubles x 2.
 template <typename T, int D>
 __device__ __forceinline__ bool gap_filter_grows(const double* __restrict__ c64, const size_t Tlen, const int lane, unsigned char* lds) {
     using Lay = XC<D>;
@@ -1134,25 +1136,31 @@ __device__ __forceinline__ bool gap_filter_grows(const double* __restrict__ c64,
     double* b = a + NN;
     for (int e = lane; e < NN; e += 64) a[e] = c64[Lay::SP + 5 * Lay::LS + e];      // AKHA^1024
     wave_lds_fence();
+    double big[2];
+    bool nan = false;
+#pragma unroll
     for (int sq = 0; sq < 2; sq++) {
         const double* src = sq ? b : a;
         double* dst = sq ? a : b;
+        double m = 0.0;
         for (int e = lane; e < NN; e += 64) {
             const int i = e / D, j = e % D;
             double acc = 0.0;
 #pragma unroll
             for (int k = 0; k < D; k++) acc = fma(src[i * D + k], src[k * D + j], acc);
             dst[e] = acc;
+            m = fmax(m, fabs(acc));
+            nan |= !(acc == acc);
         }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+        big[sq] = m;
         wave_lds_fence();
     }
-    double big = 0.0;                                                   // (NaN: treated as growing)
-    bool nan = false;
-    for (int e = lane; e < NN; e += 64) { const double v = fabs(a[e]); big = fmax(big, v); nan |= !(v == v); }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) big = fmax(big, __shfl_xor(big, o));
-    const bool grows = __builtin_amdgcn_ballot_w64(nan) != 0 || (big > 1.0 && log(big) * ((double)Tlen / 4096.0) > (sizeof(T) == 8 ? 9.2 : 4.6));
-    wave_lds_fence();
+    const double limit = sizeof(T) == 8 ? 9.2 : 4.6;                    // log of 1e4 / 1e2
+    double lg = big[1] > 0.0 ? log(big[1]) : -700.0;
+    if (big[1] > big[0] && big[0] > 0.0 && Tlen > 4096) lg += log(big[1] / big[0]) * ((double)(Tlen - 4096) / 2048.0);
+    const bool grows = __builtin_amdgcn_ballot_w64(nan) != 0 || lg > limit;
     return __builtin_amdgcn_readfirstlane((int)grows) != 0;
 }
 
