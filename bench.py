@@ -561,6 +561,40 @@ def filter_row(name, device, passes=20, warm=150):
     return row
 
 
+def gaps_row(device, name="c5", frac=0.01, passes=10, warm=3):
+    """A filter configuration with a fraction of its ticks missing (NaN: ihgp.h:83-87, :204-209), next to the same sweep without gaps: wall time of
+    all passes per sweep (the many-latent stacked sweep takes such streams by exact imputation since round 4; VERDICT r3 item 6 asked
+    <= 4 x the gap-free sweep at 1 % missing).  Median of three runs of `passes` sweeps, as tools/filternan.py."""
+    from multioutputihgp_amd.streams import LatentBank
+    L2, T2, dt2, k2, desc2 = CONFIGS[name]
+    b2 = LatentBank(0.1, synth_params(L2, 0, np.random.default_rng(SEED), k2), kernel=k2)
+    out = {"workload": f"{desc2}; {100 * frac:g} % of the ticks missing", "state_dim": b2.d, "dtype": "f32" if dt2 == torch.float32 else "f64", "missing_fraction": frac}
+    for tag, dt_ in (("", dt2), ("_f32" if dt2 == torch.float64 else "_f64", torch.float32 if dt2 == torch.float64 else torch.float64)):
+        res = {}
+        for label, fr in (("gap_free", 0.0), ("with_gaps", frac)):
+            Ty2 = synth_stream(L2, 0, T2, dt_, device, SEED + 1)
+            if fr > 0:
+                g = torch.Generator(device=device); g.manual_seed(SEED + 7)
+                Ty2[torch.rand(Ty2.shape, generator=g, device=device) < fr] = float("nan")
+            yh2 = torch.empty_like(Ty2); n2 = torch.empty((L2,), dtype=torch.float64, device=device)
+            x2 = torch.zeros((L2, b2.d), dtype=dt_, device=device); x2z = torch.zeros_like(x2)
+            for _ in range(warm):
+                b2.filter(Ty2, T=T2, x=x2, x_start=x2z, yhat=yh2, nll=n2)
+            reps = []
+            for _ in range(3):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for _ in range(passes):
+                    b2.filter(Ty2, T=T2, x=x2, x_start=x2z, yhat=yh2, nll=n2)
+                torch.cuda.synchronize(); reps.append((time.perf_counter() - t0) / passes)
+            res[label] = sorted(reps)[1] * 1e3
+            del Ty2, yh2
+        out[f"ms_gap_free{tag}"] = res["gap_free"]; out[f"ms_with_gaps{tag}"] = res["with_gaps"]; out[f"ratio{tag}"] = res["with_gaps"] / res["gap_free"]
+    out["ms_per_step"] = out["ms_with_gaps"]; out["value"] = L2 * T2 / (out["ms_with_gaps"] * 1e-3)
+    out["note"] = "wall clock of every pass of the sweep (first pass, the two imputation kernels, second pass), streams resident; round 3: 12-18 x"
+    del b2
+    return out
+
+
 def slab_row(device, passes=5, warm=2, world=1, rank=0, reduce=None):
     """BASELINE.json configs[3] as worded, this rank's part: 4096 latents x 10^5 ticks swept in 10 slabs of 10^4 ticks that carry the state,
     the per-latent NLLs summed over the slabs and (N > 1) all-reduced once per pass.  3.3 GB working set per rank: cold by construction."""
@@ -1059,6 +1093,10 @@ def main():
                     others["c4"] = slab_row(device)
                 except Exception as e:
                     others["c4"] = {"error": str(e)}
+                try:
+                    others["c5gaps"] = gaps_row(device)            # configs[4]'s shape with 1 % of the ticks missing, fp64 and fp32
+                except Exception as e:
+                    others["c5gaps"] = {"error": str(e)}
                 try:
                     lr = learn_row(3, 1, cpu=False, windows=(128,))
                     others["c3learn"] = {"workload": lr["config"]["workload"], "dtype": "f64", "ms_per_step": lr["ms_per_step"], "value": lr["value"],
